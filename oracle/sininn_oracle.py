@@ -208,6 +208,16 @@ class DenseBlockOracle(nn.Module):
         super().__init__()
         self.convs = nn.ModuleList([nn.Conv2d(cin + i * gc, gc if i < 4 else cout, 3, 1, 1)
                                     for i in range(5)])
+        # archs.py:84-86,100-132: xavier_normal*0.1 on conv1-4, kaiming_normal*0 on conv5, zero biases
+        # (same RNG draw order as the reference so a seeded net reproduces its weights)
+        for i, conv in enumerate(self.convs):
+            if i < 4:
+                nn.init.xavier_normal_(conv.weight)
+                conv.weight.data *= 0.1
+                conv.bias.data.zero_()
+        nn.init.kaiming_normal_(self.convs[4].weight, a=0, mode='fan_in')
+        self.convs[4].weight.data *= 0
+        self.convs[4].bias.data.zero_()
 
     def forward(self, x):
         feats = [x]

@@ -158,9 +158,20 @@ def test_adam_matches_torch():
 
 
 def test_g5_irn_full_net(golden):
-    # weights regenerated exactly as make_golden.py did (same seed, same constructor order as archs.py:201-222)
+    # weights regenerated exactly as make_golden.py did: same seed, same constructor + init order as
+    # archs.py:201-222 / 74-133, then conv5 of every DenseBlock re-drawn from generator 55
     torch.manual_seed(5)
     net = O.IRNOracle(3, 12, scale=4, num_coupling=4)
-    # reference DenseBlock init: xavier*0.1 for conv1-4, kaiming*0 for conv5, zero bias (archs.py:84-86);
-    # the fixture re-draws conv5 from generator 55 -> do the same here, conv1-4 come from the fixture norm check
-    assert sum(p.numel() for p in net.parameters()) == int(golden['g5_nparams'])
+    haar_params = 4 * 4 * (3 + 12 + 48)                  # reference registers haar_weights as nn.Parameter
+    assert sum(p.numel() for p in net.parameters()) + haar_params == int(golden['g5_nparams'])
+    g5 = torch.Generator().manual_seed(55)
+    for m in net.modules():
+        if isinstance(m, O.DenseBlockOracle):
+            m.convs[4].weight.data = torch.randn(m.convs[4].weight.shape, generator=g5) * 0.02
+    x = T(golden['g5_x'])
+    with torch.no_grad():
+        y = net(x)
+        xr = net(y, rev=True)
+    assert torch.allclose(y[:, ::16, ::2, ::2], T(golden['g5_out_slice']), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(y.norm(), T(golden['g5_out_norm']), rtol=1e-5)
+    assert (xr - x).abs().max() < 1e-4
