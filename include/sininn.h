@@ -1,0 +1,193 @@
+/*
+ * sininn.h -- C ABI of libsininn.so: the MI355X (gfx950) kernels behind the sin-inn
+ * single-video INN training path.
+ *
+ * Boundary rules:
+ *   - extern "C", plain pointers and sizes only; no torch types.
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch allocates and frees);
+ *     the library borrows it for the duration of the call and never allocates device memory.
+ *     Scratch is a caller-provided workspace pointer + size in bytes.
+ *   - every call is an asynchronous launch on the hipStream_t passed as `stream`
+ *     (torch.cuda.current_stream().cuda_stream); no internal threads, no hidden syncs.
+ *   - return value: 0 on success, non-zero on error (argument check or hipError_t);
+ *     sininn_last_error() returns a thread-local message.  The Python side turns this into
+ *     RuntimeError, mirroring the assert / NotImplementedError convention of the reference's only
+ *     raw-pointer kernel call site (video-interpolation/my_utils/softsplat.py:239-331).
+ *   - activations are fp32 NHWC ("pixel-major"): element (b,y,x,c) of a tensor with C channels
+ *     and pixel stride `stride` floats lives at ((b*H+y)*W+x)*stride + c.  A channel sub-range is
+ *     addressed by offsetting the base pointer (stride stays the full pixel stride).
+ *
+ * All file:line citations are into the reference repository (paramhanji/sin-inn).
+ */
+#ifndef SININN_H
+#define SININN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SININN_ABI_VERSION 1
+#define SININN_HIDDEN 256 /* hidden width of subnet_conv / subnet_conv_1x1, archs.py:12,16 */
+
+int sininn_version(void);
+const char* sininn_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Weight packing.  Source: torch Conv2d weight, OIHW fp32 [N][Cin][k][k] (archs.py:12-13,16-17).
+ *   w_fwd  [taps][Np ][Cin ]  row q holds output channel colmap[q] (or q when colmap==NULL; rows
+ *                             whose source index is <0 or >=N are zero)  -- B operand of the conv.
+ *   w_dgrad[taps][Cdp][N   ]  w_dgrad[t][c][n] = w[n][c][taps-1-t]       -- B operand of the
+ *                             data-gradient conv (input channels N, output channels Cin padded to
+ *                             Cdp, rows c>=Cin zero).
+ *   b_fwd  [Np] packed bias (may be NULL together with bias).
+ * Either destination may be NULL.
+ * ---------------------------------------------------------------------------------------------- */
+int sininn_pack_conv_weights(const float* w_oihw, const float* bias, int N, int Cin, int ksize,
+                             const int* colmap, int Np, float* w_fwd, float* b_fwd,
+                             int Cdp, float* w_dgrad, void* stream);
+
+/* Packed column order used by the coupling epilogue for a subnet with 2*Co outputs (s | t):
+ * 16-column tile q = [ s[8q..8q+7] | t[8q..8q+7] ].  Writes 2*Co ints (host memory). */
+void sininn_coupling_colmap(int Co, int* colmap_host);
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolution engine (implicit GEMM on v_mfma_f32_16x16x4_f32, LDS-staged halo tiles).
+ * One entry point, epilogue selected by `mode`.  Replaces nn.Conv2d + the elementwise tail of
+ * FrEIA's GLOWCouplingBlock.forward (call site archs.py:61-64).
+ * ---------------------------------------------------------------------------------------------- */
+enum sininn_conv_mode {
+  SININN_CONV_RELU = 0,       /* out = relu(conv + bias)                    (archs.py:12,16: Conv+ReLU)   */
+  SININN_CONV_COUPLE_FWD = 1, /* y = exp(log_e(s)) * v + t ; logdet += sum log_e(s)                        */
+  SININN_CONV_COUPLE_INV = 2, /* y = (v - t) / exp(log_e(s)) ; logdet -= sum log_e(s)                      */
+  SININN_CONV_MASK = 3,       /* out = conv * (mask > 0)   (data gradient through the ReLU)                */
+  SININN_CONV_ADD = 4,        /* out = conv + addend[addend_map]            (data gradient + skip grad)    */
+  SININN_CONV_LINEAR = 5      /* out = conv + bias                                                          */
+};
+
+typedef struct sininn_conv_args {
+  const float* in;   int in_stride;  int Cin;      /* Cin % 8 == 0                                         */
+  const float* w;    const float* bias; int Np;    /* packed weights [taps][Np][Cin], Np % 16 == 0         */
+  int B, H, W, ksize;                              /* ksize 1 or 3, zero padding ksize/2                   */
+  int mode;
+  float* out;        int out_stride; int N;        /* generic modes: N valid output columns                */
+  const int* out_map;                              /* coupling modes: y channel c -> out channel (or NULL) */
+  const float* v;    int v_stride;                 /* coupling: transformed half                           */
+  float* out2;       int out2_stride;              /* coupling: optional compact copy of y                 */
+  float* sbuf;                                     /* coupling: optional [M][Co] copy of s (for backward)  */
+  float* logdet;                                   /* coupling: optional [B], accumulated with atomics     */
+  int Co;            float clamp;                  /* coupling: channels transformed, GLOW clamp           */
+  const float* mask; int mask_stride;              /* MASK mode                                            */
+  const float* addend; int addend_stride; const int* addend_map; /* ADD mode                               */
+} sininn_conv_args;
+
+int sininn_conv(const sininn_conv_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Weight gradient: dW[n][c][tap] += sum_pixels dout[pix][n] * in[pix+tap][c], db[n] += sum dout.
+ * Split over pixel ranges into slabs in `workspace`, then reduced into OIHW gradients (+=).
+ * sininn_wgrad_workspace_bytes gives the slab size for a shape.
+ * ---------------------------------------------------------------------------------------------- */
+size_t sininn_wgrad_workspace_bytes(int N, int Cin, int ksize, int B, int H, int W);
+int sininn_wgrad(const float* in, int in_stride, int Cin, const float* dout, int dout_stride, int N,
+                 int B, int H, int W, int ksize, float* gw_oihw, float* gbias,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Backward of the coupling tail (the elementwise part of GLOWCouplingBlock).
+ *   inverse==0: y = e(s) v + t      dv = dy e ; dt = dy  ; ds = (dy v e + gld) L'(s)
+ *   inverse==1: y = (v - t)/e(s)    dv = dy/e ; dt = -dy/e ; ds = -(dy y + gld) L'(s)
+ * dy[m][c] is read from dy[m*dy_stride + (dy_map ? dy_map[c] : c)] ; `vy` is v (inverse==0) or y
+ * (inverse==1) read through vy_map likewise.  dr is [M][2*Co] = (ds | dt).  gld is the optional
+ * per-sample gradient of the block's log-det ([B], may be NULL).
+ * ---------------------------------------------------------------------------------------------- */
+int sininn_coupling_bwd(const float* dy, int dy_stride, const int* dy_map,
+                        const float* vy, int vy_stride, const int* vy_map,
+                        const float* s, const float* gld, int B, int HW, int Co, float clamp,
+                        int inverse, float* dr, float* dv, int dv_stride, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Index maps: FrEIA IRevNetDownsampling (archs.py:28-31,35-38) and PermuteRandom (archs.py:65-68),
+ * plus NCHW<->NHWC import/export, as ONE strided gather:
+ *   levels==0 : out[b,y,x,cm(c)] = in[b,c,y,x]
+ *   squeeze (inverse==0), per level: out[b,(hb*2+wb)*C+c,i,j] = in[b,c,2i+hb,2j+wb]
+ *   unsqueeze (inverse==1) is the exact inverse.
+ * `levels` squeezes are composed in one pass.  Tensors are described by element strides
+ * (sb, sc, sh, sw) so either side may be NCHW or NHWC.  chan_map (device, may be NULL) is applied on
+ * the C-channel side that is being WRITTEN when map_on_out!=0, else on the side being READ.
+ * B,C,H,W describe the un-squeezed (fine) tensor.
+ * ---------------------------------------------------------------------------------------------- */
+int sininn_squeeze(const float* in, const int64_t in_strides[4], float* out, const int64_t out_strides[4],
+                   int B, int C, int H, int W, int levels, int inverse,
+                   const int* chan_map, int map_on_out, void* stream);
+
+/* out[m][j] = in[m][idx[j]] on pixel-major tensors (PermuteRandom.forward: x[:, perm]). */
+int sininn_permute_channels(const float* in, int in_stride, float* out, int out_stride,
+                            int64_t M, int C, const int* idx, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Losses (loss.py).  Strided 4-D views (element strides sb,sc,sh,sw); sums are written to fp32
+ * device scalars, the caller divides (torch.mean) -- keeps the kernels stream-async.
+ * ---------------------------------------------------------------------------------------------- */
+/* sum (x-y)^2 -> out[0]  (loss.py:3-5).  y may be NULL => sum x^2 (loss.py:38-39).  out must be zeroed. */
+int sininn_sqdiff_sum(const float* x, const int64_t xs[4], const float* y, const int64_t ys[4],
+                      int B, int C, int H, int W, float* out, void* stream);
+/* gx = scale[0]*gscale * (x-y) (and gy = -gx when gy!=NULL); `scale` is a device scalar (upstream grad). */
+int sininn_sqdiff_bwd(const float* x, const int64_t xs[4], const float* y, const int64_t ys[4],
+                      int B, int C, int H, int W, const float* scale, float gscale,
+                      float* gx, const int64_t gxs[4], float* gy, const int64_t gys[4], void* stream);
+/* Gram matrices for loss.mmd (loss.py:15-18): g[0]=x x^T, g[1]=y y^T, g[2]=x y^T, each [B][B]; g zeroed by caller. */
+int sininn_mmd_gram(const float* x, const int64_t xs[4], const float* y, const int64_t ys[4],
+                    int B, int C, int H, int W, float* g, void* stream);
+/* loss.py:20-36 on the three Grams -> out[0] (mean) and coef[3][B][B] = dLoss/dGram (for backward). */
+int sininn_mmd_finish(const float* g, int B, int rev, float* out, float* coef, void* stream);
+/* gx[b,:] = scale*( sum_j (coefXX[b][j]+coefXX[j][b]) x[j,:] + coefXY[b][j] y[j,:] ), gy likewise. */
+int sininn_mmd_bwd(const float* x, const int64_t xs[4], const float* y, const int64_t ys[4],
+                   int B, int C, int H, int W, const float* coef, const float* scale,
+                   float* gx, const int64_t gxs[4], float* gy, const int64_t gys[4], void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Warps.
+ * affine_warp: F.affine_grid(theta, align_corners=False) + F.grid_sample(bilinear, zeros,
+ *   align_corners=False) fused -- what kornia.warp_affine evaluates for tcr.py:43 once theta (the
+ *   inverted, normalised 2x3 matrix, [B][2][3]) is known.  Optional fused MSE against `ref`
+ *   (sum (warp-ref)^2 -> sse[0]).  bwd is the image gradient (atomic scatter).
+ * flow_warp_l1: Resample2d.forward + the photometric metric
+ *   (video-interpolation/my_utils/resample2d.py:57-72, video-interpolation/trainer.py:61-62):
+ *   warped = grid_sample(img, (coords+flow)/(W-1,H-1)*2-1) ; metric = mean_c |target - warped|.
+ * ---------------------------------------------------------------------------------------------- */
+int sininn_affine_warp(const float* img, const int64_t is[4], const float* theta, int B, int C, int H, int W,
+                       float* out, const int64_t os[4], const float* ref, const int64_t rs[4], float* sse,
+                       void* stream);
+int sininn_affine_warp_bwd(const float* gout, const int64_t gs[4], const float* theta, int B, int C, int H, int W,
+                           float* gimg, const int64_t gis[4], void* stream);
+int sininn_flow_warp_l1(const float* img, const float* flow, const float* target, int B, int C, int H, int W,
+                        float* warped, float* metric, void* stream);
+int sininn_flow_warp_l1_bwd(const float* img, const float* flow, const float* target, const float* warped,
+                            const float* gwarped, const float* gmetric, int B, int C, int H, int W,
+                            float* gimg, float* gflow, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Frame-window sampler (data.py:31-45 + 112-115 on an HBM-resident uint8 clip):
+ *   hr[n] = hr_clip[idx[n]] / 255 as (3,H,W) planar or pixel-major, lr[n] = concat of the 2*win+1 LR
+ *   frames idx[n]-win..idx[n]+win on the channel axis / 255.
+ * hr_clip (T,H,W,3) u8, lr_clip (T,h,w,4) u8, idx device int32 [n].
+ * ---------------------------------------------------------------------------------------------- */
+int sininn_sample_windows(const uint8_t* hr_clip, const uint8_t* lr_clip, const int* idx, int n,
+                          int T, int H, int W, int h, int w, int win,
+                          float* hr_out, const int64_t hs[4], float* lr_out, const int64_t ls[4], void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Adam exactly as torch.optim.Adam (lit_wrapper.py:131-138: L2 weight decay, not AdamW):
+ *   g = grad*grad_scale + wd*p ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+ *   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * ---------------------------------------------------------------------------------------------- */
+int sininn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SININN_H */

@@ -1,0 +1,160 @@
+// extern "C" surface of libsininn.so (see include/sininn.h for the contract).
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace sininn {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int conv_launch(const sininn_conv_args* a, hipStream_t st);
+void conv_set_test_hooks(int force_cfg, int force_ck);
+size_t wgrad_workspace_bytes(int N, int Cin, int ksize, int B, int H, int W);
+int wgrad_launch(const float* in, int in_stride, int Cin, const float* dout, int dout_stride, int N, int B, int H, int W,
+                 int ksize, float* gw, float* gb, void* ws, size_t ws_bytes, hipStream_t st);
+int pack_launch(const float* w, const float* bias, int N, int Cin, int ksize, const int* colmap, int Np, float* w_fwd,
+                float* b_fwd, int Cdp, float* w_dgrad, hipStream_t st);
+int coupling_bwd_launch(const float* dy, int dy_stride, const int* dy_map, const float* vy, int vy_stride,
+                        const int* vy_map, const float* s, const float* gld, int B, int HW, int Co, float clamp,
+                        int inverse, float* dr, float* dv, int dv_stride, hipStream_t st);
+int squeeze_launch(const float* in, const int64_t is[4], float* out, const int64_t os[4], int B, int C, int H, int W,
+                   int levels, int inverse, const int* chan_map, int map_on_out, hipStream_t st);
+int permute_launch(const float* in, int in_stride, float* out, int out_stride, int64_t M, int C, const int* idx,
+                   hipStream_t st);
+int sqdiff_sum_launch(const float* x, const int64_t xs[4], const float* y, const int64_t ys[4], int B, int C, int H,
+                      int W, float* out, hipStream_t st);
+int sqdiff_bwd_launch(const float* x, const int64_t xs[4], const float* y, const int64_t ys[4], int B, int C, int H,
+                      int W, const float* scale, float gscale, float* gx, const int64_t gxs[4], float* gy,
+                      const int64_t gys[4], hipStream_t st);
+int mmd_gram_launch(const float* x, const int64_t xs[4], const float* y, const int64_t ys[4], int B, int C, int H,
+                    int W, float* g, hipStream_t st);
+int mmd_finish_launch(const float* g, int B, int rev, float* out, float* coef, hipStream_t st);
+int mmd_bwd_launch(const float* x, const int64_t xs[4], const float* y, const int64_t ys[4], int B, int C, int H, int W,
+                   const float* coef, const float* scale, float* gx, const int64_t gxs[4], float* gy,
+                   const int64_t gys[4], hipStream_t st);
+int affine_warp_launch(const float* img, const int64_t is[4], const float* theta, int B, int C, int H, int W, float* out,
+                       const int64_t os[4], const float* ref, const int64_t rs[4], float* sse, hipStream_t st);
+int affine_warp_bwd_launch(const float* gout, const int64_t gs[4], const float* theta, int B, int C, int H, int W,
+                           float* gimg, const int64_t gis[4], hipStream_t st);
+int flow_warp_l1_launch(const float* img, const float* flow, const float* target, int B, int C, int H, int W,
+                        float* warped, float* metric, hipStream_t st);
+int flow_warp_l1_bwd_launch(const float* img, const float* flow, const float* target, const float* warped,
+                            const float* gwarped, const float* gmetric, int B, int C, int H, int W, float* gimg,
+                            float* gflow, hipStream_t st);
+int sample_windows_launch(const uint8_t* hr_clip, const uint8_t* lr_clip, const int* idx, int n, int T, int H, int W,
+                          int h, int w, int win, float* hr_out, const int64_t hs[4], float* lr_out,
+                          const int64_t ls[4], hipStream_t st);
+int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                float wd, int step, float gscale, hipStream_t st);
+}  // namespace sininn
+
+using namespace sininn;
+#define ST(s) static_cast<hipStream_t>(s)
+
+extern "C" {
+
+int sininn_version(void) { return SININN_ABI_VERSION; }
+const char* sininn_last_error(void) { return g_err; }
+
+int sininn_pack_conv_weights(const float* w_oihw, const float* bias, int N, int Cin, int ksize, const int* colmap,
+                             int Np, float* w_fwd, float* b_fwd, int Cdp, float* w_dgrad, void* stream) {
+  return pack_launch(w_oihw, bias, N, Cin, ksize, colmap, Np, w_fwd, b_fwd, Cdp, w_dgrad, ST(stream));
+}
+
+void sininn_coupling_colmap(int Co, int* colmap_host) {
+  for (int q = 0; q < 2 * Co; ++q) {
+    const int tile = q / 16, j = q % 16;
+    colmap_host[q] = (j < 8) ? (tile * 8 + j) : (Co + tile * 8 + j - 8);
+  }
+}
+
+int sininn_conv(const sininn_conv_args* args, void* stream) { return conv_launch(args, ST(stream)); }
+
+/* test hook (not part of the documented surface): force tile configuration / channel chunk */
+void sininn_conv_test_hooks(int force_cfg, int force_ck) { conv_set_test_hooks(force_cfg, force_ck); }
+
+size_t sininn_wgrad_workspace_bytes(int N, int Cin, int ksize, int B, int H, int W) {
+  return wgrad_workspace_bytes(N, Cin, ksize, B, H, W);
+}
+int sininn_wgrad(const float* in, int in_stride, int Cin, const float* dout, int dout_stride, int N, int B, int H, int W,
+                 int ksize, float* gw_oihw, float* gbias, void* workspace, size_t workspace_bytes, void* stream) {
+  return wgrad_launch(in, in_stride, Cin, dout, dout_stride, N, B, H, W, ksize, gw_oihw, gbias, workspace,
+                      workspace_bytes, ST(stream));
+}
+
+int sininn_coupling_bwd(const float* dy, int dy_stride, const int* dy_map, const float* vy, int vy_stride,
+                        const int* vy_map, const float* s, const float* gld, int B, int HW, int Co, float clamp,
+                        int inverse, float* dr, float* dv, int dv_stride, void* stream) {
+  return coupling_bwd_launch(dy, dy_stride, dy_map, vy, vy_stride, vy_map, s, gld, B, HW, Co, clamp, inverse, dr, dv,
+                             dv_stride, ST(stream));
+}
+
+int sininn_squeeze(const float* in, const int64_t in_strides[4], float* out, const int64_t out_strides[4], int B, int C,
+                   int H, int W, int levels, int inverse, const int* chan_map, int map_on_out, void* stream) {
+  return squeeze_launch(in, in_strides, out, out_strides, B, C, H, W, levels, inverse, chan_map, map_on_out, ST(stream));
+}
+
+int sininn_permute_channels(const float* in, int in_stride, float* out, int out_stride, int64_t M, int C,
+                            const int* idx, void* stream) {
+  return permute_launch(in, in_stride, out, out_stride, M, C, idx, ST(stream));
+}
+
+int sininn_sqdiff_sum(const float* x, const int64_t xs[4], const float* y, const int64_t ys[4], int B, int C, int H,
+                      int W, float* out, void* stream) {
+  return sqdiff_sum_launch(x, xs, y, ys, B, C, H, W, out, ST(stream));
+}
+int sininn_sqdiff_bwd(const float* x, const int64_t xs[4], const float* y, const int64_t ys[4], int B, int C, int H,
+                      int W, const float* scale, float gscale, float* gx, const int64_t gxs[4], float* gy,
+                      const int64_t gys[4], void* stream) {
+  return sqdiff_bwd_launch(x, xs, y, ys, B, C, H, W, scale, gscale, gx, gxs, gy, gys, ST(stream));
+}
+int sininn_mmd_gram(const float* x, const int64_t xs[4], const float* y, const int64_t ys[4], int B, int C, int H, int W,
+                    float* g, void* stream) {
+  return mmd_gram_launch(x, xs, y, ys, B, C, H, W, g, ST(stream));
+}
+int sininn_mmd_finish(const float* g, int B, int rev, float* out, float* coef, void* stream) {
+  return mmd_finish_launch(g, B, rev, out, coef, ST(stream));
+}
+int sininn_mmd_bwd(const float* x, const int64_t xs[4], const float* y, const int64_t ys[4], int B, int C, int H, int W,
+                   const float* coef, const float* scale, float* gx, const int64_t gxs[4], float* gy,
+                   const int64_t gys[4], void* stream) {
+  return mmd_bwd_launch(x, xs, y, ys, B, C, H, W, coef, scale, gx, gxs, gy, gys, ST(stream));
+}
+
+int sininn_affine_warp(const float* img, const int64_t is[4], const float* theta, int B, int C, int H, int W, float* out,
+                       const int64_t os[4], const float* ref, const int64_t rs[4], float* sse, void* stream) {
+  return affine_warp_launch(img, is, theta, B, C, H, W, out, os, ref, rs, sse, ST(stream));
+}
+int sininn_affine_warp_bwd(const float* gout, const int64_t gs[4], const float* theta, int B, int C, int H, int W,
+                           float* gimg, const int64_t gis[4], void* stream) {
+  return affine_warp_bwd_launch(gout, gs, theta, B, C, H, W, gimg, gis, ST(stream));
+}
+int sininn_flow_warp_l1(const float* img, const float* flow, const float* target, int B, int C, int H, int W,
+                        float* warped, float* metric, void* stream) {
+  return flow_warp_l1_launch(img, flow, target, B, C, H, W, warped, metric, ST(stream));
+}
+int sininn_flow_warp_l1_bwd(const float* img, const float* flow, const float* target, const float* warped,
+                            const float* gwarped, const float* gmetric, int B, int C, int H, int W, float* gimg,
+                            float* gflow, void* stream) {
+  return flow_warp_l1_bwd_launch(img, flow, target, warped, gwarped, gmetric, B, C, H, W, gimg, gflow, ST(stream));
+}
+
+int sininn_sample_windows(const uint8_t* hr_clip, const uint8_t* lr_clip, const int* idx, int n, int T, int H, int W,
+                          int h, int w, int win, float* hr_out, const int64_t hs[4], float* lr_out, const int64_t ls[4],
+                          void* stream) {
+  return sample_windows_launch(hr_clip, lr_clip, idx, n, T, H, W, h, w, win, hr_out, hs, lr_out, ls, ST(stream));
+}
+
+int sininn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int step, float grad_scale, void* stream) {
+  return adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, ST(stream));
+}
+
+}  // extern "C"

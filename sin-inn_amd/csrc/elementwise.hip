@@ -1,0 +1,681 @@
+// HBM-bound kernels of the sin-inn training path: weight packing, coupling backward tail, index maps
+// (squeeze / permute / layout import-export), losses, warps, frame-window sampler, Adam.
+#include "common.h"
+
+namespace sininn {
+
+struct Str4 { int64_t b, c, h, w; };
+static inline Str4 mk(const int64_t s[4]) { return Str4{s[0], s[1], s[2], s[3]}; }
+
+// ------------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float* __restrict__ w, const float* __restrict__ bias, int N, int Cin,
+                                    int taps, const int* __restrict__ colmap, int Np, float* __restrict__ w_fwd,
+                                    float* __restrict__ b_fwd, int Cdp, float* __restrict__ w_dgrad) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nf = w_fwd ? taps * Np * Cin : 0;
+  const int nd = w_dgrad ? taps * Cdp * N : 0;
+  if (idx < nf) {
+    const int c = idx % Cin, q = (idx / Cin) % Np, t = idx / (Cin * Np);
+    const int n = colmap ? colmap[q] : q;
+    w_fwd[idx] = (n >= 0 && n < N) ? w[((size_t)n * Cin + c) * taps + t] : 0.f;
+  } else if (idx < nf + nd) {
+    const int k = idx - nf;
+    const int n = k % N, c = (k / N) % Cdp, t = k / (N * Cdp);
+    w_dgrad[k] = (c < Cin) ? w[((size_t)n * Cin + c) * taps + (taps - 1 - t)] : 0.f;
+  }
+  if (b_fwd && idx < Np) {
+    const int n = colmap ? colmap[idx] : idx;
+    b_fwd[idx] = (bias && n >= 0 && n < N) ? bias[n] : 0.f;
+  }
+}
+
+int pack_launch(const float* w, const float* bias, int N, int Cin, int ksize, const int* colmap, int Np,
+                float* w_fwd, float* b_fwd, int Cdp, float* w_dgrad, hipStream_t st) {
+  SININN_CHECK(w != nullptr && N > 0 && Cin > 0 && (ksize == 1 || ksize == 3), "pack: bad arguments");
+  SININN_CHECK(!w_fwd || Np >= 1, "pack: bad Np");
+  SININN_CHECK(!w_dgrad || Cdp >= Cin, "pack: Cdp < Cin");
+  const int taps = ksize * ksize;
+  int total = (w_fwd ? taps * Np * Cin : 0) + (w_dgrad ? taps * Cdp * N : 0);
+  if (total < Np) total = Np;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, bias, N, Cin, taps, colmap,
+                     Np, w_fwd, b_fwd, Cdp, w_dgrad);
+  SININN_LAUNCH_CHECK("pack_weights");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// coupling backward tail
+// ------------------------------------------------------------------------------------------------
+__global__ void coupling_bwd_kernel(const float* __restrict__ dy, int dy_stride, const int* __restrict__ dy_map,
+                                    const float* __restrict__ vy, int vy_stride, const int* __restrict__ vy_map,
+                                    const float* __restrict__ s, const float* __restrict__ gld, int64_t total,
+                                    int HW, int Co, float clamp, int inverse, float* __restrict__ dr,
+                                    float* __restrict__ dv, int dv_stride) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % Co);
+    const int64_t pix = idx / Co;
+    const float g = dy[pix * dy_stride + (dy_map ? dy_map[c] : c)];
+    const float u = vy[pix * vy_stride + (vy_map ? vy_map[c] : c)];
+    const float sv = s[idx];
+    const float L = glow_log_e(sv, clamp);
+    const float dL = glow_dlog_e(sv, clamp);
+    const float gl = gld ? gld[pix / HW] : 0.f;
+    const float e = expf(L);
+    float ds, dt, dvv;
+    if (!inverse) { dvv = g * e; dt = g; ds = (g * u * e + gl) * dL; }
+    else { dvv = g / e; dt = -dvv; ds = -(g * u + gl) * dL; }
+    dr[pix * (2 * Co) + c] = ds;
+    dr[pix * (2 * Co) + Co + c] = dt;
+    dv[pix * dv_stride + c] = dvv;
+  }
+}
+
+int coupling_bwd_launch(const float* dy, int dy_stride, const int* dy_map, const float* vy, int vy_stride,
+                        const int* vy_map, const float* s, const float* gld, int B, int HW, int Co, float clamp,
+                        int inverse, float* dr, float* dv, int dv_stride, hipStream_t st) {
+  SININN_CHECK(dy && vy && s && dr && dv, "coupling_bwd: null pointer");
+  SININN_CHECK(B > 0 && HW > 0 && Co > 0 && clamp > 0.f, "coupling_bwd: bad shape");
+  SININN_CHECK(dy_stride >= Co && vy_stride >= Co && dv_stride >= Co, "coupling_bwd: stride < Co");
+  const int64_t total = (int64_t)B * HW * Co;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(coupling_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, dy_stride, dy_map, vy, vy_stride,
+                     vy_map, s, gld, total, HW, Co, clamp, inverse, dr, dv, dv_stride);
+  SININN_LAUNCH_CHECK("coupling_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// squeeze / unsqueeze / layout change as one strided gather
+// ------------------------------------------------------------------------------------------------
+__global__ void squeeze_kernel(const float* __restrict__ in, Str4 is, float* __restrict__ out, Str4 os, int B, int C,
+                               int H, int W, int levels, int inverse, const int* __restrict__ chan_map,
+                               int map_on_out, int x_fastest) {
+  const int64_t total = (int64_t)B * C * H * W;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int b, c, y, x;
+    int64_t r = idx;
+    if (x_fastest) { x = r % W; r /= W; y = r % H; r /= H; c = r % C; b = (int)(r / C); }
+    else { c = r % C; r /= C; x = r % W; r /= W; y = r % H; b = (int)(r / H); }
+    // coarse coordinates after `levels` squeezes
+    int cc = c, cy = y, cx = x, cch = C;
+    for (int l = 0; l < levels; ++l) {
+      cc = ((cy & 1) * 2 + (cx & 1)) * cch + cc;
+      cy >>= 1; cx >>= 1; cch *= 4;
+    }
+    int fc = c, qc = cc;              // fine-side / coarse-side channel
+    // forward: in = fine, out = coarse ; inverse: in = coarse, out = fine
+    if (chan_map) {
+      if (!inverse) { if (map_on_out) qc = chan_map[qc]; else fc = chan_map[fc]; }
+      else { if (map_on_out) fc = chan_map[fc]; else qc = chan_map[qc]; }
+    }
+    const int64_t fine = b * (inverse ? os.b : is.b) + fc * (inverse ? os.c : is.c) + y * (inverse ? os.h : is.h) +
+                         x * (inverse ? os.w : is.w);
+    const int64_t coarse = b * (inverse ? is.b : os.b) + qc * (inverse ? is.c : os.c) +
+                           cy * (inverse ? is.h : os.h) + cx * (inverse ? is.w : os.w);
+    if (!inverse) out[coarse] = in[fine]; else out[fine] = in[coarse];
+  }
+}
+
+int squeeze_launch(const float* in, const int64_t is[4], float* out, const int64_t os[4], int B, int C, int H, int W,
+                   int levels, int inverse, const int* chan_map, int map_on_out, hipStream_t st) {
+  SININN_CHECK(in && out && is && os, "squeeze: null pointer");
+  SININN_CHECK(B > 0 && C > 0 && H > 0 && W > 0 && levels >= 0 && levels <= 4, "squeeze: bad shape");
+  SININN_CHECK((H % (1 << levels)) == 0 && (W % (1 << levels)) == 0, "squeeze: H=%d W=%d not divisible by 2^%d", H, W, levels);
+  const int64_t total = (int64_t)B * C * H * W;
+  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  const int64_t fine_sw = inverse ? os[3] : is[3];
+  hipLaunchKernelGGL(squeeze_kernel, dim3(blocks), dim3(256), 0, st, in, mk(is), out, mk(os), B, C, H, W, levels,
+                     inverse, chan_map, map_on_out, fine_sw == 1 ? 1 : 0);
+  SININN_LAUNCH_CHECK("squeeze");
+  return 0;
+}
+
+__global__ void permute_kernel(const float* __restrict__ in, int in_stride, float* __restrict__ out, int out_stride,
+                               int64_t M, int C, const int* __restrict__ idx) {
+  const int64_t total = M * C;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(k % C);
+    const int64_t m = k / C;
+    out[m * out_stride + j] = in[m * in_stride + idx[j]];
+  }
+}
+
+int permute_launch(const float* in, int in_stride, float* out, int out_stride, int64_t M, int C, const int* idx,
+                   hipStream_t st) {
+  SININN_CHECK(in && out && idx && M > 0 && C > 0 && in_stride >= C && out_stride >= C, "permute: bad arguments");
+  const int64_t total = M * C;
+  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  hipLaunchKernelGGL(permute_kernel, dim3(blocks), dim3(256), 0, st, in, in_stride, out, out_stride, M, C, idx);
+  SININN_LAUNCH_CHECK("permute");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// losses
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void decode4(int64_t r, int C, int H, int W, int x_fastest, int& b, int& c, int& y, int& x) {
+  if (x_fastest) { x = r % W; r /= W; y = r % H; r /= H; c = r % C; b = (int)(r / C); }
+  else { c = r % C; r /= C; x = r % W; r /= W; y = r % H; b = (int)(r / H); }
+}
+
+__global__ void sqdiff_sum_kernel(const float* __restrict__ x, Str4 xs, const float* __restrict__ y, Str4 ys, int B,
+                                  int C, int H, int W, int x_fastest, float* __restrict__ out) {
+  const int64_t total = (int64_t)B * C * H * W;
+  float acc = 0.f;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int b, c, yy, xx;
+    decode4(idx, C, H, W, x_fastest, b, c, yy, xx);
+    float d = x[b * xs.b + c * xs.c + yy * xs.h + xx * xs.w];
+    if (y) d -= y[b * ys.b + c * ys.c + yy * ys.h + xx * ys.w];
+    acc += d * d;
+  }
+  __shared__ float red[4];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+int sqdiff_sum_launch(const float* x, const int64_t xs[4], const float* y, const int64_t ys[4], int B, int C, int H,
+                      int W, float* out, hipStream_t st) {
+  SININN_CHECK(x && xs && out && B > 0 && C > 0 && H > 0 && W > 0, "sqdiff_sum: bad arguments");
+  SININN_CHECK(!y || ys, "sqdiff_sum: y without strides");
+  const int64_t total = (int64_t)B * C * H * W;
+  const int blocks = (int)((total + 1023) / 1024 < 2048 ? (total + 1023) / 1024 : 2048);
+  Str4 yss = y ? mk(ys) : Str4{0, 0, 0, 0};
+  hipLaunchKernelGGL(sqdiff_sum_kernel, dim3(blocks), dim3(256), 0, st, x, mk(xs), y, yss, B, C, H, W,
+                     xs[3] == 1 ? 1 : 0, out);
+  SININN_LAUNCH_CHECK("sqdiff_sum");
+  return 0;
+}
+
+__global__ void sqdiff_bwd_kernel(const float* __restrict__ x, Str4 xs, const float* __restrict__ y, Str4 ys, int B,
+                                  int C, int H, int W, int x_fastest, const float* __restrict__ scale, float gscale,
+                                  float* __restrict__ gx, Str4 gxs, float* __restrict__ gy, Str4 gys) {
+  const int64_t total = (int64_t)B * C * H * W;
+  const float k = scale[0] * gscale;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int b, c, yy, xx;
+    decode4(idx, C, H, W, x_fastest, b, c, yy, xx);
+    float d = x[b * xs.b + c * xs.c + yy * xs.h + xx * xs.w];
+    if (y) d -= y[b * ys.b + c * ys.c + yy * ys.h + xx * ys.w];
+    const float g = k * d;
+    if (gx) gx[b * gxs.b + c * gxs.c + yy * gxs.h + xx * gxs.w] = g;
+    if (gy) gy[b * gys.b + c * gys.c + yy * gys.h + xx * gys.w] = -g;
+  }
+}
+
+int sqdiff_bwd_launch(const float* x, const int64_t xs[4], const float* y, const int64_t ys[4], int B, int C, int H,
+                      int W, const float* scale, float gscale, float* gx, const int64_t gxs[4], float* gy,
+                      const int64_t gys[4], hipStream_t st) {
+  SININN_CHECK(x && xs && scale && (gx || gy), "sqdiff_bwd: bad arguments");
+  SININN_CHECK((!gx || gxs) && (!gy || gys) && (!y || ys), "sqdiff_bwd: missing strides");
+  const int64_t total = (int64_t)B * C * H * W;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  Str4 z{0, 0, 0, 0};
+  hipLaunchKernelGGL(sqdiff_bwd_kernel, dim3(blocks), dim3(256), 0, st, x, mk(xs), y, y ? mk(ys) : z, B, C, H, W,
+                     xs[3] == 1 ? 1 : 0, scale, gscale, gx, gx ? mk(gxs) : z, gy, gy ? mk(gys) : z);
+  SININN_LAUNCH_CHECK("sqdiff_bwd");
+  return 0;
+}
+
+// Gram matrices of loss.mmd: each block stages a chunk of KC logical positions of all B samples
+constexpr int MMD_KC = 128;
+__global__ void mmd_gram_kernel(const float* __restrict__ x, Str4 xs, const float* __restrict__ y, Str4 ys, int B,
+                                int C, int H, int W, int x_fastest, float* __restrict__ g) {
+  extern __shared__ float sm[];
+  float* xl = sm;                   // [B][KC+1]
+  float* yl = sm + B * (MMD_KC + 1);
+  const int64_t K = (int64_t)C * H * W;
+  const int npair = B * B;
+  for (int64_t k0 = (int64_t)blockIdx.x * MMD_KC; k0 < K; k0 += (int64_t)gridDim.x * MMD_KC) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < B * MMD_KC; e += blockDim.x) {
+      const int i = e / MMD_KC, kk = e % MMD_KC;
+      const int64_t k = k0 + kk;
+      float xv = 0.f, yv = 0.f;
+      if (k < K) {
+        int c, yy, xx; int64_t r = k;
+        if (x_fastest) { xx = r % W; r /= W; yy = r % H; c = (int)(r / H); }
+        else { c = r % C; r /= C; xx = r % W; yy = (int)(r / W); }
+        xv = x[i * xs.b + c * xs.c + yy * xs.h + xx * xs.w];
+        yv = y[i * ys.b + c * ys.c + yy * ys.h + xx * ys.w];
+      }
+      xl[i * (MMD_KC + 1) + kk] = xv;
+      yl[i * (MMD_KC + 1) + kk] = yv;
+    }
+    __syncthreads();
+    for (int pr = threadIdx.x; pr < npair; pr += blockDim.x) {
+      const int i = pr / B, j = pr % B;
+      float sxx = 0.f, syy = 0.f, sxy = 0.f;
+      for (int kk = 0; kk < MMD_KC; ++kk) {
+        const float xi = xl[i * (MMD_KC + 1) + kk], xj = xl[j * (MMD_KC + 1) + kk];
+        const float yi = yl[i * (MMD_KC + 1) + kk], yj = yl[j * (MMD_KC + 1) + kk];
+        sxx += xi * xj; syy += yi * yj; sxy += xi * yj;
+      }
+      atomicAdd(g + pr, sxx);
+      atomicAdd(g + npair + pr, syy);
+      atomicAdd(g + 2 * npair + pr, sxy);
+    }
+  }
+}
+
+int mmd_gram_launch(const float* x, const int64_t xs[4], const float* y, const int64_t ys[4], int B, int C, int H,
+                    int W, float* g, hipStream_t st) {
+  SININN_CHECK(x && y && xs && ys && g, "mmd_gram: null pointer");
+  SININN_CHECK(B > 0 && B <= 64 && C > 0 && H > 0 && W > 0, "mmd_gram: batch must be in 1..64 (got %d)", B);
+  const int64_t K = (int64_t)C * H * W;
+  const int blocks = (int)((K + MMD_KC - 1) / MMD_KC < 1024 ? (K + MMD_KC - 1) / MMD_KC : 1024);
+  const size_t lds = (size_t)2 * B * (MMD_KC + 1) * sizeof(float);
+  hipLaunchKernelGGL(mmd_gram_kernel, dim3(blocks), dim3(256), lds, st, x, mk(xs), y, mk(ys), B, C, H, W,
+                     xs[3] == 1 ? 1 : 0, g);
+  SININN_LAUNCH_CHECK("mmd_gram");
+  return 0;
+}
+
+// loss.py:20-36 on the Grams; also the four BxB matrices the backward needs:
+//   gx = AX x + BX y ,  gy = AY x + BY y   (rows = samples)
+__global__ void mmd_finish_kernel(const float* __restrict__ g, int B, int rev, float* __restrict__ out,
+                                  float* __restrict__ coef) {
+  extern __shared__ float sm[];
+  float* gxx = sm;            // dL/d dxx (masked), [B][B]
+  float* gyy = sm + B * B;
+  float* gxy = sm + 2 * B * B;
+  __shared__ float red[4];
+  const float Cs[2][3] = {{0.2f, 1.5f, 3.0f}, {0.2f, 0.2f, 0.2f}};
+  const float As[2][3] = {{2.f, 2.f, 2.f}, {0.1f, 0.5f, 2.f}};
+  const int npair = B * B;
+  const float inv = 1.f / (float)npair;
+  float acc = 0.f;
+  for (int pr = threadIdx.x; pr < npair; pr += blockDim.x) {
+    const int i = pr / B, j = pr % B;
+    const float xx = g[pr], yy = g[npair + pr], xy = g[2 * npair + pr];
+    const float xii = g[i * B + i], xjj = g[j * B + j], yii = g[npair + i * B + i], yjj = g[npair + j * B + j];
+    const float rxx = xii + xjj - 2.f * xx, ryy = yii + yjj - 2.f * yy, rxy = xii + yjj - 2.f * xy;
+    const float dxx = fmaxf(rxx, 0.f), dyy = fmaxf(ryy, 0.f), dxy = fmaxf(rxy, 0.f);
+    float kxx = 0.f, kyy = 0.f, kxy = 0.f, pxx = 0.f, pyy = 0.f, pxy = 0.f;
+    for (int q = 0; q < 3; ++q) {
+      const float Cq = Cs[rev][q], a = As[rev][q];
+      const float ca = powf(Cq, a);
+      const float bxx = (Cq + dxx) / a, byy = (Cq + dyy) / a, bxy = (Cq + dxy) / a;
+      kxx += ca * powf(bxx, -a); kyy += ca * powf(byy, -a); kxy += ca * powf(bxy, -a);
+      pxx -= ca * powf(bxx, -a - 1.f); pyy -= ca * powf(byy, -a - 1.f); pxy -= ca * powf(bxy, -a - 1.f);
+    }
+    acc += kxx + kyy - 2.f * kxy;
+    gxx[pr] = (rxx >= 0.f) ? pxx * inv : 0.f;
+    gyy[pr] = (ryy >= 0.f) ? pyy * inv : 0.f;
+    gxy[pr] = (rxy >= 0.f) ? -2.f * pxy * inv : 0.f;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (red[0] + red[1] + red[2] + red[3]) * inv;
+  if (!coef) return;
+  float* AX = coef; float* BX = coef + npair; float* AY = coef + 2 * npair; float* BY = coef + 3 * npair;
+  for (int pr = threadIdx.x; pr < npair; pr += blockDim.x) {
+    const int i = pr / B, j = pr % B;
+    const float sx = gxx[i * B + j] + gxx[j * B + i];
+    const float sy = gyy[i * B + j] + gyy[j * B + i];
+    float ax = -2.f * sx, by = -2.f * sy;
+    if (i == j) {
+      float rowx = 0.f, rowy = 0.f;
+      for (int k = 0; k < B; ++k) {
+        rowx += gxx[i * B + k] + gxx[k * B + i] + gxy[i * B + k];   // d/dx_i of |x_i|^2 terms
+        rowy += gyy[i * B + k] + gyy[k * B + i] + gxy[k * B + i];   // d/dy_i of |y_i|^2 terms
+      }
+      ax += 2.f * rowx; by += 2.f * rowy;
+    }
+    AX[pr] = ax;
+    BX[pr] = -2.f * gxy[i * B + j];   // gx_i <- y_j
+    AY[pr] = -2.f * gxy[j * B + i];   // gy_i <- x_j
+    BY[pr] = by;
+  }
+}
+
+int mmd_finish_launch(const float* g, int B, int rev, float* out, float* coef, hipStream_t st) {
+  SININN_CHECK(g && out && B > 0 && B <= 64, "mmd_finish: bad arguments");
+  hipLaunchKernelGGL(mmd_finish_kernel, dim3(1), dim3(256), (size_t)3 * B * B * sizeof(float), st, g, B, rev ? 1 : 0,
+                     out, coef);
+  SININN_LAUNCH_CHECK("mmd_finish");
+  return 0;
+}
+
+__global__ void mmd_bwd_kernel(const float* __restrict__ x, Str4 xs, const float* __restrict__ y, Str4 ys, int B, int C,
+                               int H, int W, int x_fastest, const float* __restrict__ coef,
+                               const float* __restrict__ scale, float* __restrict__ gx, Str4 gxs,
+                               float* __restrict__ gy, Str4 gys) {
+  const int64_t K = (int64_t)C * H * W;
+  const int64_t total = K * B;
+  const int npair = B * B;
+  const float sc = scale[0];
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = idx % K;
+    const int i = (int)(idx / K);
+    int c, yy, xx; int64_t r = k;
+    if (x_fastest) { xx = r % W; r /= W; yy = r % H; c = (int)(r / H); }
+    else { c = r % C; r /= C; xx = r % W; yy = (int)(r / W); }
+    const int64_t ox = c * xs.c + yy * xs.h + xx * xs.w, oy = c * ys.c + yy * ys.h + xx * ys.w;
+    float ax = 0.f, ay = 0.f;
+    for (int j = 0; j < B; ++j) {
+      const float xv = x[j * xs.b + ox], yv = y[j * ys.b + oy];
+      ax += coef[i * B + j] * xv + coef[npair + i * B + j] * yv;
+      ay += coef[2 * npair + i * B + j] * xv + coef[3 * npair + i * B + j] * yv;
+    }
+    if (gx) gx[i * gxs.b + c * gxs.c + yy * gxs.h + xx * gxs.w] = sc * ax;
+    if (gy) gy[i * gys.b + c * gys.c + yy * gys.h + xx * gys.w] = sc * ay;
+  }
+}
+
+int mmd_bwd_launch(const float* x, const int64_t xs[4], const float* y, const int64_t ys[4], int B, int C, int H, int W,
+                   const float* coef, const float* scale, float* gx, const int64_t gxs[4], float* gy,
+                   const int64_t gys[4], hipStream_t st) {
+  SININN_CHECK(x && y && xs && ys && coef && scale && (gx || gy), "mmd_bwd: bad arguments");
+  SININN_CHECK((!gx || gxs) && (!gy || gys), "mmd_bwd: missing strides");
+  const int64_t total = (int64_t)B * C * H * W;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  Str4 z{0, 0, 0, 0};
+  hipLaunchKernelGGL(mmd_bwd_kernel, dim3(blocks), dim3(256), 0, st, x, mk(xs), y, mk(ys), B, C, H, W,
+                     xs[3] == 1 ? 1 : 0, coef, scale, gx, gx ? mk(gxs) : z, gy, gy ? mk(gys) : z);
+  SININN_LAUNCH_CHECK("mmd_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// affine warp (kornia.warp_affine == affine_grid + grid_sample, align_corners=False, zeros padding)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void affine_src(const float* th, int x, int y, int H, int W, float& ix, float& iy) {
+  const float xn = (2.f * x + 1.f) / W - 1.f, yn = (2.f * y + 1.f) / H - 1.f;
+  const float xs = th[0] * xn + th[1] * yn + th[2];
+  const float ys = th[3] * xn + th[4] * yn + th[5];
+  ix = ((xs + 1.f) * W - 1.f) * 0.5f;
+  iy = ((ys + 1.f) * H - 1.f) * 0.5f;
+}
+
+__global__ void affine_warp_kernel(const float* __restrict__ img, Str4 is, const float* __restrict__ theta, int B,
+                                   int C, int H, int W, int x_fastest, float* __restrict__ out, Str4 os,
+                                   const float* __restrict__ ref, Str4 rs, float* __restrict__ sse) {
+  const int64_t total = (int64_t)B * C * H * W;
+  float acc = 0.f;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int b, c, y, x;
+    decode4(idx, C, H, W, x_fastest, b, c, y, x);
+    float ix, iy;
+    affine_src(theta + b * 6, x, y, H, W, ix, iy);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    const float* base = img + b * is.b + c * is.c;
+    auto tap = [&](int yy, int xx) -> float {
+      return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? base[yy * is.h + xx * is.w] : 0.f;
+    };
+    const float val = tap(y0, x0) * wy0 * wx0 + tap(y0, x0 + 1) * wy0 * wx1 + tap(y0 + 1, x0) * wy1 * wx0 +
+                      tap(y0 + 1, x0 + 1) * wy1 * wx1;
+    out[b * os.b + c * os.c + y * os.h + x * os.w] = val;
+    if (ref) { const float d = val - ref[b * rs.b + c * rs.c + y * rs.h + x * rs.w]; acc += d * d; }
+  }
+  if (sse) {
+    __shared__ float red[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sse, red[0] + red[1] + red[2] + red[3]);
+  }
+}
+
+int affine_warp_launch(const float* img, const int64_t is[4], const float* theta, int B, int C, int H, int W, float* out,
+                       const int64_t os[4], const float* ref, const int64_t rs[4], float* sse, hipStream_t st) {
+  SININN_CHECK(img && is && theta && out && os && B > 0 && C > 0 && H > 0 && W > 0, "affine_warp: bad arguments");
+  SININN_CHECK((!ref || (rs && sse)), "affine_warp: ref needs strides and sse");
+  const int64_t total = (int64_t)B * C * H * W;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  Str4 z{0, 0, 0, 0};
+  hipLaunchKernelGGL(affine_warp_kernel, dim3(blocks), dim3(256), 0, st, img, mk(is), theta, B, C, H, W,
+                     os[3] == 1 ? 1 : 0, out, mk(os), ref, ref ? mk(rs) : z, ref ? sse : nullptr);
+  SININN_LAUNCH_CHECK("affine_warp");
+  return 0;
+}
+
+__global__ void affine_warp_bwd_kernel(const float* __restrict__ gout, Str4 gs, const float* __restrict__ theta, int B,
+                                       int C, int H, int W, int x_fastest, float* __restrict__ gimg, Str4 gis) {
+  const int64_t total = (int64_t)B * C * H * W;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int b, c, y, x;
+    decode4(idx, C, H, W, x_fastest, b, c, y, x);
+    float ix, iy;
+    affine_src(theta + b * 6, x, y, H, W, ix, iy);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    const float g = gout[b * gs.b + c * gs.c + y * gs.h + x * gs.w];
+    float* base = gimg + b * gis.b + c * gis.c;
+    auto put = [&](int yy, int xx, float wgt) {
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) atomicAdd(base + yy * gis.h + xx * gis.w, g * wgt);
+    };
+    put(y0, x0, wy0 * wx0); put(y0, x0 + 1, wy0 * wx1); put(y0 + 1, x0, wy1 * wx0); put(y0 + 1, x0 + 1, wy1 * wx1);
+  }
+}
+
+int affine_warp_bwd_launch(const float* gout, const int64_t gs[4], const float* theta, int B, int C, int H, int W,
+                           float* gimg, const int64_t gis[4], hipStream_t st) {
+  SININN_CHECK(gout && gs && theta && gimg && gis && B > 0 && C > 0 && H > 0 && W > 0, "affine_warp_bwd: bad arguments");
+  const int64_t total = (int64_t)B * C * H * W;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(affine_warp_bwd_kernel, dim3(blocks), dim3(256), 0, st, gout, mk(gs), theta, B, C, H, W,
+                     gs[3] == 1 ? 1 : 0, gimg, mk(gis));
+  SININN_LAUNCH_CHECK("affine_warp_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// optical-flow backward warp + photometric L1 (planar NCHW, C <= 8)
+//   one lane per output pixel; the two right-hand taps of the 4-tap gather are taken from the next
+//   lane's left-hand taps with a wavefront shuffle whenever the neighbour samples the adjacent
+//   source column of the same rows (true almost everywhere for a smooth flow), else loaded.
+// ------------------------------------------------------------------------------------------------
+constexpr int FW_MAXC = 8;
+__global__ void flow_warp_l1_kernel(const float* __restrict__ img, const float* __restrict__ flow,
+                                    const float* __restrict__ target, int B, int C, int H, int W,
+                                    float* __restrict__ warped, float* __restrict__ metric) {
+  const int64_t HW = (int64_t)H * W;
+  const int64_t total = (int64_t)B * HW;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // grid covers total rounded up to 64
+  const bool live = idx < total;
+  const int64_t pidx = live ? idx : total - 1;
+  const int b = (int)(pidx / HW);
+  const int64_t r = pidx % HW;
+  const int y = (int)(r / W), x = (int)(r % W);
+  const float fx = flow[(b * 2 + 0) * HW + r], fy = flow[(b * 2 + 1) * HW + r];
+  // grid = (coords+flow)/(W-1,H-1)*2-1, sampled with align_corners=False  (quirk C-18 kept)
+  const float gxn = (x + fx) / (float)(W - 1) * 2.f - 1.f, gyn = (y + fy) / (float)(H - 1) * 2.f - 1.f;
+  const float ix = ((gxn + 1.f) * W - 1.f) * 0.5f, iy = ((gyn + 1.f) * H - 1.f) * 0.5f;
+  const float flx = floorf(ix), fly = floorf(iy);
+  const int x0 = (int)flx, y0 = (int)fly;
+  const float wx1 = ix - flx, wy1 = iy - fly, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+  const int lane = threadIdx.x & 63;
+  const int nx0 = __shfl_down(x0, 1), ny0 = __shfl_down(y0, 1), nb = __shfl_down(b, 1);
+  const bool share = (lane < 63) && (nb == b) && (nx0 == x0 + 1) && (ny0 == y0);
+  float l1 = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float* base = img + ((int64_t)b * C + c) * HW;
+    auto tap = [&](int yy, int xx) -> float {
+      return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? base[(int64_t)yy * W + xx] : 0.f;
+    };
+    const float t00 = tap(y0, x0), t10 = tap(y0 + 1, x0);
+    const float n00 = __shfl_down(t00, 1), n10 = __shfl_down(t10, 1);
+    const float t01 = share ? n00 : tap(y0, x0 + 1);
+    const float t11 = share ? n10 : tap(y0 + 1, x0 + 1);
+    const float val = t00 * wy0 * wx0 + t01 * wy0 * wx1 + t10 * wy1 * wx0 + t11 * wy1 * wx1;
+    if (live) {
+      if (warped) warped[((int64_t)b * C + c) * HW + r] = val;
+      if (target) l1 += fabsf(target[((int64_t)b * C + c) * HW + r] - val);
+    }
+  }
+  if (live && metric) metric[(int64_t)b * HW + r] = l1 / (float)C;
+}
+
+int flow_warp_l1_launch(const float* img, const float* flow, const float* target, int B, int C, int H, int W,
+                        float* warped, float* metric, hipStream_t st) {
+  SININN_CHECK(img && flow && (warped || metric), "flow_warp_l1: null pointer");
+  SININN_CHECK(!metric || target, "flow_warp_l1: metric needs target");
+  SININN_CHECK(B > 0 && C > 0 && C <= FW_MAXC && H > 1 && W > 1, "flow_warp_l1: bad shape (C<=8, H,W>1)");
+  const int64_t total = (int64_t)B * H * W;
+  hipLaunchKernelGGL(flow_warp_l1_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, img, flow, target, B,
+                     C, H, W, warped, metric);
+  SININN_LAUNCH_CHECK("flow_warp_l1");
+  return 0;
+}
+
+__global__ void flow_warp_l1_bwd_kernel(const float* __restrict__ img, const float* __restrict__ flow,
+                                        const float* __restrict__ target, const float* __restrict__ warped,
+                                        const float* __restrict__ gwarped, const float* __restrict__ gmetric, int B,
+                                        int C, int H, int W, float* __restrict__ gimg, float* __restrict__ gflow) {
+  const int64_t HW = (int64_t)H * W;
+  const int64_t total = (int64_t)B * HW;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int b = (int)(idx / HW);
+  const int64_t r = idx % HW;
+  const int y = (int)(r / W), x = (int)(r % W);
+  const float fx = flow[(b * 2 + 0) * HW + r], fy = flow[(b * 2 + 1) * HW + r];
+  const float gxn = (x + fx) / (float)(W - 1) * 2.f - 1.f, gyn = (y + fy) / (float)(H - 1) * 2.f - 1.f;
+  const float ix = ((gxn + 1.f) * W - 1.f) * 0.5f, iy = ((gyn + 1.f) * H - 1.f) * 0.5f;
+  const float flx = floorf(ix), fly = floorf(iy);
+  const int x0 = (int)flx, y0 = (int)fly;
+  const float wx1 = ix - flx, wy1 = iy - fly, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+  const float gm = gmetric ? gmetric[(int64_t)b * HW + r] / (float)C : 0.f;
+  float gix = 0.f, giy = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const int64_t o = ((int64_t)b * C + c) * HW;
+    float g = gwarped ? gwarped[o + r] : 0.f;
+    if (gmetric) {
+      const float d = target[o + r] - warped[o + r];
+      g += (d > 0.f) ? -gm : ((d < 0.f) ? gm : 0.f);
+    }
+    const float* base = img + o;
+    auto tap = [&](int yy, int xx) -> float {
+      return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? base[(int64_t)yy * W + xx] : 0.f;
+    };
+    const float t00 = tap(y0, x0), t01 = tap(y0, x0 + 1), t10 = tap(y0 + 1, x0), t11 = tap(y0 + 1, x0 + 1);
+    gix += g * ((t01 - t00) * wy0 + (t11 - t10) * wy1);
+    giy += g * ((t10 - t00) * wx0 + (t11 - t01) * wx1);
+    if (gimg) {
+      auto put = [&](int yy, int xx, float wgt) {
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) atomicAdd(gimg + o + (int64_t)yy * W + xx, g * wgt);
+      };
+      put(y0, x0, wy0 * wx0); put(y0, x0 + 1, wy0 * wx1); put(y0 + 1, x0, wy1 * wx0); put(y0 + 1, x0 + 1, wy1 * wx1);
+    }
+  }
+  if (gflow) {
+    gflow[(b * 2 + 0) * HW + r] = gix * (float)W / (float)(W - 1);
+    gflow[(b * 2 + 1) * HW + r] = giy * (float)H / (float)(H - 1);
+  }
+}
+
+int flow_warp_l1_bwd_launch(const float* img, const float* flow, const float* target, const float* warped,
+                            const float* gwarped, const float* gmetric, int B, int C, int H, int W, float* gimg,
+                            float* gflow, hipStream_t st) {
+  SININN_CHECK(img && flow && (gwarped || gmetric) && (gimg || gflow), "flow_warp_l1_bwd: null pointer");
+  SININN_CHECK(!gmetric || (target && warped), "flow_warp_l1_bwd: metric gradient needs target and warped");
+  SININN_CHECK(B > 0 && C > 0 && C <= FW_MAXC && H > 1 && W > 1, "flow_warp_l1_bwd: bad shape");
+  const int64_t total = (int64_t)B * H * W;
+  hipLaunchKernelGGL(flow_warp_l1_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, img, flow,
+                     target, warped, gwarped, gmetric, B, C, H, W, gimg, gflow);
+  SININN_LAUNCH_CHECK("flow_warp_l1_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// frame-window sampler
+// ------------------------------------------------------------------------------------------------
+__global__ void sample_windows_kernel(const uint8_t* __restrict__ hr_clip, const uint8_t* __restrict__ lr_clip,
+                                      const int* __restrict__ idx, int n, int T, int H, int W, int h, int w, int win,
+                                      float* __restrict__ hr_out, Str4 hs, float* __restrict__ lr_out, Str4 ls) {
+  const int64_t n_hr = (int64_t)n * H * W * 3;
+  const int lrc = (2 * win + 1) * 4;
+  const int64_t n_lr = (int64_t)n * h * w * lrc;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_hr + n_lr;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    if (k < n_hr) {
+      int64_t r = k;
+      const int c = r % 3; r /= 3;
+      const int x = r % W; r /= W;
+      const int y = r % H;
+      const int s = (int)(r / H);
+      int t = idx[s]; t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+      hr_out[s * hs.b + c * hs.c + y * hs.h + x * hs.w] = (float)hr_clip[(((int64_t)t * H + y) * W + x) * 3 + c] / 255.f;
+    } else {
+      int64_t r = k - n_hr;
+      const int c = r % lrc; r /= lrc;
+      const int x = r % w; r /= w;
+      const int y = r % h;
+      const int s = (int)(r / h);
+      int t = idx[s] - win + c / 4; t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+      lr_out[s * ls.b + c * ls.c + y * ls.h + x * ls.w] = (float)lr_clip[(((int64_t)t * h + y) * w + x) * 4 + (c & 3)] / 255.f;
+    }
+  }
+}
+
+int sample_windows_launch(const uint8_t* hr_clip, const uint8_t* lr_clip, const int* idx, int n, int T, int H, int W,
+                          int h, int w, int win, float* hr_out, const int64_t hs[4], float* lr_out,
+                          const int64_t ls[4], hipStream_t st) {
+  SININN_CHECK(hr_clip && lr_clip && idx && hr_out && lr_out && hs && ls, "sample_windows: null pointer");
+  SININN_CHECK(n > 0 && T > 0 && H > 0 && W > 0 && h > 0 && w > 0 && win >= 0, "sample_windows: bad shape");
+  const int64_t total = (int64_t)n * H * W * 3 + (int64_t)n * h * w * (2 * win + 1) * 4;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(sample_windows_kernel, dim3(blocks), dim3(256), 0, st, hr_clip, lr_clip, idx, n, T, H, W, h, w,
+                     win, hr_out, mk(hs), lr_out, mk(ls));
+  SININN_LAUNCH_CHECK("sample_windows");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam semantics, L2 weight decay)
+// ------------------------------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                            float bc1, float sqrt_bc2, float gscale) {
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const float step_size = lr / bc1;
+  auto upd = [&](float& pv, float gv, float& mv, float& vv) {
+    const float gg = gv * gscale + wd * pv;
+    mv = b1 * mv + (1.f - b1) * gg;
+    vv = b2 * vv + (1.f - b2) * gg * gg;
+    const float denom = sqrtf(vv) / sqrt_bc2 + eps;
+    pv -= step_size * (mv / denom);
+  };
+  for (int64_t i = tid; i < n4; i += stride) {
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i], mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+    const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { float a = pv[k], bm = mv[k], bv = vv[k]; upd(a, gv[k], bm, bv); pv[k] = a; mv[k] = bm; vv[k] = bv; }
+    reinterpret_cast<f32x4*>(p)[i] = pv; reinterpret_cast<f32x4*>(m)[i] = mv; reinterpret_cast<f32x4*>(v)[i] = vv;
+  }
+  for (int64_t i = (n4 << 2) + tid; i < n; i += stride) upd(p[i], g[i], m[i], v[i]);
+}
+
+int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                float wd, int step, float gscale, hipStream_t st) {
+  SININN_CHECK(p && g && m && v && n > 0 && step >= 1, "adam: bad arguments");
+  SININN_CHECK(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), "adam: buffers must be 16-byte aligned");
+  // bias corrections in double like torch.optim.Adam's python-float arithmetic
+  const float bc1 = (float)(1.0 - pow((double)b1, (double)step));
+  const float bc2 = (float)(1.0 - pow((double)b2, (double)step));
+  const int blocks = (int)(((n >> 2) + 255) / 256 < 4096 ? ((n >> 2) + 255) / 256 : 4096);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd,
+                     bc1, sqrtf(bc2), gscale);
+  SININN_LAUNCH_CHECK("adam");
+  return 0;
+}
+
+}  // namespace sininn

@@ -1,0 +1,252 @@
+// Weight gradient of the subnet convolutions (backward of nn.Conv2d in archs.py:11-17) on
+// v_mfma_f32_16x16x4_f32.
+//
+// GEMM view (reduction over pixels):
+//     dW[tap][n][c] = sum_pix dout[pix][n] * in[pix + off(tap)][c]        db[n] = sum_pix dout[pix][n]
+//   * MFMA rows = output channels n, MFMA cols = input channels c, k = 4 consecutive pixels of a row
+//   * a block owns (RT*16 rows) x (CT*16 cols) x ALL taps of the output and walks a contiguous range
+//     of 8x16-pixel tiles (split-K over pixels); the `in` halo tile is staged once per pixel tile
+//     and shared by the 9 taps; the dout A-fragment is shared by all taps / column tiles of a wave
+//   * partial sums go to a slab per split; a second kernel reduces the slabs in a fixed order
+//     (bitwise reproducible, no float atomics) straight into the OIHW gradient (+=).
+#include "common.h"
+
+namespace sininn {
+
+struct WgradDev {
+  const float* in; int in_stride; int Cin;
+  const float* dout; int dout_stride; int N;
+  int B, H, W;
+  int tiles_x, tiles_y, ntiles, tiles_per_split;
+  float* partial;   // [S][taps][Nr][Cc]
+  float* bpartial;  // [S][Nr]
+  int Nr, Cc;
+};
+
+constexpr int WG_TH = 8;   // pixel tile 8 x 16
+
+template <int KS, int RT, int CT>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradDev p) {
+  constexpr int HALO = KS / 2;
+  constexpr int IW = 16 + 2 * HALO;
+  constexpr int IH = WG_TH + 2 * HALO;
+  constexpr int NPIX_IN = IH * IW;
+  constexpr int NPIX = WG_TH * 16;
+  constexpr int TAPS = KS * KS;
+  constexpr int BNW = RT * 16, BCW = CT * 16;
+  constexpr int SD = BNW + 16;     // LDS row strides (floats): == 16 mod 32 -> the 4 k-lanes of a
+  constexpr int SI = BCW + 16;     // ds_read_b32 hit disjoint bank groups
+  constexpr int NPAIR = RT * CT / 4;
+  constexpr int D_F4 = (NPIX * BNW / 4 + 255) / 256;
+  constexpr int I_F4 = (NPIX_IN * BCW / 4 + 255) / 256;
+  static_assert((RT * CT) % 4 == 0, "pairs must split over 4 waves");
+
+  __shared__ __attribute__((aligned(16))) float d_lds[NPIX * SD];
+  __shared__ __attribute__((aligned(16))) float i_lds[NPIX_IN * SI];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, kq = lane >> 4;
+  const int split = blockIdx.x;
+  const int n0 = blockIdx.y * BNW, c0 = blockIdx.z * BCW;
+
+  int prt[NPAIR], pct[NPAIR];
+#pragma unroll
+  for (int q = 0; q < NPAIR; ++q) { const int pr = wave + 4 * q; prt[q] = pr % RT; pct[q] = pr / RT; }
+
+  f32x4 acc[NPAIR][TAPS];
+#pragma unroll
+  for (int q = 0; q < NPAIR; ++q)
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) acc[q][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum[NPAIR];
+#pragma unroll
+  for (int q = 0; q < NPAIR; ++q) bsum[q] = 0.f;
+
+  const int t_begin = split * p.tiles_per_split;
+  const int t_end = min(t_begin + p.tiles_per_split, p.ntiles);
+
+  f32x4 d_reg[D_F4], i_reg[I_F4];
+  auto load_tile = [&](int tile) {
+    int tt = tile;
+    const int tx = tt % p.tiles_x; tt /= p.tiles_x;
+    const int ty = tt % p.tiles_y;
+    const int b = tt / p.tiles_y;
+    const int y0 = ty * WG_TH, x0 = tx * 16;
+#pragma unroll
+    for (int r = 0; r < D_F4; ++r) {
+      const int f = tid + 256 * r;
+      const int pix = f / (BNW / 4), n4 = f % (BNW / 4);
+      const int gy = y0 + pix / 16, gx = x0 + (pix & 15);
+      const int n = n0 + n4 * 4;
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (pix < NPIX && gy < p.H && gx < p.W && n < p.N)   // N % 4 == 0 is checked on the host
+        val = *reinterpret_cast<const f32x4*>(p.dout + ((size_t)(b * p.H + gy) * p.W + gx) * p.dout_stride + n);
+      d_reg[r] = val;
+    }
+#pragma unroll
+    for (int r = 0; r < I_F4; ++r) {
+      const int f = tid + 256 * r;
+      const int pix = f / (BCW / 4), c4 = f % (BCW / 4);
+      const int py = pix / IW, px = pix - py * IW;
+      const int gy = y0 + py - HALO, gx = x0 + px - HALO;
+      const int c = c0 + c4 * 4;
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (pix < NPIX_IN && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && c < p.Cin)
+        val = *reinterpret_cast<const f32x4*>(p.in + ((size_t)(b * p.H + gy) * p.W + gx) * p.in_stride + c);
+      i_reg[r] = val;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int r = 0; r < D_F4; ++r) {
+      const int f = tid + 256 * r;
+      const int pix = f / (BNW / 4), n4 = f % (BNW / 4);
+      if (pix < NPIX) *reinterpret_cast<f32x4*>(d_lds + pix * SD + n4 * 4) = d_reg[r];
+    }
+#pragma unroll
+    for (int r = 0; r < I_F4; ++r) {
+      const int f = tid + 256 * r;
+      const int pix = f / (BCW / 4), c4 = f % (BCW / 4);
+      if (pix < NPIX_IN) *reinterpret_cast<f32x4*>(i_lds + pix * SI + c4 * 4) = i_reg[r];
+    }
+  };
+
+  if (t_begin < t_end) load_tile(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();            // previous tile's reads are done
+    store_tile();
+    __syncthreads();
+    if (tile + 1 < t_end) load_tile(tile + 1);   // in flight under the MFMAs below
+
+    for (int ks = 0; ks < NPIX / 4; ++ks) {
+      const int prow = ks >> 2, pcol = (ks & 3) * 4 + kq;     // this lane's pixel of the k-step
+      const float* drow = d_lds + (prow * 16 + pcol) * SD + li;
+      const float* irow = i_lds + (prow * IW + pcol) * SI + li;
+      float afr[NPAIR];
+#pragma unroll
+      for (int q = 0; q < NPAIR; ++q) {
+        afr[q] = drow[prt[q] * 16];
+        bsum[q] += afr[q];
+      }
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        const int dy = t / KS, dx = t % KS;
+#pragma unroll
+        for (int q = 0; q < NPAIR; ++q) {
+          const float bfr = irow[(dy * IW + dx) * SI + pct[q] * 16];
+          acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[q], bfr, acc[q][t], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- write the slab: D[row = n (4*kq + r)][col = c (li)] --------------------------------------
+#pragma unroll
+  for (int q = 0; q < NPAIR; ++q) {
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + prt[q] * 16 + 4 * kq + r;
+        const int c = c0 + pct[q] * 16 + li;
+        if (n < p.Nr && c < p.Cc)
+          p.partial[(((size_t)split * TAPS + t) * p.Nr + n) * p.Cc + c] = acc[q][t][r];
+      }
+    }
+    // bias partial: lanes (li, kq) hold sum over their pixels of dout[.][n = rt*16 + li]
+    float bs = bsum[q];
+    bs += __shfl_xor(bs, 16);
+    bs += __shfl_xor(bs, 32);
+    if (blockIdx.z == 0 && pct[q] == 0 && kq == 0) {
+      const int n = n0 + prt[q] * 16 + li;
+      if (n < p.Nr) p.bpartial[(size_t)split * p.Nr + n] = bs;
+    }
+  }
+}
+
+// Reduce S slabs in order and accumulate into the OIHW gradient:  gw[n][c][tap] += sum_s partial[s][tap][n][c]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial,
+                                    int S, int taps, int Nr, int Cc, int N, int Cin,
+                                    float* __restrict__ gw, float* __restrict__ gb) {
+  const int total = taps * N * Cin;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < total) {
+    const int c = idx % Cin;
+    const int n = (idx / Cin) % N;
+    const int t = idx / (Cin * N);
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += partial[(((size_t)k * taps + t) * Nr + n) * Cc + c];
+    gw[((size_t)n * Cin + c) * taps + t] += s;
+  }
+  if (gb != nullptr && idx < N) {
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += bpartial[(size_t)k * Nr + idx];
+    gb[idx] += s;
+  }
+}
+
+struct WgradPlan { int RT, CT, Nr, Cc, nblk, cblk, S, tiles_per_split, ntiles, tiles_x, tiles_y; size_t bytes; };
+
+static WgradPlan make_plan(int N, int Cin, int ksize, int B, int H, int W) {
+  WgradPlan pl;
+  // row tiles: 3 when N is a multiple of 48 but not of 64 (N=48), else 4; col tiles 4 with RT=3, else 2 or 4
+  if (N % 64 != 0 && N % 48 == 0) { pl.RT = 3; pl.CT = 4; }
+  else { pl.RT = 4; pl.CT = (Cin >= 64 && ksize == 1) ? 4 : 2; }
+  const int bnw = pl.RT * 16, bcw = pl.CT * 16;
+  pl.nblk = (N + bnw - 1) / bnw;
+  pl.cblk = (Cin + bcw - 1) / bcw;
+  pl.Nr = pl.nblk * bnw;
+  pl.Cc = pl.cblk * bcw;
+  pl.tiles_x = (W + 15) / 16;
+  pl.tiles_y = (H + WG_TH - 1) / WG_TH;
+  pl.ntiles = B * pl.tiles_x * pl.tiles_y;
+  int S = 512 / (pl.nblk * pl.cblk);
+  if (S < 1) S = 1;
+  if (S > pl.ntiles) S = pl.ntiles;
+  pl.tiles_per_split = (pl.ntiles + S - 1) / S;
+  pl.S = (pl.ntiles + pl.tiles_per_split - 1) / pl.tiles_per_split;
+  const int taps = ksize * ksize;
+  pl.bytes = ((size_t)pl.S * taps * pl.Nr * pl.Cc + (size_t)pl.S * pl.Nr) * sizeof(float);
+  return pl;
+}
+
+size_t wgrad_workspace_bytes(int N, int Cin, int ksize, int B, int H, int W) {
+  return make_plan(N, Cin, ksize, B, H, W).bytes;
+}
+
+template <int KS>
+static void launch_wgrad(const WgradPlan& pl, const WgradDev& d, hipStream_t st) {
+  dim3 grid(pl.S, pl.nblk, pl.cblk);
+  if (pl.RT == 3) hipLaunchKernelGGL((wgrad_mfma_kernel<KS, 3, 4>), grid, dim3(256), 0, st, d);
+  else if (pl.CT == 4) hipLaunchKernelGGL((wgrad_mfma_kernel<KS, 4, 4>), grid, dim3(256), 0, st, d);
+  else hipLaunchKernelGGL((wgrad_mfma_kernel<KS, 4, 2>), grid, dim3(256), 0, st, d);
+}
+
+int wgrad_launch(const float* in, int in_stride, int Cin, const float* dout, int dout_stride, int N,
+                 int B, int H, int W, int ksize, float* gw, float* gb, void* ws, size_t ws_bytes, hipStream_t st) {
+  SININN_CHECK(ksize == 1 || ksize == 3, "wgrad: ksize %d not in {1,3}", ksize);
+  SININN_CHECK(in && dout && gw && ws, "wgrad: null pointer");
+  SININN_CHECK(Cin > 0 && Cin % 4 == 0 && N > 0 && N % 4 == 0, "wgrad: Cin=%d and N=%d must be multiples of 4", Cin, N);
+  SININN_CHECK(in_stride >= Cin && in_stride % 4 == 0 && aligned16(in), "wgrad: in must be 16-byte aligned, stride %% 4 == 0");
+  SININN_CHECK(dout_stride >= N && dout_stride % 4 == 0 && aligned16(dout), "wgrad: dout must be 16-byte aligned, stride %% 4 == 0");
+  SININN_CHECK(B > 0 && H > 0 && W > 0, "wgrad: bad shape");
+  const WgradPlan pl = make_plan(N, Cin, ksize, B, H, W);
+  SININN_CHECK(ws_bytes >= pl.bytes, "wgrad: workspace too small (%zu < %zu)", ws_bytes, pl.bytes);
+  WgradDev d;
+  d.in = in; d.in_stride = in_stride; d.Cin = Cin; d.dout = dout; d.dout_stride = dout_stride; d.N = N;
+  d.B = B; d.H = H; d.W = W; d.tiles_x = pl.tiles_x; d.tiles_y = pl.tiles_y; d.ntiles = pl.ntiles;
+  d.tiles_per_split = pl.tiles_per_split; d.Nr = pl.Nr; d.Cc = pl.Cc;
+  const int taps = ksize * ksize;
+  d.partial = static_cast<float*>(ws);
+  d.bpartial = d.partial + (size_t)pl.S * taps * pl.Nr * pl.Cc;
+  if (ksize == 3) launch_wgrad<3>(pl, d, st); else launch_wgrad<1>(pl, d, st);
+  SININN_LAUNCH_CHECK("wgrad_mfma");
+  const int total = taps * N * Cin;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st,
+                     d.partial, d.bpartial, pl.S, taps, pl.Nr, pl.Cc, N, Cin, gw, gb);
+  SININN_LAUNCH_CHECK("wgrad_reduce");
+  return 0;
+}
+
+}  // namespace sininn
