@@ -1,0 +1,195 @@
+"""bench.py -- training frames/sec of the sin-inn INN training step on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full SingleVideoINN.training_step (forward pass + loss + backward, reverse pass + loss + backward,
+fused Adam) on a batch drawn by the frame-window sampler kernel from a synthetic uint8 clip that is already
+resident in HBM.  Workload = BASELINE configs[1]: 8 GLOW blocks (-c 4 per level x 2 levels), 256x256x3 frames,
+batch 16 per GPU, fp32 (f32 MFMA).  N>1: weak scaling, one RCCL all-reduce of the flat gradient per step.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the f32-MFMA implicit-GEMM conv of the 3x3
+coupling subnet, 256 -> 2*Co channels at level 0) timed with HIP events on the launch stream inside the timed
+region; `cpu_baseline` times the CPU oracle (torch-CPU restatement, "port") on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def make_opt(num_coupling, lr_window):
+    o = types.SimpleNamespace(scale=4, num_coupling=num_coupling, lr_window=lr_window, architecture='SRF', gpu_ids=[0],
+                              rotation=5.0, translation=5.0, tcr_iters=5, lambda_fwd_rec=1.0, lambda_fwd_mmd=0.0,
+                              lambda_latent_nll=0.0, lambda_bwd_rec=1.0, lambda_bwd_mmd=0.0, lambda_bwd_tcr=0.0,
+                              learning_rate=1e-4, adam_betas=[0.9, 0.99], weight_decay=1e-5, temp=0.8,
+                              operation='train', fps=10, random_seed=0)
+    o.lr_dims = (2 * lr_window + 1) * 4
+    o.z_dims = 192 - o.lr_dims
+    return o
+
+
+class KernelTimer:
+    """HIP events around every launch of the dominant kernel (recorded on the stream the kernel is launched on)."""
+
+    def __init__(self, match):
+        self.match, self.events, self.enabled = match, [], False
+
+    def install(self):
+        from sin_inn_amd import ops
+        real = ops.conv
+        timer = self
+
+        def timed_conv(**kw):
+            if timer.enabled and timer.match(kw):
+                s = torch.cuda.current_stream()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(s)
+                real(**kw)
+                e1.record(s)
+                timer.events.append((e0, e1))
+            else:
+                real(**kw)
+        ops.conv = timed_conv
+
+    def mean_ms(self):
+        if not self.events:
+            return None
+        return sum(a.elapsed_time(b) for a, b in self.events) / len(self.events)
+
+
+def cpu_baseline(args, opt, seconds_budget=30.0):
+    """The CPU oracle's training step on the host cores (same architecture / sizes; bounded sample)."""
+    from oracle import sininn_oracle as O
+    torch.manual_seed(0)
+    b = args.cpu_batch
+    ref = O.SRFlowOracle(3, args.size, args.size, scale=4, num_coupling=args.num_coupling)
+    o = torch.optim.Adam(ref.parameters(), lr=1e-4, betas=(0.9, 0.99), weight_decay=1e-5)
+    hr = torch.rand(b, 3, args.size, args.size)
+    lr = torch.rand(b, opt.lr_dims, args.size // 8, args.size // 8)
+    z = torch.randn(b, opt.z_dims, args.size // 8, args.size // 8)
+    lam = dict(fwd_rec=1.0, fwd_mmd=0.0, latent_nll=0.0, bwd_rec=1.0, bwd_mmd=0.0)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    O.training_step(ref, hr, lr, z, lam, opt.lr_dims); o.step()          # warm-up
+    t0, n = time.time(), 0
+    while n < 1 or (time.time() - t0 < seconds_budget * 0.5 and n < 3):
+        O.training_step(ref, hr, lr, z, lam, opt.lr_dims); o.step()
+        n += 1
+    dt = (time.time() - t0) / n
+    return {'value': b / dt, 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{n} timed + 1 warm-up training steps of the torch-CPU oracle, batch {b}, '
+                      f'{args.size}x{args.size}, -c {args.num_coupling}, fp32'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--num-coupling', type=int, default=4, help='GLOW blocks per level (2 levels): 4 -> 8-block INN')
+    ap.add_argument('--lr-window', type=int, default=10)
+    ap.add_argument('--frames', type=int, default=64)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=4)
+    args = ap.parse_args()
+
+    import sin_inn_amd
+    from sin_inn_amd import dist as sdist
+    rank, ws = sdist.init_from_env()
+    assert ws == args.gpus or (ws == 1 and args.gpus == 1), f'--gpus {args.gpus} but WORLD_SIZE={ws}'
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    import lit_wrapper
+    from data import FrameStore
+    from sin_inn_amd.functional import sample_windows
+
+    opt = make_opt(args.num_coupling, args.lr_window)
+    torch.manual_seed(0)                                   # identical random-init weights on every rank
+    model = lit_wrapper.SingleVideoINN(3, args.size, args.size, opt).to(dev)
+    optim = model.attach_optimizer()
+    store = FrameStore.synthetic(args.frames, args.size, args.size).to(dev)   # clip resident in HBM before timing
+    lo, hi = args.lr_window, args.frames - args.lr_window
+    gen = torch.Generator().manual_seed(100 + rank)        # each rank draws its own frames (data-parallel shard)
+
+    b, m0 = args.batch, args.batch * (args.size // 4) ** 2
+    co0 = 24
+
+    def is_dominant(kw):   # 3x3 coupling conv, 256 -> 2*24 columns, level-0 resolution
+        return kw.get('ksize') == 3 and kw.get('Cin') == 256 and kw.get('Np') == 2 * co0 and kw.get('H') == args.size // 4
+    timer = KernelTimer(is_dominant)
+    timer.install()
+
+    def step():
+        idx = torch.randint(lo, hi, (b,), generator=gen).to(dev)
+        hr, lr = sample_windows(store.hr, store.lr, idx, args.lr_window)
+        batch = {'hr': hr, 'lr': lr}
+        model.training_step([batch, batch], 0)
+
+    def barrier():
+        if ws > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if ws > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank != 0:
+        return
+    ms_per_step = dt / args.steps * 1e3
+    value = ws * b * args.steps / dt
+    # roofline of the dominant kernel: algorithmic FLOPs (2 * pixels * 9*256 * 2*Co) per launch
+    kms = timer.mean_ms()
+    flops = 2.0 * m0 * 9 * 256 * (2 * co0)
+    roof = None
+    if kms:
+        ach = flops / (kms * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                'kernel': 'conv_mfma_kernel<3,8,4,1,2,3> (3x3 coupling conv 256->48, level 0)',
+                'launches_timed': len(timer.events), 'avg_ms': kms, 'alg_flops_per_launch': flops,
+                'alg_bytes_per_launch': 4.0 * (m0 * 256 + m0 * 3 * co0 + 9 * 256 * 2 * co0)}
+    out = {'metric': 'training frames/sec at 256x256 bs=16', 'value': value, 'unit': 'frames/s', 'n_gpus': ws,
+           'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'config': {'workload': f'BASELINE configs[1]: 8-block INN (SRF, -c {args.num_coupling} x 2 levels), '
+                                  f'{args.size}x{args.size}x3 synthetic clip ({args.frames} frames, lr_window '
+                                  f'{args.lr_window}), batch {b}/GPU, full training step (fwd+bwd, rev+bwd, Adam)',
+                      'global_batch': ws * b, 'num_coupling': args.num_coupling, 'parallelism': f'dp{ws}'},
+           'roofline': roof}
+    if not args.no_cpu_baseline and ws == 1:
+        out['cpu_baseline'] = cpu_baseline(args, opt)
+    else:
+        out['cpu_baseline'] = None
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

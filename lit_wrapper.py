@@ -1,0 +1,137 @@
+"""``SingleVideoINN`` -- the training / validation / inference surface of the sin-inn path (drop-in for the
+reference's lit_wrapper.py:12-138), running on the HIP kernels of ``sin-inn_amd``.
+
+Same method names and step structure as the reference: forward pass HR -> (LR | z) with reconstruction + MMD +
+latent terms, backward; reverse pass (LR | z) -> HR with reconstruction + MMD, backward; optional TCR iterations;
+one optimizer step.  Differences, all deliberate: device-agnostic construction (no hard-coded 'cuda' strings),
+``tcr_iters`` is cast to int (the reference feeds a float to range(), main.py:63 / lit_wrapper.py:63), latents are
+drawn directly in the pixel-major layout the kernels use, and Adam is the fused single-launch HIP optimizer.
+"""
+import logging
+import os
+import subprocess as sp
+
+import torch
+
+import sin_inn_amd.lightning as pl
+from sin_inn_amd import FusedAdam
+
+import loss
+from archs import InvRescaleNet, UncondSRFlow
+from tcr import TCR
+
+
+def _latent(b, z_dims, h, w, device, temp=1.0):
+    """z ~ N(0, temp^2), shape (b, z_dims, h, w), stored pixel-major (channels_last) like every other activation."""
+    z = torch.randn(b, h, w, z_dims, device=device)
+    if temp != 1.0:
+        z = z * temp
+    return z.permute(0, 3, 1, 2)
+
+
+def _cat_channels(a, b):
+    """torch.cat on dim 1 that keeps the pixel-major layout."""
+    return torch.cat((a.permute(0, 2, 3, 1), b.permute(0, 2, 3, 1)), dim=3).permute(0, 3, 1, 2)
+
+
+class SingleVideoINN(pl.LightningModule):
+    def __init__(self, c, h, w, opt):
+        super().__init__()
+        self.save_hyperparameters()
+        self.opt = opt
+        self.inn = {'SRF': UncondSRFlow, 'IRN': InvRescaleNet}[opt.architecture](c, h, w, opt)
+        n_params = sum(p.numel() for p in self.inn.parameters())
+        logging.info(f'Created model with {n_params / 1e6:.2f}M parameters. Using GPUs {opt.gpu_ids}')
+        self.tcr = TCR(opt.rotation, opt.translation)
+        self.automatic_optimization = False        # several backward() calls per step
+
+    # ---- training --------------------------------------------------------------------------------
+    def training_step(self, batch, batch_idx):
+        o = self.opt
+        optim = self.optimizers()
+        optim.zero_grad()
+        hr, lr = batch[0]['hr'], batch[0]['lr']
+        b, _, h, w = lr.shape
+        z = _latent(b, o.z_dims, h, w, hr.device)
+        lr_z = _cat_channels(lr, z)
+
+        # forward pass: HR -> (LR | z)
+        lr_z_hat = self.inn(hr)
+        fwd_loss = o.lambda_fwd_rec * loss.reconstruction(lr_z_hat[:, :o.lr_dims], lr)
+        fwd_loss = fwd_loss + o.lambda_fwd_mmd * loss.mmd(lr_z_hat, lr_z)
+        fwd_loss = fwd_loss + o.lambda_latent_nll * loss.latent_nll(lr_z_hat[:, o.lr_dims:])
+        self.manual_backward(fwd_loss)
+
+        # reverse pass: (LR | z) -> HR
+        hr_hat = self.inn(lr_z, rev=True)
+        bwd_loss = o.lambda_bwd_rec * loss.reconstruction(hr_hat, hr)
+        bwd_loss = bwd_loss + o.lambda_bwd_mmd * loss.mmd(hr_hat, hr, rev=True)
+        self.manual_backward(bwd_loss)
+
+        tcr_loss = 0
+        if o.lambda_bwd_tcr > 0:
+            # transformation consistency on the unsupervised pair: INN(warp(LR)) should equal warp(INN(LR))
+            hr_u, lr_u = batch[1]['hr'], batch[1]['lr']
+            iters = int(o.tcr_iters)
+            for _ in range(iters):
+                rand = torch.rand(b, 3)
+                z = _latent(b, o.z_dims, h, w, hr_u.device)
+                plain = _cat_channels(lr_u, z)
+                warped = _cat_channels(self.tcr(lr_u, rand, scale=1 / o.scale), z)
+                tcr_hr_hat = self.inn(warped, rev=True)
+                hr_hat_tcr = self.tcr(self.inn(plain, rev=True), rand)
+                tcr_loss = o.lambda_bwd_tcr / iters * loss.reconstruction(tcr_hr_hat, hr_hat_tcr)
+                self.manual_backward(tcr_loss)
+
+        optim.step()
+        self.log('train', (fwd_loss + bwd_loss + tcr_loss).detach())
+
+    def validation_step(self, batch, batch_idx):
+        o = self.opt
+        hr, lr = batch['hr'], batch['lr']
+        b, _, h, w = lr.shape
+        lr_z = _cat_channels(lr, _latent(b, o.z_dims, h, w, hr.device))
+        lr_z_hat = self.inn(hr)
+        hr_hat = self.inn(lr_z, rev=True)
+        self.log('lr_acc', loss.reconstruction(lr_z_hat[:, :o.lr_dims], lr))
+        self.log('hr_acc', loss.reconstruction(hr_hat, hr))
+        self.log('z_nll', loss.latent_nll(lr_z_hat[:, o.lr_dims:]))
+
+    # ---- inference -------------------------------------------------------------------------------
+    def infer(self, loader, opt, save_images=None, save_video=None):
+        """Reverse pass over every LR window; frames go to PNG files or are piped to ffmpeg (reference :91-128)."""
+        from PIL import Image
+        self.inn.eval()
+        device = self.device if self.device.type == 'cuda' else torch.device('cuda', opt.gpu_ids[0])
+        self.inn.to(device)
+        video = None
+        if save_video:
+            video = sp.Popen(['ffmpeg', '-framerate', '30', '-i', '-', '-c:v', 'libx264', '-preset', 'veryslow',
+                              '-crf', '18', '-y', save_video], stdin=sp.PIPE, stderr=sp.DEVNULL)
+        if save_images:
+            os.makedirs(save_images, exist_ok=True)
+        outputs = []
+        for bb, batch in enumerate(loader):
+            lr = batch['lr'].to(device)
+            b, _, h, w = lr.shape
+            lr_z = _cat_channels(lr, _latent(b, opt.z_dims, h, w, device, temp=opt.temp))
+            with torch.no_grad():
+                hr_hat = self.inn(lr_z, rev=True)
+            if save_images or video is not None:
+                frames = (hr_hat.permute(0, 2, 3, 1).clamp(0, 1) * 255).to(torch.uint8).cpu().numpy()
+                for i, frame in enumerate(frames):
+                    im = Image.fromarray(frame)
+                    if save_images:
+                        im.save(os.path.join(save_images, f'out_{bb:04d}_{i:02d}.png'))
+                    else:
+                        im.save(video.stdin, 'PNG')
+            else:
+                outputs.append(hr_hat)
+        if video is not None:
+            video.stdin.close()
+            video.communicate()
+        return outputs
+
+    def configure_optimizers(self):
+        return FusedAdam(self.parameters(), lr=self.opt.learning_rate, betas=tuple(self.opt.adam_betas),
+                         weight_decay=self.opt.weight_decay)

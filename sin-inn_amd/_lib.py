@@ -1,0 +1,97 @@
+"""ctypes binding of libsininn.so (the C ABI declared in include/sininn.h).
+
+The product path has NO CPU fallback: if the shared library is missing, or a tensor is not a
+contiguous-enough fp32 CUDA(HIP) tensor, the call raises.  (Same convention as the reference's raw
+pointer kernel call site, video-interpolation/my_utils/softsplat.py:239-331: asserts +
+NotImplementedError for CPU tensors.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsininn.so')
+
+c_f = C.c_void_p      # device float*
+c_i = C.c_void_p      # device int*
+I64x4 = C.c_int64 * 4
+
+
+class ConvArgs(C.Structure):
+    """Mirror of sininn_conv_args (include/sininn.h)."""
+    _fields_ = [
+        ('inp', c_f), ('in_stride', C.c_int), ('Cin', C.c_int),
+        ('w', c_f), ('bias', c_f), ('Np', C.c_int),
+        ('B', C.c_int), ('H', C.c_int), ('W', C.c_int), ('ksize', C.c_int),
+        ('mode', C.c_int),
+        ('out', c_f), ('out_stride', C.c_int), ('N', C.c_int),
+        ('out_map', c_i),
+        ('v', c_f), ('v_stride', C.c_int),
+        ('out2', c_f), ('out2_stride', C.c_int),
+        ('sbuf', c_f),
+        ('logdet', c_f),
+        ('Co', C.c_int), ('clamp', C.c_float),
+        ('mask', c_f), ('mask_stride', C.c_int),
+        ('addend', c_f), ('addend_stride', C.c_int), ('addend_map', c_i),
+    ]
+
+
+CONV_RELU, CONV_COUPLE_FWD, CONV_COUPLE_INV, CONV_MASK, CONV_ADD, CONV_LINEAR = range(6)
+
+_SIGS = {
+    'sininn_version': (C.c_int, []),
+    'sininn_last_error': (C.c_char_p, []),
+    'sininn_pack_conv_weights': (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, c_i, C.c_int, c_f, c_f, C.c_int, c_f, C.c_void_p]),
+    'sininn_coupling_colmap': (None, [C.c_int, C.POINTER(C.c_int)]),
+    'sininn_conv': (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    'sininn_conv_test_hooks': (None, [C.c_int, C.c_int]),
+    'sininn_wgrad_workspace_bytes': (C.c_size_t, [C.c_int] * 6),
+    'sininn_wgrad': (C.c_int, [c_f, C.c_int, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                               c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'sininn_coupling_bwd': (C.c_int, [c_f, C.c_int, c_i, c_f, C.c_int, c_i, c_f, c_f, C.c_int, C.c_int, C.c_int,
+                                      C.c_float, C.c_int, c_f, c_f, C.c_int, C.c_void_p]),
+    'sininn_squeeze': (C.c_int, [c_f, I64x4, c_f, I64x4, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i,
+                                 C.c_int, C.c_void_p]),
+    'sininn_permute_channels': (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int64, C.c_int, c_i, C.c_void_p]),
+    'sininn_sqdiff_sum': (C.c_int, [c_f, I64x4, c_f, I64x4, C.c_int, C.c_int, C.c_int, C.c_int, c_f, C.c_void_p]),
+    'sininn_sqdiff_bwd': (C.c_int, [c_f, I64x4, c_f, I64x4, C.c_int, C.c_int, C.c_int, C.c_int, c_f, C.c_float,
+                                    c_f, I64x4, c_f, I64x4, C.c_void_p]),
+    'sininn_mmd_gram': (C.c_int, [c_f, I64x4, c_f, I64x4, C.c_int, C.c_int, C.c_int, C.c_int, c_f, C.c_void_p]),
+    'sininn_mmd_finish': (C.c_int, [c_f, C.c_int, C.c_int, c_f, c_f, C.c_void_p]),
+    'sininn_mmd_bwd': (C.c_int, [c_f, I64x4, c_f, I64x4, C.c_int, C.c_int, C.c_int, C.c_int, c_f, c_f,
+                                 c_f, I64x4, c_f, I64x4, C.c_void_p]),
+    'sininn_affine_warp': (C.c_int, [c_f, I64x4, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f, I64x4, c_f, I64x4,
+                                     c_f, C.c_void_p]),
+    'sininn_affine_warp_bwd': (C.c_int, [c_f, I64x4, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f, I64x4, C.c_void_p]),
+    'sininn_flow_warp_l1': (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f, c_f, C.c_void_p]),
+    'sininn_flow_warp_l1_bwd': (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f, c_f,
+                                          C.c_void_p]),
+    'sininn_sample_windows': (C.c_int, [C.c_void_p, C.c_void_p, c_i, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, c_f, I64x4, c_f, I64x4, C.c_void_p]),
+    'sininn_adam_step': (C.c_int, [c_f, c_f, c_f, c_f, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
+                                   C.c_float, C.c_int, C.c_float, C.c_void_p]),
+}
+
+EXPORTED = tuple(_SIGS)
+_lib = None
+
+
+def lib():
+    """Load libsininn.so (once).  Raises if the HIP extension has not been built: no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise ImportError(f'{LIB_PATH} is missing: build it with `make -C sin-inn_amd/csrc` '
+                              '(or __graft_entry__.build()); there is no CPU fallback for the HIP path')
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)          # AttributeError if the ABI lost a symbol
+            fn.restype, fn.argtypes = res, args
+        if handle.sininn_version() != 1:
+            raise ImportError('libsininn.so ABI version mismatch')
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError('libsininn: ' + lib().sininn_last_error().decode())

@@ -1,0 +1,55 @@
+"""Data-parallel glue: one process per GPU, torch.distributed (backend "nccl" == RCCL on ROCm, "gloo" on CPU
+tests).  The only collective of the path is ONE all-reduce of the flat fp32 gradient buffer per step
+ -- the reference's Lightning DDP fires one bucketed all-reduce per manual_backward
+(main.py:112, lit_wrapper.py:49,56,72); summing locally first is mathematically identical."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from torchrun's environment (no-op for a single process)."""
+    ws = int(os.environ.get('WORLD_SIZE', '1'))
+    if ws <= 1 or dist.is_initialized():
+        return world()
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29500')
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if backend == 'nccl':
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    dist.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=ws)
+    return world()
+
+
+def allreduce_mean_(flat_buffers):
+    """In-place average of each flat gradient buffer over the ranks (one collective per buffer)."""
+    _, ws = world()
+    if ws == 1:
+        return
+    for buf in flat_buffers:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        buf.div_(ws)
+
+
+def broadcast_(tensors, src=0):
+    _, ws = world()
+    if ws == 1:
+        return
+    for t in tensors:
+        dist.broadcast(t, src=src)
+
+
+def shard_indices(global_indices, rank=None, world_size=None):
+    """Rank r takes positions r::world of every global batch."""
+    r, ws = world()
+    rank = r if rank is None else rank
+    world_size = ws if world_size is None else world_size
+    return global_indices[rank::world_size]

@@ -1,0 +1,198 @@
+"""Minimal stand-in for the slice of pytorch_lightning 1.2 that the reference's training loop uses
+(main.py:108-118, lit_wrapper.py:12-138, data.py:125-137).  pytorch_lightning is not installed in this image and
+its 1.2 API (``Trainer(gpus=...)``, ``ModelCheckpoint(period=...)``) no longer exists upstream, so the surface
+is provided here: ``LightningModule`` (optimizers / manual_backward / log / save_hyperparameters),
+``LightningDataModule``, ``Trainer.fit`` (epoch loop, validation every n epochs, checkpoint every ``period``
+epochs, resume), ``ModelCheckpoint`` and a file logger in place of WandbLogger.
+
+Data parallel: under ``torchrun`` every rank runs the same loop on its shard of each batch; the optimizer proxy
+averages the flat gradient buffer with ONE all-reduce (RCCL) right before ``step()``.
+"""
+import inspect
+import json
+import os
+import time
+
+import torch
+import torch.nn as nn
+
+from . import dist as sdist
+
+
+class LightningModule(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.automatic_optimization = True
+        self.trainer = None
+        self.hparams = {}
+        self._logged = {}
+
+    def save_hyperparameters(self, *_):
+        frame = inspect.currentframe().f_back
+        args = inspect.getargvalues(frame)
+        self.hparams = {k: args.locals[k] for k in args.args if k != 'self'}
+
+    def optimizers(self):
+        assert self.trainer is not None, 'optimizers() needs a Trainer (or attach_optimizer())'
+        return self.trainer.optimizer
+
+    def manual_backward(self, loss, *a, **kw):
+        loss.backward(*a, **kw)
+
+    def log(self, name, value, **_):
+        self._logged[name] = value.detach() if torch.is_tensor(value) else value
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def attach_optimizer(self, optimizer=None):
+        """Use the module without Trainer.fit (bench.py, tests): builds the optimizer proxy."""
+        tr = Trainer.__new__(Trainer)
+        tr.optimizer = _OptimizerProxy(optimizer if optimizer is not None else self.configure_optimizers())
+        tr.current_epoch, tr.global_step = 0, 0
+        self.trainer = tr
+        return tr.optimizer
+
+
+class LightningDataModule:
+    def train_dataloader(self):
+        raise NotImplementedError
+
+    def val_dataloader(self):
+        return None
+
+
+class _OptimizerProxy:
+    """What ``self.optimizers()`` returns: zero_grad()/step() of the wrapped optimizer + the DP gradient all-reduce."""
+
+    def __init__(self, optimizer):
+        self.optimizer = optimizer
+
+    def zero_grad(self):
+        self.optimizer.zero_grad()
+
+    def step(self, *a, **kw):
+        _, ws = sdist.world()
+        if ws > 1:
+            if hasattr(self.optimizer, 'flat_grads'):
+                sdist.allreduce_mean_(self.optimizer.flat_grads())
+            else:
+                sdist.allreduce_mean_([p.grad for g in self.optimizer.param_groups for p in g['params']
+                                       if p.grad is not None])
+        return self.optimizer.step(*a, **kw)
+
+    def __getattr__(self, name):
+        return getattr(self.optimizer, name)
+
+
+class ModelCheckpoint:
+    def __init__(self, period=1, dirpath=None):
+        self.period, self.dirpath = max(int(period), 1), dirpath
+
+
+class FileLogger:
+    """JSON-lines logger (stands in for WandbLogger(project='sin-inn', ...), main.py:105-107)."""
+
+    def __init__(self, project='sin-inn', save_dir='.', name='run', **_):
+        self.path = os.path.join(save_dir, f'{project}_{name}.jsonl')
+
+    def log_hyperparams(self, args):
+        self._write({'hyperparams': {k: (v if isinstance(v, (int, float, str, bool, type(None))) else str(v))
+                                     for k, v in vars(args).items()}})
+
+    def log_metrics(self, metrics, step):
+        self._write({'step': step, **metrics})
+
+    def _write(self, obj):
+        rank, _ = sdist.world()
+        if rank == 0:
+            with open(self.path, 'a') as f:
+                f.write(json.dumps(obj) + '\n')
+
+
+WandbLogger = FileLogger
+
+
+def _to_device(batch, device):
+    if torch.is_tensor(batch):
+        return batch.to(device, non_blocking=True)
+    if isinstance(batch, dict):
+        return {k: _to_device(v, device) for k, v in batch.items()}
+    if isinstance(batch, (list, tuple)):
+        return type(batch)(_to_device(v, device) for v in batch)
+    return batch
+
+
+class Trainer:
+    def __init__(self, gpus=None, max_epochs=1000, check_val_every_n_epoch=1, default_root_dir='.', logger=None,
+                 resume_from_checkpoint=None, callbacks=(), auto_lr_find=False, auto_scale_batch_size=False,
+                 log_every_n_steps=50, **_):
+        # auto_lr_find / auto_scale_batch_size are inert in the reference as well (trainer.tune() is never
+        # called, main.py:108-109)
+        self.gpus = list(gpus) if isinstance(gpus, (list, tuple)) else ([gpus] if gpus is not None else [0])
+        self.max_epochs, self.val_every = max_epochs, max(int(check_val_every_n_epoch), 1)
+        self.root, self.logger, self.resume = default_root_dir, logger, resume_from_checkpoint
+        self.ckpt = next((c for c in callbacks if isinstance(c, ModelCheckpoint)), None)
+        self.log_every = log_every_n_steps
+        self.optimizer = None
+        self.current_epoch, self.global_step = 0, 0
+
+    def _device(self):
+        rank, ws = sdist.init_from_env()
+        if ws > 1:
+            return torch.device('cuda', int(os.environ.get('LOCAL_RANK', rank)))
+        return torch.device('cuda', self.gpus[0])
+
+    def save_checkpoint(self, model, path):
+        rank, _ = sdist.world()
+        if rank != 0:
+            return
+        os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+        hp = {k: (vars(v) if hasattr(v, '__dict__') else v) for k, v in model.hparams.items()}
+        torch.save({'state_dict': model.state_dict(), 'epoch': self.current_epoch, 'global_step': self.global_step,
+                    'optimizer_states': [self.optimizer.state_dict()], 'hyper_parameters': hp}, path)
+
+    def fit(self, model, datamodule):
+        device = self._device()
+        model.to(device)
+        model.trainer = self
+        self.optimizer = _OptimizerProxy(model.configure_optimizers())
+        if self.resume:
+            ck = torch.load(self.resume, map_location=device)
+            model.load_state_dict(ck['state_dict'])
+            if ck.get('optimizer_states'):
+                self.optimizer.load_state_dict(ck['optimizer_states'][0])
+            self.current_epoch = int(ck.get('epoch', -1)) + 1
+            self.global_step = int(ck.get('global_step', 0))
+        _, ws = sdist.world()
+        if ws > 1:   # identical initial weights on every rank
+            sdist.broadcast_([p.data for p in model.parameters()])
+        train_loader = datamodule.train_dataloader()
+        val_loader = datamodule.val_dataloader()
+        ckpt_dir = (self.ckpt.dirpath if self.ckpt and self.ckpt.dirpath else os.path.join(self.root, 'checkpoints'))
+        t0 = time.time()
+        for epoch in range(self.current_epoch, self.max_epochs):
+            self.current_epoch = epoch
+            model.train()
+            for i, batch in enumerate(train_loader):
+                model.training_step(_to_device(batch, device), i)
+                self.global_step += 1
+                if self.logger is not None and self.global_step % self.log_every == 0:
+                    self._flush(model)
+            if val_loader is not None and (epoch + 1) % self.val_every == 0:
+                model.eval()
+                with torch.no_grad():
+                    for i, batch in enumerate(val_loader):
+                        model.validation_step(_to_device(batch, device), i)
+                self._flush(model, extra={'epoch': epoch, 'wall_s': time.time() - t0})
+            if self.ckpt is not None and (epoch + 1) % self.ckpt.period == 0:
+                self.save_checkpoint(model, os.path.join(ckpt_dir, f'epoch={epoch}.ckpt'))
+        return model
+
+    def _flush(self, model, extra=None):
+        if self.logger is None:
+            return
+        vals = {k: (float(v) if torch.is_tensor(v) else v) for k, v in model._logged.items()}
+        vals.update(extra or {})
+        self.logger.log_metrics(vals, self.global_step)

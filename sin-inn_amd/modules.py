@@ -1,0 +1,360 @@
+"""HIP-backed equivalents of the FrEIA operators the reference wires together in archs.py:26-71.
+
+Same operator protocol as the (absent, third-party) FrEIA modules the reference uses:
+``Op(dims_in, **kwargs)``; ``op([x], rev=False) -> [y]``; ``op.jacobian(x, rev)``;
+``op.output_dims(dims)``.  Semantics follow SURVEY.md Appendix A (GLOWCouplingBlock,
+PermuteRandom, IRevNetDownsampling).  All arithmetic runs in libsininn.so; tensors are fp32 and
+pixel-major (NHWC) inside the network, NCHW-shaped channels_last views at the boundary.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import CONV_ADD, CONV_COUPLE_FWD, CONV_COUPLE_INV, CONV_MASK, CONV_RELU
+
+HIDDEN = ops.HIDDEN
+
+# bumped by the fused optimiser (it updates weights through raw pointers, invisible to torch's
+# tensor version counters) so cached packed weights are rebuilt.
+WEIGHTS_EPOCH = [0]
+
+
+def bump_weights_epoch():
+    WEIGHTS_EPOCH[0] += 1
+
+
+def _vp(t, off=0, dtype=torch.float32):
+    return ops.ptr(t, off, dtype)
+
+
+def to_pixel_major(x):
+    """(B,C,H,W)-shaped tensor of any strides -> contiguous (B,H,W,C) tensor (zero-copy when already channels_last)."""
+    b, c, h, w = x.shape
+    v = x.permute(0, 2, 3, 1)
+    if v.is_contiguous():
+        return v
+    out = torch.empty((b, h, w, c), device=x.device, dtype=torch.float32)
+    ops.squeeze(x, out.permute(0, 3, 1, 2), b, c, h, w, 0, False)
+    return out
+
+
+class _LayoutImport(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return to_pixel_major(x.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.permute(0, 3, 1, 2)
+
+
+def import_nchw(x):
+    """autograd-aware to_pixel_major"""
+    v = x.permute(0, 2, 3, 1)
+    if v.is_contiguous():
+        return v
+    return _LayoutImport.apply(x)
+
+
+# ------------------------------------------------------------------------------------------------
+# subnet inspection + packed-weight cache
+# ------------------------------------------------------------------------------------------------
+def inspect_subnet(seq):
+    """The HIP path implements exactly archs.py:11-17: Conv(k) -> ReLU -> Conv(k), k in {1,3}, 'same' padding."""
+    ok = (isinstance(seq, nn.Sequential) and len(seq) == 3 and isinstance(seq[0], nn.Conv2d)
+          and isinstance(seq[1], nn.ReLU) and isinstance(seq[2], nn.Conv2d))
+    if ok:
+        k = seq[0].kernel_size[0]
+        for cv in (seq[0], seq[2]):
+            ok = ok and cv.kernel_size == (k, k) and cv.padding == (k // 2, k // 2) and cv.stride == (1, 1) \
+                and cv.dilation == (1, 1) and cv.groups == 1 and cv.bias is not None and k in (1, 3)
+        ok = ok and seq[0].out_channels == HIDDEN and seq[2].in_channels == HIDDEN
+    if not ok:
+        raise NotImplementedError('sin-inn_amd GLOWCouplingBlock supports subnet_conv / subnet_conv_1x1 style '
+                                  'subnets only (Conv2d(k)->ReLU->Conv2d(k), 256 hidden channels, k in {1,3})')
+    return seq[0], seq[2], k
+
+
+class _PackCache:
+    def __init__(self):
+        self.store = {}
+
+    def get(self, conv, colmap, want_dgrad):
+        key = (conv.weight.data_ptr(), conv.weight._version, conv.bias._version, WEIGHTS_EPOCH[0], want_dgrad)
+        hit = self.store.get(id(conv))
+        if hit is None or hit[0] != key:
+            packs = ops.pack_conv(conv.weight.detach(), conv.bias.detach(), colmap, want_dgrad)
+            hit = (key, packs)
+            self.store[id(conv)] = hit
+        return hit[1]
+
+
+def _grad_buf(p):
+    """The tensor parameter gradients are accumulated into (created on first use, like autograd would)."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    assert p.grad.is_contiguous()
+    return p.grad
+
+
+# ------------------------------------------------------------------------------------------------
+# GLOW coupling block: fused conv-subnet + affine + log-det
+# ------------------------------------------------------------------------------------------------
+class _GlowFn(torch.autograd.Function):
+    """x (B,H,W,C) pixel-major -> (out (B,H,W,C) with channel c stored at dst[c], logdet (B,))."""
+
+    @staticmethod
+    def forward(ctx, x, block, rev, dst, *params):
+        x = x.detach()
+        assert x.is_contiguous() and x.dim() == 4
+        b, h, w, c = x.shape
+        l1, l2 = block.split_len1, block.split_len2
+        m = b * h * w
+        dev = x.device
+        need_grad = any(ctx.needs_input_grad)      # False under torch.no_grad(): nothing is saved then
+        k = block.ksize
+        out = torch.empty_like(x)
+        logdet = torch.zeros(b, device=dev, dtype=torch.float32)
+        mode = CONV_COUPLE_INV if rev else CONV_COUPLE_FWD
+        # halves in execution order: (subnet, offset of the conditioning channels in x (None -> the first
+        # half's compact output), offset of the transformed channels v in x == output base, Co)
+        if not rev:
+            halves = [(block.s2, l1, 0, l1), (block.s1, None, l1, l2)]
+        else:
+            halves = [(block.s1, 0, l1, l2), (block.s2, None, 0, l1)]
+        saved = {}
+        ybuf = None
+        for i, (seq, cond_off, vbase, co) in enumerate(halves):
+            conv1, conv2, _ = inspect_subnet(seq)
+            cmap = ops.coupling_colmap(co, dev)
+            w1, b1, _ = block._packs.get(conv1, None, need_grad)
+            w2, b2, _ = block._packs.get(conv2, cmap, need_grad)
+            hbuf = torch.empty((m, HIDDEN), device=dev, dtype=torch.float32)
+            if i == 0:
+                cin = c - co
+                cond_t, cond_o, cond_s = x, cond_off, c
+            else:
+                cin = halves[0][3]
+                cond_t, cond_o, cond_s = ybuf, 0, cin
+            ops.conv(in_=_vp(cond_t, cond_o), in_stride=cond_s, Cin=cin, w=_vp(w1), bias=_vp(b1), Np=HIDDEN,
+                     B=b, H=h, W=w, ksize=k, mode=CONV_RELU, out=_vp(hbuf), out_stride=HIDDEN, N=HIDDEN)
+            sbuf = torch.empty((m, co), device=dev, dtype=torch.float32) if need_grad else None
+            y_compact = torch.empty((m, co), device=dev, dtype=torch.float32) if i == 0 else None
+            if dst is None:
+                o_ptr, o_map = _vp(out, vbase), None
+            else:
+                o_ptr, o_map = _vp(out), _vp(dst, vbase, torch.int32)
+            ops.conv(in_=_vp(hbuf), in_stride=HIDDEN, Cin=HIDDEN, w=_vp(w2), bias=_vp(b2), Np=2 * co,
+                     B=b, H=h, W=w, ksize=k, mode=mode, out=o_ptr, out_stride=c, out_map=o_map,
+                     v=_vp(x, vbase), v_stride=c, out2=_vp(y_compact), out2_stride=co, sbuf=_vp(sbuf),
+                     logdet=_vp(logdet), Co=co, clamp=block.clamp)
+            if i == 0:
+                ybuf = y_compact
+            saved[i] = (hbuf, sbuf)
+        if need_grad:
+            ctx.block, ctx.rev, ctx.dst = block, rev, dst
+            ctx.save_for_backward(x, out, ybuf, saved[0][0], saved[0][1], saved[1][0], saved[1][1])
+        ctx.set_materialize_grads(False)
+        return out, logdet
+
+    @staticmethod
+    def backward(ctx, dout, gld):
+        block, rev, dst = ctx.block, ctx.rev, ctx.dst
+        x, out, ybuf, h_a, s_a, h_b, s_b = ctx.saved_tensors
+        b, h, w, c = x.shape
+        m, hw = b * h * w, h * w
+        dev = x.device
+        l1, l2 = block.split_len1, block.split_len2
+        k = block.ksize
+        inv = 1 if rev else 0
+        if dout is None:
+            dout = torch.zeros_like(x)
+        dout = dout.contiguous()
+        if gld is not None:
+            gld = gld.contiguous()
+        dx = torch.empty_like(x)
+        if not rev:
+            halves = [(block.s2, l1, 0, l1), (block.s1, None, l1, l2)]
+        else:
+            halves = [(block.s1, 0, l1, l2), (block.s2, None, 0, l1)]
+        co_a, co_b = halves[0][3], halves[1][3]
+        base_a, base_b = halves[0][2], halves[1][2]
+
+        def dmap(base):
+            return None if dst is None else _vp(dst, base, torch.int32)
+
+        def half_bwd(seq, hbuf, sbuf, co, dy_t, dy_off, dy_stride, dy_map, vy_t, vy_off, vy_stride, vy_map,
+                     dv_off, cond_t, cond_off, cond_stride, cond_cin, add_t, add_off, add_stride, add_map,
+                     dcond_t, dcond_off, dcond_stride):
+            conv1, conv2, _ = inspect_subnet(seq)
+            cmap = ops.coupling_colmap(co, dev)
+            _, _, wd1 = block._packs.get(conv1, None, True)
+            _, _, wd2 = block._packs.get(conv2, cmap, True)
+            dr = torch.empty((m, 2 * co), device=dev, dtype=torch.float32)
+            ops.coupling_bwd(dy_t, dy_off, dy_stride, dy_map, vy_t, vy_off, vy_stride, vy_map, sbuf, gld, b, hw, co,
+                             block.clamp, inv, dr, dx, dv_off, c)
+            if conv2.weight.requires_grad:
+                ops.wgrad(hbuf, 0, HIDDEN, HIDDEN, dr, 2 * co, 2 * co, b, h, w, k, _grad_buf(conv2.weight),
+                          _grad_buf(conv2.bias))
+            dh = torch.empty((m, HIDDEN), device=dev, dtype=torch.float32)
+            ops.conv(in_=_vp(dr), in_stride=2 * co, Cin=2 * co, w=_vp(wd2), Np=HIDDEN, B=b, H=h, W=w, ksize=k,
+                     mode=CONV_MASK, out=_vp(dh), out_stride=HIDDEN, N=HIDDEN, mask=_vp(hbuf), mask_stride=HIDDEN)
+            if conv1.weight.requires_grad:
+                ops.wgrad(cond_t, cond_off, cond_stride, cond_cin, dh, HIDDEN, HIDDEN, b, h, w, k,
+                          _grad_buf(conv1.weight), _grad_buf(conv1.bias))
+            ops.conv(in_=_vp(dh), in_stride=HIDDEN, Cin=HIDDEN, w=_vp(wd1), Np=ops.pad16(cond_cin), B=b, H=h, W=w,
+                     ksize=k, mode=CONV_ADD, out=_vp(dcond_t, dcond_off), out_stride=dcond_stride, N=cond_cin,
+                     addend=_vp(add_t, add_off), addend_stride=add_stride, addend_map=add_map)
+
+        # ---- second half first: its condition is the first half's output (compact ybuf) ----------
+        dy_first = torch.empty((m, co_a), device=dev, dtype=torch.float32)
+        if not rev:
+            vy = (x, base_b, c, None)                 # v = untouched input half
+        else:
+            vy = (out, 0, c, dmap(base_b)) if dst is not None else (out, base_b, c, None)   # y of this half
+        if dst is None:
+            dy_b = (dout, base_b, c, None)
+            add_a = (dout, base_a, c, None)
+        else:
+            dy_b = (dout, 0, c, dmap(base_b))
+            add_a = (dout, 0, c, dmap(base_a))
+        half_bwd(halves[1][0], h_b, s_b, co_b, *dy_b, *vy, base_b, ybuf, 0, co_a, co_a, *add_a, dy_first, 0, co_a)
+        # ---- first half: condition = x[:, cond range]; its dgrad accumulates in place into dx ------
+        cond_off = halves[0][1]
+        cond_cin = c - co_a
+        vy = (x, base_a, c, None) if not rev else (ybuf, 0, co_a, None)
+        half_bwd(halves[0][0], h_a, s_a, co_a, dy_first, 0, co_a, None, *vy, base_a, x, cond_off, c, cond_cin,
+                 dx, cond_off, c, None, dx, cond_off, c)
+        return (dx, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+
+
+class GLOWCouplingBlock(nn.Module):
+    """FrEIA GLOWCouplingBlock, as used at archs.py:61-64 with clamp=1.2."""
+
+    def __init__(self, dims_in, dims_c=[], subnet_constructor=None, clamp=5.):
+        super().__init__()
+        assert not dims_c, 'conditional coupling is not on the sin-inn path'
+        channels = dims_in[0][0]
+        assert len(dims_in[0]) == 3, 'image tensors (C,H,W) only'
+        self.split_len1 = channels // 2
+        self.split_len2 = channels - channels // 2
+        assert self.split_len1 % 8 == 0 and self.split_len2 % 8 == 0, \
+            'the HIP coupling kernel needs both halves to be multiples of 8 channels'
+        self.clamp = float(clamp)
+        self.s1 = subnet_constructor(self.split_len1, self.split_len2 * 2)
+        self.s2 = subnet_constructor(self.split_len2, self.split_len1 * 2)
+        self.ksize = inspect_subnet(self.s1)[2]
+        assert inspect_subnet(self.s2)[2] == self.ksize
+        self._packs = _PackCache()
+        self.last_jac = None
+
+    def _params(self):
+        return [p for s in (self.s1, self.s2) for p in s.parameters()]
+
+    def apply_pixel_major(self, x, rev=False, dst=None):
+        out, logdet = _GlowFn.apply(x, self, bool(rev), dst, *self._params())
+        self.last_jac = logdet
+        return out
+
+    def forward(self, x, c=[], rev=False):
+        y = self.apply_pixel_major(import_nchw(x[0]), rev=rev)
+        return [y.permute(0, 3, 1, 2)]
+
+    def jacobian(self, x, c=[], rev=False):
+        return self.last_jac
+
+    def output_dims(self, input_dims):
+        return input_dims
+
+
+# ------------------------------------------------------------------------------------------------
+# index-map operators
+# ------------------------------------------------------------------------------------------------
+class _SqueezeFn(torch.autograd.Function):
+    """levels x IRevNetDownsampling (or its inverse) between arbitrary-stride 4-D tensors, optional channel map."""
+
+    @staticmethod
+    def forward(ctx, x, levels, inverse, chan_map, map_on_out, out_pixel_major):
+        x = x.detach()
+        b, c, h, w = x.shape                       # logical NCHW shape of the input
+        f = 1 << levels
+        if not inverse:
+            fc, fh, fw = c, h, w
+            oc, oh, ow = c * f * f, h // f, w // f
+        else:
+            fc, fh, fw = c // (f * f), h * f, w * f
+            oc, oh, ow = fc, fh, fw
+        if out_pixel_major:
+            out = torch.empty((b, oh, ow, oc), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
+        else:
+            out = torch.empty((b, oc, oh, ow), device=x.device, dtype=torch.float32)
+        ops.squeeze(x, out, b, fc, fh, fw, levels, inverse, chan_map, map_on_out)
+        ctx.cfg = (levels, inverse, chan_map, map_on_out, x.permute(0, 2, 3, 1).is_contiguous())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        levels, inverse, chan_map, map_on_out, in_pm = ctx.cfg
+        # the adjoint of a permutation is its inverse: swap direction, keep the map on the same tensor side
+        gx = _SqueezeFn.apply(g, levels, not inverse, chan_map, not map_on_out, in_pm)
+        return gx, None, None, None, None, None
+
+
+def squeeze_op(x, levels, inverse=False, chan_map=None, map_on_out=False, out_pixel_major=True):
+    """x: (B,C,H,W)-shaped (any strides) -> (B,C',H',W')-shaped; pixel-major storage unless told otherwise."""
+    return _SqueezeFn.apply(x, levels, inverse, chan_map, map_on_out, out_pixel_major)
+
+
+class IRevNetDownsampling(nn.Module):
+    """FrEIA IRevNetDownsampling: out[b,(hb*2+wb)*C+c,i,j] = in[b,c,2i+hb,2j+wb] (archs.py:28-31,35-38)."""
+
+    def __init__(self, dims_in):
+        super().__init__()
+        self.last_jac = 0.
+
+    def forward(self, x, rev=False):
+        return [squeeze_op(x[0], 1, inverse=rev)]
+
+    def jacobian(self, x, rev=False):
+        return 0.
+
+    def output_dims(self, input_dims):
+        c, h, w = input_dims[0]
+        return [(c * 4, h // 2, w // 2)]
+
+
+class PermuteRandom(nn.Module):
+    """FrEIA PermuteRandom(seed): np.random.seed(seed); perm = np.random.permutation(C) (archs.py:65-68)."""
+
+    def __init__(self, dims_in, seed):
+        super().__init__()
+        self.in_channels = dims_in[0][0]
+        np.random.seed(seed)
+        self.perm = np.random.permutation(self.in_channels)
+        np.random.seed()
+        self.perm_inv = np.zeros_like(self.perm)
+        for i, p in enumerate(self.perm):
+            self.perm_inv[p] = i
+        self._dev = {}
+
+    def maps(self, device):
+        """(perm, perm_inv) as device int32 tensors."""
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = (torch.as_tensor(self.perm.astype(np.int32), device=device),
+                              torch.as_tensor(self.perm_inv.astype(np.int32), device=device))
+        return self._dev[key]
+
+    def forward(self, x, rev=False):
+        perm, perm_inv = self.maps(x[0].device)
+        # out[:, j] = in[:, idx[j]]  ==  read-side channel map on a 0-level "squeeze"
+        return [squeeze_op(x[0], 0, inverse=False, chan_map=perm_inv if rev else perm, map_on_out=False)]
+
+    def jacobian(self, x, rev=False):
+        return 0.
+
+    def output_dims(self, input_dims):
+        return input_dims

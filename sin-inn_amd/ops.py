@@ -1,0 +1,190 @@
+"""Thin torch-tensor front end of the C ABI: argument checking + pointer plumbing only.
+
+Every function launches asynchronously on torch's current HIP stream.  CPU tensors are refused
+(``NotImplementedError``, like softsplat.py:331 in the reference) -- there is no fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvArgs, I64x4, check
+
+HIDDEN = 256
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, dtype=torch.float32):
+    if not t.is_cuda:
+        raise NotImplementedError('sin-inn_amd ops run on the GPU only (got a CPU tensor)')
+    assert t.dtype == dtype, f'expected {dtype}, got {t.dtype}'
+    return t
+
+
+def ptr(t, offset=0, dtype=torch.float32):
+    """Device pointer of element `offset` (in elements) of tensor t; None -> NULL."""
+    if t is None:
+        return None
+    _chk(t, dtype)
+    return C.c_void_p(t.data_ptr() + offset * t.element_size())
+
+
+def strides4(t):
+    assert t.dim() == 4
+    return I64x4(*t.stride())
+
+
+def pad16(n):
+    return (n + 15) // 16 * 16
+
+
+# ---- weights -------------------------------------------------------------------------------------
+_colmap_cache = {}
+
+
+def coupling_colmap(co, device):
+    """Device int32 [2*co]: packed column -> subnet output channel, (s|t) interleaved per 16-col tile."""
+    key = (co, str(device))
+    if key not in _colmap_cache:
+        host = (C.c_int * (2 * co))()
+        _lib.lib().sininn_coupling_colmap(co, host)
+        _colmap_cache[key] = torch.tensor(list(host), dtype=torch.int32, device=device)
+    return _colmap_cache[key]
+
+
+def pack_conv(weight, bias, colmap=None, want_dgrad=True):
+    """OIHW conv weight -> (w_fwd [taps][Np][Cin], b_fwd [Np], w_dgrad [taps][Cdp][N])."""
+    _chk(weight)
+    n, cin, k, _ = weight.shape
+    assert weight.is_contiguous() and (bias is None or bias.is_contiguous())
+    npk = colmap.numel() if colmap is not None else pad16(n)
+    cdp = pad16(cin)
+    taps = k * k
+    w_fwd = torch.empty(taps * npk * cin, device=weight.device, dtype=torch.float32)
+    b_fwd = torch.empty(npk, device=weight.device, dtype=torch.float32)
+    w_dg = torch.empty(taps * cdp * n, device=weight.device, dtype=torch.float32) if want_dgrad else None
+    check(_lib.lib().sininn_pack_conv_weights(ptr(weight), ptr(bias), n, cin, k, ptr(colmap, dtype=torch.int32), npk,
+                                              ptr(w_fwd), ptr(b_fwd), cdp, ptr(w_dg), _stream()))
+    return w_fwd, b_fwd, w_dg
+
+
+# ---- conv engine ---------------------------------------------------------------------------------
+def conv(**kw):
+    """Launch sininn_conv; keyword names follow sininn_conv_args (tensors given as (tensor, offset) or c_void_p)."""
+    a = ConvArgs()
+    for k, v in kw.items():
+        setattr(a, 'inp' if k == 'in_' else k, v)
+    check(_lib.lib().sininn_conv(C.byref(a), _stream()))
+
+
+def wgrad(in_t, in_off, in_stride, cin, dout, dout_stride, n, b, h, w, ksize, gw, gb):
+    """gw (OIHW, contiguous) += dW ; gb += db."""
+    lib = _lib.lib()
+    nbytes = lib.sininn_wgrad_workspace_bytes(n, cin, ksize, b, h, w)
+    ws = torch.empty((nbytes + 3) // 4, device=dout.device, dtype=torch.float32)
+    assert gw.is_contiguous() and (gb is None or gb.is_contiguous())
+    check(lib.sininn_wgrad(ptr(in_t, in_off), in_stride, cin, ptr(dout), dout_stride, n, b, h, w, ksize,
+                           ptr(gw), ptr(gb), ptr(ws), nbytes, _stream()))
+
+
+def coupling_bwd(dy, dy_off, dy_stride, dy_map, vy, vy_off, vy_stride, vy_map, s, gld, b, hw, co, clamp, inverse,
+                 dr, dv, dv_off, dv_stride):
+    check(_lib.lib().sininn_coupling_bwd(ptr(dy, dy_off), dy_stride, dy_map, ptr(vy, vy_off), vy_stride, vy_map,
+                                         ptr(s), ptr(gld), b, hw, co, clamp, inverse, ptr(dr), ptr(dv, dv_off),
+                                         dv_stride, _stream()))
+
+
+# ---- index maps ----------------------------------------------------------------------------------
+def squeeze(x, out, b, c, h, w, levels, inverse, chan_map=None, map_on_out=False):
+    """x / out are 4-D (B,C,H,W)-shaped tensors of ANY strides (fine side has C,H,W; coarse side C*4^l,H/2^l,W/2^l)."""
+    check(_lib.lib().sininn_squeeze(ptr(x), strides4(x), ptr(out), strides4(out), b, c, h, w, levels,
+                                    1 if inverse else 0, ptr(chan_map, dtype=torch.int32), 1 if map_on_out else 0,
+                                    _stream()))
+
+
+def permute_channels(x2d, out2d, idx):
+    m, c = x2d.shape
+    check(_lib.lib().sininn_permute_channels(ptr(x2d), x2d.stride(0), ptr(out2d), out2d.stride(0), m, c,
+                                             ptr(idx, dtype=torch.int32), _stream()))
+
+
+# ---- losses --------------------------------------------------------------------------------------
+def sqdiff_sum(x, y, out):
+    b, c, h, w = x.shape
+    check(_lib.lib().sininn_sqdiff_sum(ptr(x), strides4(x), ptr(y), strides4(y) if y is not None else I64x4(),
+                                       b, c, h, w, ptr(out), _stream()))
+
+
+def sqdiff_bwd(x, y, scale, gscale, gx, gy):
+    b, c, h, w = x.shape
+    z = I64x4()
+    check(_lib.lib().sininn_sqdiff_bwd(ptr(x), strides4(x), ptr(y), strides4(y) if y is not None else z, b, c, h, w,
+                                       ptr(scale), gscale, ptr(gx), strides4(gx) if gx is not None else z,
+                                       ptr(gy), strides4(gy) if gy is not None else z, _stream()))
+
+
+def mmd_gram(x, y, g):
+    b, c, h, w = x.shape
+    check(_lib.lib().sininn_mmd_gram(ptr(x), strides4(x), ptr(y), strides4(y), b, c, h, w, ptr(g), _stream()))
+
+
+def mmd_finish(g, b, rev, out, coef):
+    check(_lib.lib().sininn_mmd_finish(ptr(g), b, 1 if rev else 0, ptr(out), ptr(coef), _stream()))
+
+
+def mmd_bwd(x, y, coef, scale, gx, gy):
+    b, c, h, w = x.shape
+    z = I64x4()
+    check(_lib.lib().sininn_mmd_bwd(ptr(x), strides4(x), ptr(y), strides4(y), b, c, h, w, ptr(coef), ptr(scale),
+                                    ptr(gx), strides4(gx) if gx is not None else z,
+                                    ptr(gy), strides4(gy) if gy is not None else z, _stream()))
+
+
+# ---- warps ---------------------------------------------------------------------------------------
+def affine_warp(img, theta, out, ref=None, sse=None):
+    b, c, h, w = img.shape
+    assert theta.shape == (b, 2, 3) and theta.is_contiguous()
+    check(_lib.lib().sininn_affine_warp(ptr(img), strides4(img), ptr(theta), b, c, h, w, ptr(out), strides4(out),
+                                        ptr(ref), strides4(ref) if ref is not None else I64x4(), ptr(sse), _stream()))
+
+
+def affine_warp_bwd(gout, theta, gimg):
+    b, c, h, w = gout.shape
+    check(_lib.lib().sininn_affine_warp_bwd(ptr(gout), strides4(gout), ptr(theta), b, c, h, w, ptr(gimg),
+                                            strides4(gimg), _stream()))
+
+
+def flow_warp_l1(img, flow, target, warped, metric):
+    b, c, h, w = img.shape
+    for t in (img, flow, target, warped, metric):
+        assert t is None or t.is_contiguous()
+    check(_lib.lib().sininn_flow_warp_l1(ptr(img), ptr(flow), ptr(target), b, c, h, w, ptr(warped), ptr(metric),
+                                         _stream()))
+
+
+def flow_warp_l1_bwd(img, flow, target, warped, gwarped, gmetric, gimg, gflow):
+    b, c, h, w = img.shape
+    for t in (img, flow, target, warped, gwarped, gmetric, gimg, gflow):
+        assert t is None or t.is_contiguous()
+    check(_lib.lib().sininn_flow_warp_l1_bwd(ptr(img), ptr(flow), ptr(target), ptr(warped), ptr(gwarped),
+                                             ptr(gmetric), b, c, h, w, ptr(gimg), ptr(gflow), _stream()))
+
+
+# ---- sampler / optimiser -------------------------------------------------------------------------
+def sample_windows(hr_clip, lr_clip, idx, win, hr_out, lr_out):
+    t, hh, ww, _ = hr_clip.shape
+    _, h, w, _ = lr_clip.shape
+    assert hr_clip.is_contiguous() and lr_clip.is_contiguous() and idx.dtype == torch.int32
+    check(_lib.lib().sininn_sample_windows(ptr(hr_clip, dtype=torch.uint8), ptr(lr_clip, dtype=torch.uint8),
+                                           ptr(idx, dtype=torch.int32), idx.numel(), t, hh, ww, h, w, win,
+                                           ptr(hr_out), strides4(hr_out), ptr(lr_out), strides4(lr_out), _stream()))
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    for t in (p, g, m, v):
+        assert t.is_contiguous() and t.numel() == p.numel()
+    check(_lib.lib().sininn_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay,
+                                      step, grad_scale, _stream()))

@@ -1,0 +1,267 @@
+"""GPU parity: every HIP kernel (called through the C ABI via sin_inn_amd.ops) against the CPU oracle on the
+same seeded inputs.  Tolerance for this path (north_star): 1e-4 relative, fp32."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def relerr(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+@pytest.fixture(scope='module')
+def env():
+    import sin_inn_amd
+    from oracle import sininn_oracle as O
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    return sin_inn_amd, O, torch.device('cuda', 0)
+
+
+def nhwc(t):           # (B,C,H,W) cpu -> contiguous (B,H,W,C) cuda
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):           # (B,H,W,C) cuda -> (B,C,H,W) cpu
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+# ---------------------------------------------------------------------------------------------------
+# conv engine
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('ksize', [3, 1])
+@pytest.mark.parametrize('cin,n,hw', [(24, 256, (16, 32)), (96, 256, (8, 16)), (256, 48, (16, 16)),
+                                      (256, 192, (12, 20)), (48, 256, (9, 17)), (8, 24, (5, 7))])
+@pytest.mark.parametrize('force', [(0, 0), (1, 8), (2, 16)])
+def test_conv_relu_and_linear(env, ksize, cin, n, hw, force):
+    S, O, dev = env
+    from sin_inn_amd import ops, _lib
+    torch.manual_seed(cin + n + ksize)
+    h, w = hw
+    conv = torch.nn.Conv2d(cin, n, ksize, padding=ksize // 2)
+    x = torch.randn(2, cin, h, w)
+    want = conv(x)
+    xg = nhwc(x)
+    wf, bf, _ = ops.pack_conv(conv.weight.detach().cuda().contiguous(), conv.bias.detach().cuda().contiguous(), None, False)
+    _lib.lib().sininn_conv_test_hooks(*force)
+    try:
+        for mode, ref in ((_lib.CONV_LINEAR, want), (_lib.CONV_RELU, F.relu(want))):
+            out = torch.full((2, h, w, n), float('nan'), device=dev)
+            ops.conv(in_=ops.ptr(xg), in_stride=cin, Cin=cin, w=ops.ptr(wf), bias=ops.ptr(bf), Np=ops.pad16(n),
+                     B=2, H=h, W=w, ksize=ksize, mode=mode, out=ops.ptr(out), out_stride=n, N=n)
+            assert relerr(nchw(out), ref) < RTOL
+    finally:
+        _lib.lib().sininn_conv_test_hooks(0, 0)
+
+
+@pytest.mark.parametrize('ksize', [3, 1])
+def test_conv_strided_input_and_mask_add(env, ksize):
+    """channel sub-range input (x2 = x[:, 24:]), MASK and ADD (+map, in place) epilogues = the dgrad path."""
+    S, O, dev = env
+    from sin_inn_amd import ops, _lib
+    torch.manual_seed(5)
+    b, h, w = 2, 10, 18
+    x = torch.randn(b, 48, h, w)
+    conv = torch.nn.Conv2d(24, 256, ksize, padding=ksize // 2)
+    xg = nhwc(x)
+    wf, bf, wd = ops.pack_conv(conv.weight.detach().cuda().contiguous(), conv.bias.detach().cuda().contiguous(), None, True)
+    out = torch.empty((b, h, w, 256), device=dev)
+    ops.conv(in_=ops.ptr(xg, 24), in_stride=48, Cin=24, w=ops.ptr(wf), bias=ops.ptr(bf), Np=256, B=b, H=h, W=w,
+             ksize=ksize, mode=_lib.CONV_RELU, out=ops.ptr(out), out_stride=256, N=256)
+    hid = F.relu(conv(x[:, 24:]))
+    assert relerr(nchw(out), hid) < RTOL
+    # data gradient through the conv: d/dx of sum(conv(x) * g), masked / added
+    g = torch.randn(b, 256, h, w)
+    xin = x[:, 24:].clone().requires_grad_(True)
+    conv(xin).backward(g)
+    gg = nhwc(g)
+    add = torch.randn(b, h, w, 48, device=dev)
+    amap = torch.randperm(48)[:24].to(torch.int32).cuda()
+    dcond = torch.empty((b, h, w, 24), device=dev)
+    ops.conv(in_=ops.ptr(gg), in_stride=256, Cin=256, w=ops.ptr(wd), Np=32, B=b, H=h, W=w, ksize=ksize,
+             mode=_lib.CONV_ADD, out=ops.ptr(dcond), out_stride=24, N=24, addend=ops.ptr(add), addend_stride=48,
+             addend_map=ops.ptr(amap, dtype=torch.int32))
+    want = xin.grad + nchw(add)[:, amap.cpu().long()]
+    assert relerr(nchw(dcond), want) < RTOL
+    # in-place accumulate into a channel sub-range
+    acc = add.clone()
+    ops.conv(in_=ops.ptr(gg), in_stride=256, Cin=256, w=ops.ptr(wd), Np=32, B=b, H=h, W=w, ksize=ksize,
+             mode=_lib.CONV_ADD, out=ops.ptr(acc, 24), out_stride=48, N=24, addend=ops.ptr(acc, 24), addend_stride=48)
+    assert relerr(nchw(acc)[:, 24:], xin.grad + nchw(add)[:, 24:]) < RTOL
+    assert torch.equal(acc[..., :24], add[..., :24])
+    # MASK: dgrad of the second conv through the ReLU
+    conv2 = torch.nn.Conv2d(256, 48, ksize, padding=ksize // 2)
+    _, _, wd2 = ops.pack_conv(conv2.weight.detach().cuda().contiguous(), conv2.bias.detach().cuda().contiguous(), None, True)
+    g2 = torch.randn(b, 48, h, w)
+    hin = hid.detach().clone().requires_grad_(True)
+    conv2(hin).backward(g2)
+    dh = torch.empty((b, h, w, 256), device=dev)
+    ops.conv(in_=ops.ptr(nhwc(g2)), in_stride=48, Cin=48, w=ops.ptr(wd2), Np=256, B=b, H=h, W=w, ksize=ksize,
+             mode=_lib.CONV_MASK, out=ops.ptr(dh), out_stride=256, N=256, mask=ops.ptr(out), mask_stride=256)
+    assert relerr(nchw(dh), hin.grad * (hid > 0)) < RTOL
+
+
+@pytest.mark.parametrize('ksize', [3, 1])
+@pytest.mark.parametrize('cin,n', [(256, 48), (24, 256), (96, 256), (256, 192)])
+def test_wgrad(env, ksize, cin, n):
+    S, O, dev = env
+    from sin_inn_amd import ops
+    torch.manual_seed(cin * 3 + n)
+    b, h, w = 3, 12, 20
+    conv = torch.nn.Conv2d(cin, n, ksize, padding=ksize // 2)
+    x = torch.randn(b, cin + 8, h, w)
+    g = torch.randn(b, n, h, w)
+    conv(x[:, 8:]).backward(g)
+    gw = torch.ones_like(conv.weight).cuda()          # wgrad accumulates (+=)
+    gb = torch.ones_like(conv.bias).cuda()
+    ops.wgrad(nhwc(x), 8, cin + 8, cin, nhwc(g), n, n, b, h, w, ksize, gw, gb)
+    assert relerr(gw.cpu() - 1, conv.weight.grad) < RTOL
+    assert relerr(gb.cpu() - 1, conv.bias.grad) < RTOL
+
+
+def test_golden_subnets_on_gpu(env, golden):
+    """the reference's own subnet_conv / subnet_conv_1x1 outputs (tests/golden) through the HIP conv engine."""
+    S, O, dev = env
+    from sin_inn_amd import ops, _lib
+    for tag, k in (('3x3', 3), ('1x1', 1)):
+        x = torch.from_numpy(golden[f'g3_{tag}_x'])
+        b, c, h, w = x.shape
+        w0 = torch.from_numpy(golden[f'g3_{tag}_w0']).cuda(); b0 = torch.from_numpy(golden[f'g3_{tag}_b0']).cuda()
+        w2 = torch.from_numpy(golden[f'g3_{tag}_w2']).cuda(); b2 = torch.from_numpy(golden[f'g3_{tag}_b2']).cuda()
+        p0 = ops.pack_conv(w0, b0, None, False); p2 = ops.pack_conv(w2, b2, None, False)
+        hid = torch.empty((b, h, w, 256), device=dev); out = torch.empty((b, h, w, 48), device=dev)
+        ops.conv(in_=ops.ptr(nhwc(x)), in_stride=c, Cin=c, w=ops.ptr(p0[0]), bias=ops.ptr(p0[1]), Np=256, B=b, H=h, W=w,
+                 ksize=k, mode=_lib.CONV_RELU, out=ops.ptr(hid), out_stride=256, N=256)
+        ops.conv(in_=ops.ptr(hid), in_stride=256, Cin=256, w=ops.ptr(p2[0]), bias=ops.ptr(p2[1]), Np=48, B=b, H=h, W=w,
+                 ksize=k, mode=_lib.CONV_LINEAR, out=ops.ptr(out), out_stride=48, N=48)
+        assert relerr(nchw(out), torch.from_numpy(golden[f'g3_{tag}_y'])) < RTOL
+
+
+# ---------------------------------------------------------------------------------------------------
+# index maps, losses, warps, sampler, adam
+# ---------------------------------------------------------------------------------------------------
+def test_squeeze_permute(env):
+    S, O, dev = env
+    from sin_inn_amd.modules import squeeze_op, PermuteRandom, IRevNetDownsampling
+    x = torch.randn(2, 3, 16, 24)
+    y = squeeze_op(x.cuda(), 2)                      # NCHW in, pixel-major out, two levels fused
+    assert torch.equal(y.cpu(), O.squeeze_fwd(O.squeeze_fwd(x)))
+    back = squeeze_op(y, 2, inverse=True, out_pixel_major=False)
+    assert back.is_contiguous() and torch.equal(back.cpu(), x)
+    op = IRevNetDownsampling([(3, 16, 24)])
+    assert torch.equal(op([x.cuda()])[0].cpu(), O.squeeze_fwd(x))
+    assert torch.equal(op([op([x.cuda()])[0]], rev=True)[0].cpu(), x)
+    p = PermuteRandom([(48, 4, 4)], seed=3)
+    perm, inv = O.permutation(48, 3)
+    z = torch.randn(2, 48, 4, 4)
+    assert torch.equal(p([z.cuda()])[0].cpu(), z[:, perm])
+    assert torch.equal(p([z.cuda()], rev=True)[0].cpu(), z[:, inv])
+    # autograd: gradient of a permutation is the inverse permutation
+    zc = z.cuda().requires_grad_(True)
+    (p([zc])[0] * torch.arange(48, device=dev).view(1, -1, 1, 1)).sum().backward()
+    want = torch.zeros(48); want[perm] = torch.arange(48.)
+    assert torch.equal(zc.grad[0, :, 0, 0].cpu(), want)
+
+
+def test_losses(env, golden):
+    S, O, dev = env
+    import loss
+    x, y = torch.from_numpy(golden['g1_x']), torch.from_numpy(golden['g1_y'])
+    assert abs(float(loss.reconstruction(x.cuda(), y.cuda())) / float(golden['g1_rec']) - 1) < 1e-5
+    assert abs(float(loss.latent_nll(x.cuda())) / float(golden['g1_nll']) - 1) < 1e-5
+    # strided views (channel slice of a pixel-major tensor) + gradients
+    torch.manual_seed(0)
+    a = torch.randn(3, 20, 6, 5); b = torch.randn(3, 12, 6, 5)
+    ag = a.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    ac = a.clone().requires_grad_(True)
+    lg = 0.7 * loss.reconstruction(ag[:, :12], b.cuda()) + 0.3 * loss.latent_nll(ag[:, 12:])
+    lc = 0.7 * O.reconstruction(ac[:, :12], b) + 0.3 * O.latent_nll(ac[:, 12:])
+    lg.backward(); lc.backward()
+    assert abs(float(lg) / float(lc) - 1) < 1e-5
+    assert relerr(ag.grad, ac.grad) < RTOL
+
+
+@pytest.mark.parametrize('rev', [False, True])
+def test_mmd(env, rev):
+    S, O, dev = env
+    import loss
+    torch.manual_seed(1)
+    x = (torch.randn(6, 5, 4, 3) * 0.3); y = (torch.randn(6, 5, 4, 3) * 0.3)
+    xc, yc = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    yg = y.cuda().requires_grad_(True)
+    lc = O.mmd(xc, yc, rev=rev); lc.backward()
+    lg = loss.mmd(xg, yg, rev=rev); lg.backward()
+    assert abs(float(lg) - float(lc)) < 1e-5 * max(1.0, abs(float(lc)))
+    assert relerr(xg.grad, xc.grad) < 1e-3 and relerr(yg.grad, yc.grad) < 1e-3
+
+
+def test_tcr_affine_warp(env):
+    S, O, dev = env
+    from tcr import TCR
+    torch.manual_seed(2)
+    img = torch.rand(3, 5, 12, 16)
+    rand = torch.rand(3, 3)
+    for scale in (1, 0.25):
+        want = O.tcr_warp(img, rand, 5.0, 5.0, scale=scale)
+        got = TCR(5.0, 5.0)(img.cuda(), rand, scale=scale)
+        assert relerr(got, want) < RTOL
+    ic = img.clone().requires_grad_(True)
+    ig = img.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wgt = torch.randn(3, 5, 12, 16)
+    (O.tcr_warp(ic, rand, 5.0, 5.0) * wgt).sum().backward()
+    (TCR(5.0, 5.0)(ig, rand) * wgt.cuda()).sum().backward()
+    assert relerr(ig.grad, ic.grad) < RTOL
+
+
+def test_flow_warp_l1(env):
+    S, O, dev = env
+    from sin_inn_amd.functional import flow_warp_l1
+    torch.manual_seed(3)
+    img = torch.rand(2, 3, 20, 70); tgt = torch.rand(2, 3, 20, 70)
+    flow = torch.randn(2, 2, 20, 70) * 2.0
+    flow[0] = 0.3                                        # constant flow -> exercises the shuffle-shared taps
+    fc, ic = flow.clone().requires_grad_(True), img.clone().requires_grad_(True)
+    wc = O.flow_warp(ic, fc); mc = O.photometric_l1(tgt, wc)
+    fg, ig = flow.cuda().requires_grad_(True), img.cuda().requires_grad_(True)
+    wg, mg = flow_warp_l1(ig, fg, tgt.cuda())
+    assert relerr(wg, wc) < RTOL and relerr(mg, mc) < RTOL
+    k1, k2 = torch.randn_like(wc), torch.rand_like(mc)
+    ((wc * k1).sum() + (mc * k2).sum()).backward()
+    ((wg * k1.cuda()).sum() + (mg * k2.cuda()).sum()).backward()
+    assert relerr(ig.grad, ic.grad) < 1e-3 and relerr(fg.grad, fc.grad) < 1e-3
+
+
+def test_sampler(env):
+    S, O, dev = env
+    from data import FrameStore
+    from sin_inn_amd.functional import sample_windows
+    st = FrameStore.synthetic(12, 32, 48)
+    idx = torch.tensor([3, 7, 5])
+    hr, lr = sample_windows(st.hr.cuda(), st.lr.cuda(), idx.cuda(), 2)
+    for n, i in enumerate(idx.tolist()):
+        h0, l0 = O.gather_window(st.lr, st.hr, i, 2)
+        assert torch.equal(hr[n].cpu(), h0) and torch.equal(lr[n].cpu(), l0)
+
+
+def test_fused_adam_matches_torch(env):
+    S, O, dev = env
+    torch.manual_seed(4)
+    ps = [torch.randn(13, 7), torch.randn(5), torch.randn(3, 3, 3, 3)]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    mine = [torch.nn.Parameter(p.clone().cuda()) for p in ps]
+    o_ref = torch.optim.Adam(ref, lr=1e-3, betas=(0.9, 0.99), weight_decay=1e-5)
+    o_mine = S.FusedAdam(mine, lr=1e-3, betas=(0.9, 0.99), weight_decay=1e-5)
+    for _ in range(3):
+        o_mine.zero_grad()
+        for r, m in zip(ref, mine):
+            g = torch.randn_like(r)
+            r.grad = g.clone(); m.grad.copy_(g.cuda())
+        o_ref.step(); o_mine.step()
+    for r, m in zip(ref, mine):
+        assert relerr(m, r) < 1e-5

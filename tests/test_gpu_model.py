@@ -1,0 +1,177 @@
+"""GPU parity of the composed path: GLOW block (fwd / inverse / log-det / gradients), the lowered SRF network,
+one full training step (losses, gradients, fused Adam) against the CPU oracle, plus size-independent properties
+at BASELINE config-2 size (256x256, bs 16)."""
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def relerr(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def make_opt(**kw):
+    d = dict(scale=4, num_coupling=2, lr_window=1, architecture='SRF', gpu_ids=[0], rotation=5.0, translation=5.0,
+             tcr_iters=2, lambda_fwd_rec=1.0, lambda_fwd_mmd=0.0, lambda_latent_nll=0.0, lambda_bwd_rec=1.0,
+             lambda_bwd_mmd=0.0, lambda_bwd_tcr=0.0, learning_rate=1e-4, adam_betas=[0.9, 0.99], weight_decay=1e-5,
+             temp=0.8, operation='train', fps=1)
+    d.update(kw)
+    o = types.SimpleNamespace(**d)
+    o.lr_dims = (2 * o.lr_window + 1) * 4
+    o.z_dims = o.scale * o.scale * 3 * 4 - o.lr_dims
+    return o
+
+
+def copy_weights(oracle_net, hip_net):
+    sd = {k: v.detach().cpu().clone() for k, v in hip_net.state_dict().items()}
+    oracle_net.load_state_dict(sd)
+
+
+@pytest.mark.parametrize('ksize', [3, 1])
+@pytest.mark.parametrize('rev', [False, True])
+@pytest.mark.parametrize('channels,hw', [(48, (12, 20)), (192, (8, 16))])
+def test_glow_block(ksize, rev, channels, hw):
+    import archs
+    import sin_inn_amd as S
+    from oracle import sininn_oracle as O
+    torch.manual_seed(channels + ksize)
+    h, w = hw
+    ctor = archs.subnet_conv if ksize == 3 else archs.subnet_conv_1x1
+    blk = S.GLOWCouplingBlock([(channels, h, w)], subnet_constructor=ctor, clamp=1.2)
+    ref = O.GlowBlock(channels, ksize, 1.2)
+    ref.load_state_dict({k: v.clone() for k, v in blk.state_dict().items()})
+    for net in (blk, ref):      # default init gives tiny s; scale up so e(s) and the clamp actually matter
+        for p in net.parameters():
+            p.data.mul_(3.0)
+    blk.cuda()
+    x = torch.randn(2, channels, h, w)
+    xc = x.clone().requires_grad_(True)
+    xg = x.cuda().requires_grad_(True)
+    yc = ref(xc, rev=rev)
+    yg = blk([xg], rev=rev)[0]
+    assert relerr(yg, yc) < RTOL
+    assert relerr(blk.jacobian(None), ref.last_jac) < RTOL
+    wgt = torch.randn_like(yc)
+    ld_w = torch.randn(2)
+    (yc * wgt).sum().add((ref.last_jac * ld_w).sum()).backward()
+    ((yg * wgt.cuda()).sum() + (blk.last_jac * ld_w.cuda()).sum()).backward()
+    assert relerr(xg.grad, xc.grad) < RTOL
+    for (n, pg), (_, pc) in zip(blk.named_parameters(), ref.named_parameters()):
+        assert relerr(pg.grad, pc.grad) < 2e-4, n
+    # round trip through the HIP kernels alone
+    with torch.no_grad():
+        back = blk([yg.detach()], rev=not rev)[0]
+    assert relerr(back, x) < RTOL
+
+
+@pytest.mark.parametrize('num_coupling', [1, 2])
+def test_srflow_network_and_gradients(num_coupling):
+    import archs
+    from oracle import sininn_oracle as O
+    torch.manual_seed(7)
+    opt = make_opt(num_coupling=num_coupling)
+    net = archs.UncondSRFlow(3, 32, 48, opt)
+    ref = O.SRFlowOracle(3, 32, 48, scale=4, num_coupling=num_coupling)
+    copy_weights(ref, net)
+    net.cuda()
+    x = torch.rand(2, 3, 32, 48)
+    xg = x.cuda().requires_grad_(True); xc = x.clone().requires_grad_(True)
+    yg, yc = net(xg), ref(xc)
+    assert yg.shape == yc.shape and relerr(yg, yc) < RTOL
+    assert relerr(net.log_jacobian(), ref.log_jacobian()) < RTOL
+    wgt = torch.randn_like(yc)
+    (yc * wgt).sum().backward(); (yg * wgt.cuda()).sum().backward()
+    assert relerr(xg.grad, xc.grad) < RTOL
+    for (n, pg), (_, pc) in zip(net.named_parameters(), ref.named_parameters()):
+        assert relerr(pg.grad, pc.grad) < 2e-4, n
+    # reverse direction (input NCHW-contiguous, permutes folded into the producers)
+    z = torch.randn(2, 192, 4, 6)
+    zg = z.cuda().requires_grad_(True); zc = z.clone().requires_grad_(True)
+    net.zero_grad(); ref.zero_grad()
+    hg, hc = net(zg, rev=True), ref(zc, rev=True)
+    assert relerr(hg, hc) < RTOL
+    (hc * hc).sum().backward(); (hg * hg).sum().backward()
+    assert relerr(zg.grad, zc.grad) < RTOL
+    for (n, pg), (_, pc) in zip(net.named_parameters(), ref.named_parameters()):
+        assert relerr(pg.grad, pc.grad) < 2e-4, n
+    with torch.no_grad():
+        assert relerr(net(net(x.cuda()), rev=True), x) < RTOL
+
+
+@pytest.mark.parametrize('lam', [dict(), dict(lambda_fwd_mmd=0.5, lambda_latent_nll=0.25, lambda_bwd_mmd=0.5),
+                                 dict(lambda_bwd_tcr=0.5)])
+def test_training_step_matches_oracle(lam):
+    """config-1 shaped step (64x64, lr_window 1): same weights, frames and latents -> same losses, gradients, Adam update."""
+    import lit_wrapper
+    from data import FrameStore
+    from oracle import sininn_oracle as O
+    from sin_inn_amd.functional import sample_windows
+    torch.manual_seed(11)
+    opt = make_opt(num_coupling=2, **lam)
+    model = lit_wrapper.SingleVideoINN(3, 64, 64, opt)
+    ref = O.SRFlowOracle(3, 64, 64, scale=4, num_coupling=2)
+    ref.load_state_dict({k[len('inn.'):]: v.detach().clone() for k, v in model.state_dict().items()})
+    model.cuda()
+    optim = model.attach_optimizer()
+    store = FrameStore.synthetic(8, 64, 64)
+    idx = torch.tensor([2, 3, 4, 5])
+    hr_g, lr_g = sample_windows(store.hr.cuda(), store.lr.cuda(), idx.cuda(), 1)
+    hr_c = torch.stack([O.gather_window(store.lr, store.hr, i, 1)[0] for i in idx.tolist()])
+    lr_c = torch.stack([O.gather_window(store.lr, store.hr, i, 1)[1] for i in idx.tolist()])
+    # identical latents / TCR randoms on both sides: patch the module-level samplers
+    g = torch.Generator().manual_seed(2)
+    zs = [torch.randn(4, opt.z_dims, 8, 8, generator=g) for _ in range(1 + 2)]
+    rands = [torch.rand(4, 3, generator=g) for _ in range(2)]
+    zq, rq = list(zs), list(rands)
+    lit_wrapper._latent = lambda b, zd, h, w, device, temp=1.0: zq.pop(0).to(device)
+    real_rand = torch.rand
+    torch.rand = lambda *a, **k: rq.pop(0) if a == (4, 3) else real_rand(*a, **k)
+    try:
+        model.training_step([{'hr': hr_g, 'lr': lr_g}, {'hr': hr_g, 'lr': lr_g}], 0)
+    finally:
+        torch.rand = real_rand
+    lamd = dict(fwd_rec=opt.lambda_fwd_rec, fwd_mmd=opt.lambda_fwd_mmd, latent_nll=opt.lambda_latent_nll,
+                bwd_rec=opt.lambda_bwd_rec, bwd_mmd=opt.lambda_bwd_mmd)
+    tcr = None
+    if opt.lambda_bwd_tcr > 0:
+        tcr = dict(hr_u=hr_c, lr_u=lr_c, rands=rands, zs=zs[1:], weight=opt.lambda_bwd_tcr, angle=5.0, trans=5.0,
+                   scale=opt.scale)
+    before = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    fwd, bwd, tl, _, _ = O.training_step(ref, hr_c, lr_c, zs[0], lamd, opt.lr_dims, tcr)
+    total = float(fwd + bwd + tl)
+    assert abs(float(model._logged['train']) / total - 1) < RTOL
+    flat_g = optim.flat_grads()[0]
+    ref_g = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+    assert relerr(flat_g[:ref_g.numel()], ref_g) < 3e-4
+    # Adam update of the oracle with torch.optim.Adam (what the reference configures, lit_wrapper.py:131-138)
+    o = torch.optim.Adam(ref.parameters(), lr=opt.learning_rate, betas=tuple(opt.adam_betas), weight_decay=opt.weight_decay)
+    o.step()
+    new_ref = torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
+    old_ref = torch.cat([before[k].reshape(-1) for k, _ in ref.named_parameters()])
+    new_hip = optim.flat_params()[0][:new_ref.numel()].cpu()
+    assert relerr(new_hip - old_ref, new_ref - old_ref) < 2e-2      # sign-like first Adam step, tiny-gradient entries
+    assert relerr(new_hip, new_ref) < 1e-5
+
+
+def test_full_size_properties():
+    """BASELINE config 2 (256x256, bs 16, -c 4): too big for the oracle in seconds -> size-independent properties:
+    HIP forward -> HIP inverse round trip, log-det antisymmetry, permutation/squeeze bijectivity."""
+    import archs
+    torch.manual_seed(0)
+    opt = make_opt(num_coupling=4, lr_window=10)
+    net = archs.UncondSRFlow(3, 256, 256, opt).cuda()
+    x = torch.rand(16, 3, 256, 256, device='cuda')
+    with torch.no_grad():
+        y = net(x)
+        ld_f = net.log_jacobian()
+        back = net(y, rev=True)
+        ld_r = net.log_jacobian()
+    assert y.shape == (16, 192, 32, 32)
+    assert relerr(back, x) < RTOL
+    assert relerr(ld_r, -ld_f) < 1e-3
+    assert torch.isfinite(y).all()

@@ -1,0 +1,149 @@
+"""CPU: the C ABI loads and exports every declared symbol, host-side logic (graph lowering, sampler index
+arithmetic, TCR matrices, CLI), and the data-parallel glue with world_size 2 on gloo."""
+import os
+import re
+import subprocess
+import sys
+import types
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol():
+    import sin_inn_amd
+    from sin_inn_amd import _lib
+    header = open(os.path.join(ROOT, 'include', 'sininn.h')).read()
+    declared = set(re.findall(r'\b(sininn_[a-z0-9_]+)\s*\(', header))
+    declared -= {'sininn_conv_args'}
+    handle = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(handle, name), f'{name} declared in include/sininn.h but not exported'
+    assert declared <= set(_lib.EXPORTED) | {'sininn_conv_args'}
+    assert handle.sininn_version() == 1
+
+
+def test_cpu_tensors_are_refused_loudly():
+    import sin_inn_amd
+    from sin_inn_amd import ops
+    with pytest.raises(NotImplementedError):
+        ops.ptr(torch.zeros(4))
+    import loss
+    with pytest.raises(NotImplementedError):
+        loss.reconstruction(torch.zeros(1, 1, 2, 2), torch.zeros(1, 1, 2, 2))
+
+
+def test_coupling_colmap_layout():
+    import ctypes as C
+    import sin_inn_amd
+    from sin_inn_amd import _lib
+    buf = (C.c_int * 48)()
+    _lib.lib().sininn_coupling_colmap(24, buf)
+    m = list(buf)
+    assert m[:8] == list(range(8)) and m[8:16] == list(range(24, 32)) and m[16:24] == list(range(8, 16))
+    assert sorted(m) == list(range(48))
+
+
+def _opt(**kw):
+    d = dict(scale=4, num_coupling=3, lr_window=1, architecture='SRF', gpu_ids=[0], rotation=5.0, translation=5.0)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def test_graph_lowering_folds_all_permutes():
+    import archs
+    net = archs.UncondSRFlow(3, 64, 64, _opt())
+    fwd = net._lower(False)
+    kinds = [k for k, _ in fwd]
+    assert kinds == ['squeeze'] + ['glow'] * 3 + ['squeeze'] + ['glow'] * 3
+    assert fwd[0][1]['levels'] == 2 and all(p['perm'] is not None for k, p in fwd if k == 'glow')
+    rev = net._lower(True)
+    kinds = [k for k, _ in rev]
+    # only the very first inverse permute (applied to the network input) stays a standalone gather
+    assert kinds == ['permute'] + ['glow'] * 3 + ['squeeze'] + ['glow'] * 3 + ['squeeze']
+    assert rev[4][1]['perm'] is not None and rev[4][1]['levels'] == 1 and rev[8][1]['levels'] == 2
+    assert [p['perm'] is not None for k, p in rev if k == 'glow'] == [True, True, False, True, True, False]
+    keys = list(net.state_dict().keys())
+    assert keys[0] == 'module_list.3.s1.0.weight' and len(keys) == 6 * 8
+
+
+def test_same_seed_same_weights_as_oracle():
+    import archs
+    from oracle import sininn_oracle as O
+    torch.manual_seed(0)
+    net = archs.UncondSRFlow(3, 64, 64, _opt(num_coupling=2))
+    torch.manual_seed(0)
+    ref = O.SRFlowOracle(3, 64, 64, num_coupling=2)
+    for (ka, a), (kb, b) in zip(net.state_dict().items(), ref.state_dict().items()):
+        assert ka == kb and torch.equal(a, b)
+
+
+def test_dataset_index_arithmetic_and_cli():
+    import main
+    from data import ConcatDataset, VideoAllDataset, VideoTrainDataset, VideoValDataset
+    from oracle import sininn_oracle as O
+    a = main.get_args(['train', '--synthetic', '300', '16', '16', '--fps', '10', '--lr_window', '2'])
+    assert (a.lr_dims, a.z_dims) == (20, 172)
+    sup, unsup = VideoTrainDataset(a), VideoAllDataset(a)
+    n = a.frame_store.num_lr
+    assert sup.frames == O.train_indices(n, 10) and unsup.frames == O.all_indices(n, 10)
+    torch.manual_seed(3)
+    val = VideoValDataset(a, 7)
+    torch.manual_seed(3)
+    assert val.frames == O.val_indices(n, 10, 2, 7, torch.randperm(n - 4).tolist())
+    cd = ConcatDataset(sup, unsup)
+    assert len(cd) == len(sup) and all(0 <= p < len(unsup) for p in cd.pair_positions(range(5)))
+    b = main.get_args(['train', '--synthetic', '8', '64', '64', '--fps', '1', '--lr_window', '1', '--tcr_iters', '3'])
+    assert VideoTrainDataset(b).frames == [2] and isinstance(b.tcr_iters, int)
+
+
+def test_tcr_matrices_match_oracle():
+    import tcr
+    from oracle import sininn_oracle as O
+    rand = torch.rand(5, 3)
+    for scale in (1, 0.25):
+        m = tcr.pixel_matrix(rand, 12, 20, 5.0, 5.0, scale)
+        assert torch.allclose(m, O.tcr_matrix(rand, 12, 20, 5.0, 5.0, scale), atol=1e-6)
+        assert torch.allclose(tcr.normalized_inverse(m, 12, 20), O.tcr_theta(m, 12, 20), atol=1e-6)
+
+
+_DP_SCRIPT = r'''
+import os, sys, torch
+sys.path.insert(0, %r)
+import sin_inn_amd
+from sin_inn_amd import dist as sd
+rank, ws = sd.init_from_env('gloo')
+assert ws == 2
+g = torch.full((10,), float(rank + 1))
+sd.allreduce_mean_([g])
+assert torch.allclose(g, torch.full((10,), 1.5))
+w = torch.full((4,), float(rank))
+sd.broadcast_([w])
+assert torch.equal(w, torch.zeros(4))
+assert sd.shard_indices(list(range(8))) == list(range(8))[rank::2]
+import data
+st = data.FrameStore.synthetic(40, 16, 16)
+class D(torch.utils.data.Dataset):
+    store = st; frames = list(range(3, 35)); win_size = 1; shuffle = False
+    def __len__(self): return len(self.frames)
+    def batch(self, pos): return [self.frames[p] for p in pos]
+class L(data.DeviceLoader):
+    def _store(self): return types.SimpleNamespace(device=types.SimpleNamespace(type='cuda'))
+import types
+seen = [x for b in L(D(), 4) for x in b]
+assert seen == D.frames[rank::2], seen
+print('rank', rank, 'ok')
+'''
+
+
+def test_data_parallel_glue_world2_gloo(tmp_path):
+    script = tmp_path / 'dp.py'
+    script.write_text(_DP_SCRIPT % ROOT)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                          '--master-addr', '127.0.0.1', '--master-port', '29713', str(script)],
+                         capture_output=True, text=True, env=env, timeout=240)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert 'rank 0 ok' in out.stdout and 'rank 1 ok' in out.stdout
