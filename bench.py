@@ -80,14 +80,17 @@ def cpu_baseline(args, opt, seconds_budget=30.0):
     lr = torch.rand(b, opt.lr_dims, args.size // 8, args.size // 8)
     z = torch.randn(b, opt.z_dims, args.size // 8, args.size // 8)
     lam = dict(fwd_rec=1.0, fwd_mmd=0.0, latent_nll=0.0, bwd_rec=1.0, bwd_mmd=0.0)
-    cores = os.cpu_count() or 1
+    # host cores actually available to this process (the box's CPU share), not the machine's core count
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get('SININN_CPU_THREADS', '16')))
     torch.set_num_threads(cores)
+    tw = time.time()
     O.training_step(ref, hr, lr, z, lam, opt.lr_dims); o.step()          # warm-up
+    tw = time.time() - tw
     t0, n = time.time(), 0
-    while n < 1 or (time.time() - t0 < seconds_budget * 0.5 and n < 3):
+    while tw < seconds_budget and (n < 1 or (time.time() - t0 < seconds_budget * 0.5 and n < 3)):
         O.training_step(ref, hr, lr, z, lam, opt.lr_dims); o.step()
         n += 1
-    dt = (time.time() - t0) / n
+    dt = (time.time() - t0) / n if n else tw
     return {'value': b / dt, 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'sample': f'{n} timed + 1 warm-up training steps of the torch-CPU oracle, batch {b}, '
                       f'{args.size}x{args.size}, -c {args.num_coupling}, fp32'}
@@ -104,7 +107,7 @@ def main():
     ap.add_argument('--lr-window', type=int, default=10)
     ap.add_argument('--frames', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-batch', type=int, default=4)
+    ap.add_argument('--cpu-batch', type=int, default=2)
     args = ap.parse_args()
 
     import sin_inn_amd
@@ -149,6 +152,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    print(f'[bench] rank {rank}: warm-up done', file=sys.stderr, flush=True)
     timer.enabled = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -163,6 +167,7 @@ def main():
 
     if rank != 0:
         return
+    print(f'[bench] timed region {dt:.3f}s for {args.steps} steps', file=sys.stderr, flush=True)
     ms_per_step = dt / args.steps * 1e3
     value = ws * b * args.steps / dt
     # roofline of the dominant kernel: algorithmic FLOPs (2 * pixels * 9*256 * 2*Co) per launch

@@ -154,7 +154,9 @@ def test_training_step_matches_oracle(lam):
     new_ref = torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
     old_ref = torch.cat([before[k].reshape(-1) for k, _ in ref.named_parameters()])
     new_hip = optim.flat_params()[0][:new_ref.numel()].cpu()
-    assert relerr(new_hip - old_ref, new_ref - old_ref) < 2e-2      # sign-like first Adam step, tiny-gradient entries
+    # first Adam step is ~ -lr*sign(g): compare the update only where the gradient is not in the rounding noise
+    big = ref_g.abs() > 1e-3 * ref_g.abs().max()
+    assert relerr((new_hip - old_ref)[big], (new_ref - old_ref)[big]) < 1e-2
     assert relerr(new_hip, new_ref) < 1e-5
 
 
