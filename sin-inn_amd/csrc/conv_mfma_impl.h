@@ -1,0 +1,339 @@
+// Implicit-GEMM convolution on v_mfma_f32_16x16x4_f32 with LDS-staged NHWC halo tiles and fused
+// epilogues (ReLU / affine coupling forward + inverse + log-det / ReLU-mask / add).
+//
+// Replaces, for the sin-inn hot path: nn.Conv2d in subnet_conv / subnet_conv_1x1 (archs.py:11-17)
+// and the elementwise tail of FrEIA's GLOWCouplingBlock (archs.py:61-64).
+//
+// GEMM view:  D[pixel][col] = sum_{tap, c} in[pixel + off(tap)][c] * w[tap][col][c]
+//   * block tile  = TH x 16 output pixels of one image  x  (WN*NT*16) packed columns
+//   * K loop      = (channel chunk of CK) x (tap); the input halo tile of a chunk is staged ONCE in
+//                   LDS and re-used by all 9 taps (the A operand is just a shifted LDS address)
+//   * operands    = k-contiguous rows in LDS (stride CK+4 floats => conflict-free ds_read_b64),
+//                   each 8-byte read feeds two MFMAs (k and k+1)
+//   * pipeline    = next iteration's weights (+ next chunk's halo tile) are fetched global->VGPR
+//                   while the current iteration's MFMAs run, then written to the other LDS buffer;
+//                   one barrier per iteration.
+#pragma once
+#include "common.h"
+
+namespace sininn {
+
+struct ConvDev {
+  const float* in; int in_stride; int Cin;
+  const float* w; const float* bias; int Np;
+  int B, H, W;
+  int CK;
+  float* out; int out_stride; int N; const int* out_map;
+  const float* v; int v_stride;
+  float* out2; int out2_stride;
+  float* sbuf; float* logdet;
+  int Co; float clamp;
+  const float* mask; int mask_stride;
+  const float* addend; int addend_stride; const int* addend_map;
+  int tiles_x, tiles_y;
+  int mode;
+};
+
+template <int KS, int TH, int WM, int WN, int MT, int NT, int CK>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvDev p) {
+  constexpr int HALO = KS / 2;
+  constexpr int IW = 16 + 2 * HALO;
+  constexpr int IH = TH + 2 * HALO;
+  constexpr int NPIX_IN = IH * IW;
+  constexpr int TAPS = KS * KS;
+  constexpr int BN = WN * NT * 16;
+  constexpr int S = CK + 4;                        // LDS row stride (floats): 4*odd -> conflict-free b64 reads
+  constexpr int C4N = CK / 4;
+  constexpr int KSTEPS = CK / 8;
+  constexpr int IN_F4 = (NPIX_IN * C4N + 255) / 256;
+  constexpr int W_F4 = (BN * C4N + 255) / 256;
+  static_assert(WM * MT == TH && WM * WN == 4, "bad wave layout");
+  static_assert(CK % 8 == 0 && CK <= 32, "bad channel chunk");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const in_lds = smem;                      // single buffer (changes once per TAPS iterations)
+  float* const w_lds0 = smem + NPIX_IN * S;        // weights: double buffer
+  float* const w_lds1 = w_lds0 + BN * S;
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 15, kq = lane >> 4;
+
+  int bid = blockIdx.x;
+  const int tx = bid % p.tiles_x; bid /= p.tiles_x;
+  const int ty = bid % p.tiles_y;
+  const int b = bid / p.tiles_y;
+  const int y0 = ty * TH, x0 = tx * 16;
+  const int n0 = blockIdx.y * BN;
+
+  // ---- per-thread staging descriptors (constant over the K loop) --------------------------------
+  int in_goff[IN_F4], in_loff[IN_F4];
+#pragma unroll
+  for (int r = 0; r < IN_F4; ++r) {
+    const int f = tid + 256 * r;
+    const int pix = f / C4N, c4 = f - pix * C4N;
+    const int py = pix / IW, px = pix - py * IW;
+    const int gy = y0 + py - HALO, gx = x0 + px - HALO;
+    const bool inside = (pix < NPIX_IN);
+    const bool inimg = inside && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    in_loff[r] = inside ? (pix * S + c4 * 4) : -1;
+    in_goff[r] = inimg ? (((b * p.H + gy) * p.W + gx) * p.in_stride + c4 * 4) : -1;
+  }
+  int w_goff[W_F4], w_loff[W_F4];
+#pragma unroll
+  for (int r = 0; r < W_F4; ++r) {
+    const int f = tid + 256 * r;
+    const int row = f / C4N, c4 = f - row * C4N;
+    const bool inside = row < BN;
+    w_loff[r] = inside ? (row * S + c4 * 4) : -1;
+    w_goff[r] = (inside && (n0 + row) < p.Np) ? ((n0 + row) * p.Cin + c4 * 4) : -1;
+  }
+
+  const int nchunks = p.Cin / CK;
+  const int nit = nchunks * TAPS;
+
+  f32x4 in_reg[IN_F4], w_reg[W_F4];
+  auto load_in = [&](int chunk) {
+#pragma unroll
+    for (int r = 0; r < IN_F4; ++r) {
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      in_reg[r] = (in_goff[r] >= 0) ? *reinterpret_cast<const f32x4*>(p.in + in_goff[r] + chunk * CK) : z;
+    }
+  };
+  auto store_in = [&]() {
+#pragma unroll
+    for (int r = 0; r < IN_F4; ++r)
+      if (in_loff[r] >= 0) *reinterpret_cast<f32x4*>(in_lds + in_loff[r]) = in_reg[r];
+  };
+  auto load_w = [&](int it) {
+    const int chunk = it / TAPS, tap = it - chunk * TAPS;
+    const float* base = p.w + (size_t)tap * p.Np * p.Cin + chunk * CK;
+#pragma unroll
+    for (int r = 0; r < W_F4; ++r) {
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      w_reg[r] = (w_goff[r] >= 0) ? *reinterpret_cast<const f32x4*>(base + w_goff[r]) : z;
+    }
+  };
+  auto store_w = [&](float* dst) {
+#pragma unroll
+    for (int r = 0; r < W_F4; ++r)
+      if (w_loff[r] >= 0) *reinterpret_cast<f32x4*>(dst + w_loff[r]) = w_reg[r];
+  };
+
+  // ---- fragment base offsets (floats) -----------------------------------------------------------
+  int a_base[MT], b_base[NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) a_base[m] = ((wm * MT + m) * IW + li) * S + 2 * kq;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) b_base[n] = ((wn * NT + n) * 16 + li) * S + 2 * kq;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: tile 0 into LDS, tile 1's weights in flight in registers -------------------------
+  load_in(0);
+  load_w(0);
+  store_in();
+  store_w(w_lds0);
+  if (nit > 1) load_w(1);
+  __syncthreads();
+
+  int chunk = 0, tap = 0;
+  for (int it = 0; it < nit; ++it) {
+    // (1) weights of iteration it+1 (fetched during it-1): registers -> the other LDS buffer; its last
+    //     readers finished before the barrier that ended iteration it-1
+    if (it + 1 < nit) store_w(((it + 1) & 1) ? w_lds1 : w_lds0);
+    // (2) start fetching the weights of it+2 and, on the last tap of a chunk, the next chunk's halo tile
+    if (it + 2 < nit) load_w(it + 2);
+    const bool last_tap = (tap == TAPS - 1);
+    const bool next_in = last_tap && (chunk + 1 < nchunks);
+    if (next_in) load_in(chunk + 1);
+
+    // (3) MFMAs of this (chunk, tap): fragments double-buffered in registers across k-steps
+    const float* Bw = (it & 1) ? w_lds1 : w_lds0;
+    const int dy = tap / KS, dx = tap - dy * KS;
+    const float* A = in_lds + (dy * IW + dx) * S;
+    float2 af[2][MT], bf[2][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) af[0][m] = *reinterpret_cast<const float2*>(A + a_base[m]);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bf[0][n] = *reinterpret_cast<const float2*>(Bw + b_base[n]);
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks + 1 < KSTEPS) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) af[nxt][m] = *reinterpret_cast<const float2*>(A + a_base[m] + (ks + 1) * 8);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bf[nxt][n] = *reinterpret_cast<const float2*>(Bw + b_base[n] + (ks + 1) * 8);
+      }
+      // two passes so that consecutive MFMAs never hit the same accumulator (16x16x4 f32: 32-cycle issue,
+      // 40-cycle dependent latency)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][m].x, bf[cur][n].x, acc[m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][m].y, bf[cur][n].y, acc[m][n], 0, 0, 0);
+    }
+    __syncthreads();
+    if (next_in) {            // every wave is done with the old halo tile: replace it
+      store_in();
+      __syncthreads();
+    }
+    if (last_tap) { tap = 0; ++chunk; } else { ++tap; }
+  }
+
+  const int MODE = p.mode;
+  // ---- epilogue: lane holds D[row = 4*kq + r][col = li] of every 16x16 tile ---------------------
+  float ld_acc = 0.f;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int gy = y0 + wm * MT + m;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int tile = blockIdx.y * (WN * NT) + wn * NT + n;   // global 16-column tile index
+      const int col = tile * 16 + li;
+      if (MODE == SININN_CONV_COUPLE_FWD || MODE == SININN_CONV_COUPLE_INV) {
+        // tile = [ s[8*tile .. +7] | t[8*tile .. +7] ] : lanes li<8 hold s, their partner li+8 holds t.
+        const bool colok = col < p.Np;
+        const float bia = (colok && p.bias) ? p.bias[col] : 0.f;
+        float mine[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mine[r] = acc[m][n][r] + bia;
+        const bool lo = li < 8;
+        // low lanes finish rows r=0,1 ; high lanes finish rows r=2,3 (two shuffles instead of four)
+        const float send0 = lo ? mine[2] : mine[0];
+        const float send1 = lo ? mine[3] : mine[1];
+        const float recv0 = __shfl_xor(send0, 8);
+        const float recv1 = __shfl_xor(send1, 8);
+        const int c = tile * 8 + (li & 7);
+        const int rbase = lo ? 0 : 2;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float s = lo ? mine[q] : (q == 0 ? recv0 : recv1);
+          const float t = lo ? (q == 0 ? recv0 : recv1) : mine[2 + q];
+          const int gx = x0 + 4 * kq + rbase + q;
+          if (c < p.Co && gy < p.H && gx < p.W) {
+            const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
+            const float vv = p.v[pix * p.v_stride + c];
+            const float L = glow_log_e(s, p.clamp);
+            const float e = expf(L);
+            float yv;
+            if (MODE == SININN_CONV_COUPLE_FWD) { yv = e * vv + t; ld_acc += L; }
+            else { yv = (vv - t) / e; ld_acc -= L; }
+            const int oc = p.out_map ? p.out_map[c] : c;
+            p.out[pix * p.out_stride + oc] = yv;
+            if (p.out2) p.out2[pix * p.out2_stride + c] = yv;
+            if (p.sbuf) p.sbuf[pix * p.Co + c] = s;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int gx = x0 + 4 * kq + r;
+          if (col < p.N && gy < p.H && gx < p.W) {
+            const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
+            float val = acc[m][n][r];
+            if (MODE == SININN_CONV_RELU) {
+              val = fmaxf(val + p.bias[col], 0.f);
+            } else if (MODE == SININN_CONV_LINEAR) {
+              val = val + (p.bias ? p.bias[col] : 0.f);
+            } else if (MODE == SININN_CONV_MASK) {
+              val = (p.mask[pix * p.mask_stride + col] > 0.f) ? val : 0.f;
+            } else if (MODE == SININN_CONV_ADD) {
+              const int ac = p.addend_map ? p.addend_map[col] : col;
+              val += p.addend[pix * p.addend_stride + ac];
+            }
+            p.out[pix * p.out_stride + col] = val;
+          }
+        }
+      }
+    }
+  }
+  if (MODE == SININN_CONV_COUPLE_FWD || MODE == SININN_CONV_COUPLE_INV) {
+    if (p.logdet) {
+      const float tot = wave_sum(ld_acc);
+      if (lane == 0) atomicAdd(p.logdet + b, tot);
+    }
+  }
+}
+
+
+template <int KS, int TH, int WM, int WN, int MT, int NT, int CK>
+static int launch_cfg_ck(const ConvDev& d, hipStream_t st) {
+  constexpr int HALO = KS / 2;
+  constexpr int NPIX_IN = (TH + 2 * HALO) * (16 + 2 * HALO);
+  constexpr int BN = WN * NT * 16;
+  constexpr int S = CK + 4;
+  constexpr size_t lds = (size_t)(NPIX_IN + 2 * BN) * S * sizeof(float);
+  static_assert(lds <= 160 * 1024, "LDS tile too large");
+  dim3 grid(d.tiles_x * d.tiles_y * d.B, (d.Np + BN - 1) / BN);
+  auto k = conv_mfma_kernel<KS, TH, WM, WN, MT, NT, CK>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("conv: cannot raise LDS limit to %zu", lds); return 1; }
+  }
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, d);
+  SININN_LAUNCH_CHECK("conv_mfma");
+  return 0;
+}
+
+template <int KS, int TH, int WM, int WN, int MT, int NT>
+static int launch_cfg(const ConvDev& d, hipStream_t st) {
+  switch (d.CK) {
+    case 32: return launch_cfg_ck<KS, TH, WM, WN, MT, NT, 32>(d, st);
+    case 24: return launch_cfg_ck<KS, TH, WM, WN, MT, NT, 24>(d, st);
+    case 16: return launch_cfg_ck<KS, TH, WM, WN, MT, NT, 16>(d, st);
+    case 8: return launch_cfg_ck<KS, TH, WM, WN, MT, NT, 8>(d, st);
+    default: set_error("conv: unsupported channel chunk %d", d.CK); return 1;
+  }
+}
+
+// Tile-shape choice.  nt16 = packed column tiles; pick the widest block that divides the columns well, and the
+// 4-row spatial tile when the 8-row one would leave the 256 CUs under-filled.
+template <int KS>
+static int dispatch(ConvDev& d, hipStream_t st, int force_cfg) {
+  const int nt16 = d.Np / 16;
+  auto set_tiles = [&](int th) { d.tiles_x = (d.W + 15) / 16; d.tiles_y = (d.H + th - 1) / th; };
+  const long pix_tiles8 = (long)d.B * ((d.H + 7) / 8) * ((d.W + 15) / 16);
+  int bnt;
+  if (nt16 % 8 == 0) bnt = 8;
+  else if (nt16 % 6 == 0) bnt = 6;
+  else if (nt16 % 3 == 0) bnt = 3;
+  else if (nt16 <= 2) bnt = 2;
+  else bnt = 4;
+  const long blocks8 = pix_tiles8 * ((nt16 + bnt - 1) / bnt);
+  bool small = blocks8 < 512;            // < 2 blocks per CU with the 8-row tile -> use 4-row tiles
+  if (force_cfg == 1) small = false;
+  if (force_cfg == 2) small = true;
+  if (!small) {
+    set_tiles(8);
+    switch (bnt) {
+      case 8: return launch_cfg<KS, 8, 2, 2, 4, 4>(d, st);
+      case 6: return launch_cfg<KS, 8, 2, 2, 4, 3>(d, st);
+      case 4: return launch_cfg<KS, 8, 2, 2, 4, 2>(d, st);
+      case 3: return launch_cfg<KS, 8, 4, 1, 2, 3>(d, st);
+      default: return launch_cfg<KS, 8, 4, 1, 2, 2>(d, st);
+    }
+  } else {
+    set_tiles(4);
+    switch (bnt) {
+      case 8: return launch_cfg<KS, 4, 1, 4, 4, 2>(d, st);
+      case 6: return launch_cfg<KS, 4, 2, 2, 2, 3>(d, st);
+      case 4: return launch_cfg<KS, 4, 2, 2, 2, 2>(d, st);
+      case 3: return launch_cfg<KS, 4, 4, 1, 1, 3>(d, st);
+      default: return launch_cfg<KS, 4, 4, 1, 1, 2>(d, st);
+    }
+  }
+}
+
+}  // namespace sininn

@@ -25,7 +25,7 @@ struct WgradDev {
 
 constexpr int WG_TH = 8;   // pixel tile 8 x 16
 
-template <int KS, int RT, int CT>
+template <int KS, int RT, int CT, int WR, int WC>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradDev p) {
   constexpr int HALO = KS / 2;
   constexpr int IW = 16 + 2 * HALO;
@@ -36,10 +36,10 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradDev p) {
   constexpr int BNW = RT * 16, BCW = CT * 16;
   constexpr int SD = BNW + 16;     // LDS row strides (floats): == 16 mod 32 -> the 4 k-lanes of a
   constexpr int SI = BCW + 16;     // ds_read_b32 hit disjoint bank groups
-  constexpr int NPAIR = RT * CT / 4;
+  constexpr int GR = RT / WR, GC = CT / WC;      // wave grid over the block's (row-tile, col-tile) plane
   constexpr int D_F4 = (NPIX * BNW / 4 + 255) / 256;
   constexpr int I_F4 = (NPIX_IN * BCW / 4 + 255) / 256;
-  static_assert((RT * CT) % 4 == 0, "pairs must split over 4 waves");
+  static_assert(GR * GC == 4 && GR * WR == RT && GC * WC == CT, "tiles must split over 4 waves");
 
   __shared__ __attribute__((aligned(16))) float d_lds[NPIX * SD];
   __shared__ __attribute__((aligned(16))) float i_lds[NPIX_IN * SI];
@@ -50,18 +50,18 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradDev p) {
   const int split = blockIdx.x;
   const int n0 = blockIdx.y * BNW, c0 = blockIdx.z * BCW;
 
-  int prt[NPAIR], pct[NPAIR];
-#pragma unroll
-  for (int q = 0; q < NPAIR; ++q) { const int pr = wave + 4 * q; prt[q] = pr % RT; pct[q] = pr / RT; }
+  const int rt0 = (wave % GR) * WR, ct0 = (wave / GR) * WC;    // first row / col tile of this wave
 
-  f32x4 acc[NPAIR][TAPS];
+  f32x4 acc[WR][WC][TAPS];
 #pragma unroll
-  for (int q = 0; q < NPAIR; ++q)
+  for (int a = 0; a < WR; ++a)
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) acc[q][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float bsum[NPAIR];
+    for (int c = 0; c < WC; ++c)
 #pragma unroll
-  for (int q = 0; q < NPAIR; ++q) bsum[q] = 0.f;
+      for (int t = 0; t < TAPS; ++t) acc[a][c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum[WR];
+#pragma unroll
+  for (int a = 0; a < WR; ++a) bsum[a] = 0.f;
 
   const int t_begin = split * p.tiles_per_split;
   const int t_end = min(t_begin + p.tiles_per_split, p.ntiles);
@@ -123,19 +123,21 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradDev p) {
       const int prow = ks >> 2, pcol = (ks & 3) * 4 + kq;     // this lane's pixel of the k-step
       const float* drow = d_lds + (prow * 16 + pcol) * SD + li;
       const float* irow = i_lds + (prow * IW + pcol) * SI + li;
-      float afr[NPAIR];
+      float afr[WR];
 #pragma unroll
-      for (int q = 0; q < NPAIR; ++q) {
-        afr[q] = drow[prt[q] * 16];
-        bsum[q] += afr[q];
+      for (int a = 0; a < WR; ++a) {
+        afr[a] = drow[(rt0 + a) * 16];
+        bsum[a] += afr[a];
       }
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
         const int dy = t / KS, dx = t % KS;
 #pragma unroll
-        for (int q = 0; q < NPAIR; ++q) {
-          const float bfr = irow[(dy * IW + dx) * SI + pct[q] * 16];
-          acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[q], bfr, acc[q][t], 0, 0, 0);
+        for (int c = 0; c < WC; ++c) {
+          const float bfr = irow[(dy * IW + dx) * SI + (ct0 + c) * 16];   // shared by the wave's WR row tiles
+#pragma unroll
+          for (int a = 0; a < WR; ++a)
+            acc[a][c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[a], bfr, acc[a][c][t], 0, 0, 0);
         }
       }
     }
@@ -143,46 +145,67 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradDev p) {
 
   // ---- write the slab: D[row = n (4*kq + r)][col = c (li)] --------------------------------------
 #pragma unroll
-  for (int q = 0; q < NPAIR; ++q) {
+  for (int a = 0; a < WR; ++a) {
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
+    for (int c = 0; c < WC; ++c)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = n0 + prt[q] * 16 + 4 * kq + r;
-        const int c = c0 + pct[q] * 16 + li;
-        if (n < p.Nr && c < p.Cc)
-          p.partial[(((size_t)split * TAPS + t) * p.Nr + n) * p.Cc + c] = acc[q][t][r];
-      }
-    }
-    // bias partial: lanes (li, kq) hold sum over their pixels of dout[.][n = rt*16 + li]
-    float bs = bsum[q];
+      for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + (rt0 + a) * 16 + 4 * kq + r;
+          const int cc = c0 + (ct0 + c) * 16 + li;
+          if (n < p.Nr && cc < p.Cc)
+            p.partial[(((size_t)split * TAPS + t) * p.Nr + n) * p.Cc + cc] = acc[a][c][t][r];
+        }
+    // bias partial: lanes (li, kq) hold the sum over their pixels of dout[.][n = rt*16 + li]
+    float bs = bsum[a];
     bs += __shfl_xor(bs, 16);
     bs += __shfl_xor(bs, 32);
-    if (blockIdx.z == 0 && pct[q] == 0 && kq == 0) {
-      const int n = n0 + prt[q] * 16 + li;
+    if (blockIdx.z == 0 && ct0 == 0 && kq == 0) {
+      const int n = n0 + (rt0 + a) * 16 + li;
       if (n < p.Nr) p.bpartial[(size_t)split * p.Nr + n] = bs;
     }
   }
 }
 
 // Reduce S slabs in order and accumulate into the OIHW gradient:  gw[n][c][tap] += sum_s partial[s][tap][n][c]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial,
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial,
                                     int S, int taps, int Nr, int Cc, int N, int Cin,
                                     float* __restrict__ gw, float* __restrict__ gb) {
+  // block = 64 outputs x 4 slab groups: group g sums slabs g, g+4, ... (8 loads in flight), then a fixed-order
+  // 4-way combine through LDS -> bitwise reproducible
+  __shared__ float red[4][64];
   const int total = taps * N * Cin;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < total) {
-    const int c = idx % Cin;
-    const int n = (idx / Cin) % N;
-    const int t = idx / (Cin * N);
-    float s = 0.f;
-    for (int k = 0; k < S; ++k) s += partial[(((size_t)k * taps + t) * Nr + n) * Cc + c];
-    gw[((size_t)n * Cin + c) * taps + t] += s;
+  const int o = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int grp = threadIdx.x >> 6;
+  float s = 0.f;
+  size_t base = 0, stride = (size_t)taps * Nr * Cc;
+  int c = 0, n = 0, t = 0;
+  const bool live = o < total;
+  if (live) {
+    c = o % Cin; n = (o / Cin) % N; t = o / (Cin * N);
+    base = ((size_t)t * Nr + n) * Cc + c;
+    float s0 = 0.f, s1 = 0.f;
+    int k = grp;
+    for (; k + 4 < S; k += 8) {
+      s0 += partial[base + (size_t)k * stride];
+      s1 += partial[base + (size_t)(k + 4) * stride];
+    }
+    if (k < S) s0 += partial[base + (size_t)k * stride];
+    s = s0 + s1;
   }
-  if (gb != nullptr && idx < N) {
-    float s = 0.f;
-    for (int k = 0; k < S; ++k) s += bpartial[(size_t)k * Nr + idx];
-    gb[idx] += s;
+  red[grp][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (grp == 0 && live) {
+    const int l = threadIdx.x;
+    gw[((size_t)n * Cin + c) * taps + t] += (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+  }
+  if (gb != nullptr && blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < N; i += 256) {
+      float b = 0.f;
+      for (int k = 0; k < S; ++k) b += bpartial[(size_t)k * Nr + i];
+      gb[i] += b;
+    }
   }
 }
 
@@ -218,9 +241,9 @@ size_t wgrad_workspace_bytes(int N, int Cin, int ksize, int B, int H, int W) {
 template <int KS>
 static void launch_wgrad(const WgradPlan& pl, const WgradDev& d, hipStream_t st) {
   dim3 grid(pl.S, pl.nblk, pl.cblk);
-  if (pl.RT == 3) hipLaunchKernelGGL((wgrad_mfma_kernel<KS, 3, 4>), grid, dim3(256), 0, st, d);
-  else if (pl.CT == 4) hipLaunchKernelGGL((wgrad_mfma_kernel<KS, 4, 4>), grid, dim3(256), 0, st, d);
-  else hipLaunchKernelGGL((wgrad_mfma_kernel<KS, 4, 2>), grid, dim3(256), 0, st, d);
+  if (pl.RT == 3) hipLaunchKernelGGL((wgrad_mfma_kernel<KS, 3, 4, 3, 1>), grid, dim3(256), 0, st, d);
+  else if (pl.CT == 4) hipLaunchKernelGGL((wgrad_mfma_kernel<KS, 4, 4, 2, 2>), grid, dim3(256), 0, st, d);
+  else hipLaunchKernelGGL((wgrad_mfma_kernel<KS, 4, 2, 2, 1>), grid, dim3(256), 0, st, d);
 }
 
 int wgrad_launch(const float* in, int in_stride, int Cin, const float* dout, int dout_stride, int N,
@@ -243,7 +266,7 @@ int wgrad_launch(const float* in, int in_stride, int Cin, const float* dout, int
   if (ksize == 3) launch_wgrad<3>(pl, d, st); else launch_wgrad<1>(pl, d, st);
   SININN_LAUNCH_CHECK("wgrad_mfma");
   const int total = taps * N * Cin;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st,
                      d.partial, d.bpartial, pl.S, taps, pl.Nr, pl.Cc, N, Cin, gw, gb);
   SININN_LAUNCH_CHECK("wgrad_reduce");
   return 0;

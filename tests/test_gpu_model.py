@@ -157,7 +157,9 @@ def test_training_step_matches_oracle(lam):
     # first Adam step is ~ -lr*sign(g): compare the update only where the gradient is not in the rounding noise
     big = ref_g.abs() > 1e-3 * ref_g.abs().max()
     assert relerr((new_hip - old_ref)[big], (new_ref - old_ref)[big]) < 1e-2
-    assert relerr(new_hip, new_ref) < 1e-5
+    assert relerr(new_hip[big], new_ref[big]) < 1e-5
+    # entries whose gradient is rounding noise move by +-lr in either implementation (Adam's first step is sign-like)
+    assert float((new_hip - new_ref).abs().max()) <= 2.5 * opt.learning_rate
 
 
 def test_full_size_properties():
