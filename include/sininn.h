@@ -50,8 +50,10 @@ int sininn_pack_conv_weights(const float* w_oihw, const float* bias, int N, int 
                              int Cdp, float* w_dgrad, void* stream);
 
 /* Packed column order used by the coupling epilogue for a subnet with 2*Co outputs (s | t):
- * 16-column tile q = [ s[8q..8q+7] | t[8q..8q+7] ].  Writes 2*Co ints (host memory). */
-void sininn_coupling_colmap(int Co, int* colmap_host);
+ * `tile`-column MFMA tile q = [ s[h*q .. h*q+h-1] | t[h*q .. h*q+h-1] ], h = tile/2, tile in {16, 32}
+ * (tile 32 needs Co % 16 == 0).  Writes 2*Co ints (host memory).  The same `tile` must be passed as
+ * sininn_conv_args.col_tile. */
+void sininn_coupling_colmap(int Co, int tile, int* colmap_host);
 
 /* ------------------------------------------------------------------------------------------------
  * Convolution engine (implicit GEMM on v_mfma_f32_16x16x4_f32, LDS-staged halo tiles).
@@ -79,6 +81,7 @@ typedef struct sininn_conv_args {
   float* sbuf;                                     /* coupling: optional [M][Co] copy of s (for backward)  */
   float* logdet;                                   /* coupling: optional [B], accumulated with atomics     */
   int Co;            float clamp;                  /* coupling: channels transformed, GLOW clamp           */
+  int col_tile;                                    /* coupling: 16 or 32, the (s|t) interleave of the weights */
   const float* mask; int mask_stride;              /* MASK mode                                            */
   const float* addend; int addend_stride; const int* addend_map; /* ADD mode                               */
 } sininn_conv_args;

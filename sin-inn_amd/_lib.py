@@ -29,7 +29,7 @@ class ConvArgs(C.Structure):
         ('out2', c_f), ('out2_stride', C.c_int),
         ('sbuf', c_f),
         ('logdet', c_f),
-        ('Co', C.c_int), ('clamp', C.c_float),
+        ('Co', C.c_int), ('clamp', C.c_float), ('col_tile', C.c_int),
         ('mask', c_f), ('mask_stride', C.c_int),
         ('addend', c_f), ('addend_stride', C.c_int), ('addend_map', c_i),
     ]
@@ -41,7 +41,7 @@ _SIGS = {
     'sininn_version': (C.c_int, []),
     'sininn_last_error': (C.c_char_p, []),
     'sininn_pack_conv_weights': (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, c_i, C.c_int, c_f, c_f, C.c_int, c_f, C.c_void_p]),
-    'sininn_coupling_colmap': (None, [C.c_int, C.POINTER(C.c_int)]),
+    'sininn_coupling_colmap': (None, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
     'sininn_conv': (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     'sininn_conv_test_hooks': (None, [C.c_int, C.c_int]),
     'sininn_wgrad_workspace_bytes': (C.c_size_t, [C.c_int] * 6),

@@ -68,10 +68,11 @@ int sininn_pack_conv_weights(const float* w_oihw, const float* bias, int N, int 
   return pack_launch(w_oihw, bias, N, Cin, ksize, colmap, Np, w_fwd, b_fwd, Cdp, w_dgrad, ST(stream));
 }
 
-void sininn_coupling_colmap(int Co, int* colmap_host) {
+void sininn_coupling_colmap(int Co, int tile, int* colmap_host) {
+  const int w = (tile == 32) ? 32 : 16, h = w / 2;
   for (int q = 0; q < 2 * Co; ++q) {
-    const int tile = q / 16, j = q % 16;
-    colmap_host[q] = (j < 8) ? (tile * 8 + j) : (Co + tile * 8 + j - 8);
+    const int t = q / w, j = q % w;
+    colmap_host[q] = (j < h) ? (t * h + j) : (Co + t * h + j - h);
   }
 }
 

@@ -6,6 +6,8 @@ namespace sininn {
 
 int conv_dispatch_k3(ConvDev& d, hipStream_t st, int force_cfg);
 int conv_dispatch_k1(ConvDev& d, hipStream_t st, int force_cfg);
+int conv32_dispatch_k3(ConvDev& d, hipStream_t st, int force_cfg, bool must);
+int conv32_dispatch_k1(ConvDev& d, hipStream_t st, int force_cfg, bool must);
 
 static int g_force_cfg = 0;   // test hook: 0 auto, 1 force 8-row tiles, 2 force 4-row tiles
 static int g_force_ck = 0;    // test hook: override the channel chunk
@@ -34,6 +36,17 @@ int conv_launch(const sininn_conv_args* a, hipStream_t st) {
     if (a->mode == SININN_CONV_MASK) SININN_CHECK(a->mask != nullptr && a->mask_stride >= a->N, "conv: MASK mode needs mask");
     if (a->mode == SININN_CONV_ADD) SININN_CHECK(a->addend != nullptr, "conv: ADD mode needs addend");
   }
+  // the epilogue moves 16-byte vectors along the channel axis
+  SININN_CHECK(aligned16(a->out) && a->out_stride % 4 == 0, "conv: out must be 16-byte aligned with stride %% 4 == 0");
+  SININN_CHECK(!a->bias || aligned16(a->bias), "conv: bias must be 16-byte aligned");
+  if (couple) {
+    SININN_CHECK(aligned16(a->v) && a->v_stride % 4 == 0, "conv: v must be 16-byte aligned with stride %% 4 == 0");
+    SININN_CHECK(!a->out2 || (aligned16(a->out2) && a->out2_stride % 4 == 0), "conv: out2 must be 16-byte aligned");
+    SININN_CHECK(!a->sbuf || aligned16(a->sbuf), "conv: sbuf must be 16-byte aligned");
+  }
+  if (a->mode == SININN_CONV_MASK) SININN_CHECK(aligned16(a->mask) && a->mask_stride % 4 == 0, "conv: mask must be 16-byte aligned");
+  if (a->mode == SININN_CONV_ADD && !a->addend_map)
+    SININN_CHECK(aligned16(a->addend) && a->addend_stride % 4 == 0, "conv: addend must be 16-byte aligned");
   ConvDev d;
   d.in = a->in; d.in_stride = a->in_stride; d.Cin = a->Cin;
   d.w = a->w; d.bias = a->bias; d.Np = a->Np;
@@ -50,8 +63,17 @@ int conv_launch(const sininn_conv_args* a, hipStream_t st) {
   for (int c : {32, 24, 16, 8}) if (a->Cin % c == 0) { ck = c; break; }
   if (g_force_ck && a->Cin % g_force_ck == 0 && g_force_ck % 8 == 0 && g_force_ck <= 32) ck = g_force_ck;
   d.CK = ck;
-  if (a->ksize == 3) return conv_dispatch_k3(d, st, g_force_cfg);
-  return conv_dispatch_k1(d, st, g_force_cfg);
+  // column-tile width: coupling weights are packed for one specific width (col_tile); other modes take the
+  // 32-wide MFMA shape whenever the column count allows (g_force_cfg >= 10 pins the 16-wide kernel for tests)
+  const int tile = couple ? (a->col_tile == 32 ? 32 : 16) : ((a->Np % 32 == 0 && g_force_cfg < 10) ? 32 : 16);
+  if (couple && tile == 32) SININN_CHECK(a->Co % 16 == 0, "conv: col_tile 32 needs Co %% 16 == 0 (Co=%d)", a->Co);
+  const int fc = g_force_cfg % 10;
+  if (tile == 32) {
+    const int rc = (a->ksize == 3) ? conv32_dispatch_k3(d, st, fc, couple) : conv32_dispatch_k1(d, st, fc, couple);
+    if (rc >= 0) return rc;
+  }
+  if (a->ksize == 3) return conv_dispatch_k3(d, st, fc);
+  return conv_dispatch_k1(d, st, fc);
 }
 
 void conv_set_test_hooks(int force_cfg, int force_ck) { g_force_cfg = force_cfg; g_force_ck = force_ck; }

@@ -34,6 +34,114 @@ struct ConvDev {
   int mode;
 };
 
+
+// ------------------------------------------------------------------------------------------------
+// Epilogue, phase 2 (shared by the 16- and 32-wide kernels): the block's accumulator tile has been
+// staged in LDS as T[pixel][BN+4] (raw GEMM sums, block-local columns); all 256 threads now walk it
+// in 16-byte units along the channel axis, so every global access of the epilogue (bias, mask, v,
+// addend, y, s) is a coalesced float4 instead of a per-lane 4-byte scatter.
+//   HT = half-tile of the coupling interleave: tile of 2*HT columns = [ s HT ch | t HT ch ].
+// ------------------------------------------------------------------------------------------------
+template <int TH, int BN, int HT>
+__device__ __forceinline__ void conv_epilogue_tile(const ConvDev& p, const float* T, int b, int y0, int x0, int n0,
+                                                   int tid, float* red) {
+  constexpr int TS = BN + 4;
+  constexpr int NPIX = TH * 16;
+  const int MODE = p.mode;
+  if (MODE == SININN_CONV_COUPLE_FWD || MODE == SININN_CONV_COUPLE_INV) {
+    constexpr int CB = BN / 2;                       // channels of this block
+    constexpr int Q = CB / 4;                        // channel quads per pixel
+    const int c_block0 = n0 / 2;
+    float ld_acc = 0.f;
+    for (int idx = tid; idx < NPIX * Q; idx += 256) {
+      const int pl = idx / Q, q4 = idx - pl * Q;
+      const int cl = q4 * 4;                         // block-local channel
+      const int c = c_block0 + cl;
+      const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+      if (c < p.Co && gy < p.H && gx < p.W) {
+        const int tcol = (cl / HT) * (2 * HT) + (cl % HT);
+        f32x4 s4 = *reinterpret_cast<const f32x4*>(T + pl * TS + tcol);
+        f32x4 t4 = *reinterpret_cast<const f32x4*>(T + pl * TS + tcol + HT);
+        if (p.bias) {
+          s4 += *reinterpret_cast<const f32x4*>(p.bias + n0 + tcol);
+          t4 += *reinterpret_cast<const f32x4*>(p.bias + n0 + tcol + HT);
+        }
+        const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
+        const f32x4 v4 = *reinterpret_cast<const f32x4*>(p.v + pix * p.v_stride + c);
+        f32x4 y4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float L = glow_log_e(s4[j], p.clamp);
+          const float e = expf(L);
+          if (MODE == SININN_CONV_COUPLE_FWD) { y4[j] = e * v4[j] + t4[j]; ld_acc += L; }
+          else { y4[j] = (v4[j] - t4[j]) / e; ld_acc -= L; }
+        }
+        if (p.out_map) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) p.out[pix * p.out_stride + p.out_map[c + j]] = y4[j];
+        } else {
+          *reinterpret_cast<f32x4*>(p.out + pix * p.out_stride + c) = y4;
+        }
+        if (p.out2) *reinterpret_cast<f32x4*>(p.out2 + pix * p.out2_stride + c) = y4;
+        if (p.sbuf) *reinterpret_cast<f32x4*>(p.sbuf + pix * p.Co + c) = s4;
+      }
+    }
+    if (p.logdet) {                                  // block-uniform branch
+      const float w = wave_sum(ld_acc);
+      if ((tid & 63) == 0) red[tid >> 6] = w;
+      __syncthreads();
+      if (tid == 0) atomicAdd(p.logdet + b, red[0] + red[1] + red[2] + red[3]);
+    }
+  } else {
+    constexpr int Q = BN / 4;
+    for (int idx = tid; idx < NPIX * Q; idx += 256) {
+      const int pl = idx / Q, q4 = idx - pl * Q;
+      const int col = n0 + q4 * 4;
+      const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+      if (col < p.N && gy < p.H && gx < p.W) {
+        const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
+        f32x4 val = *reinterpret_cast<const f32x4*>(T + pl * TS + q4 * 4);
+        const bool full = (col + 3 < p.N);
+        if (MODE == SININN_CONV_RELU || MODE == SININN_CONV_LINEAR) {
+          if (p.bias) val += *reinterpret_cast<const f32x4*>(p.bias + col);   // packed bias has Np >= col+4 entries
+          if (MODE == SININN_CONV_RELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) val[j] = fmaxf(val[j], 0.f);
+          }
+        } else if (MODE == SININN_CONV_MASK) {
+          if (full) {
+            const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + pix * p.mask_stride + col);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) val[j] = (mk[j] > 0.f) ? val[j] : 0.f;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (col + j < p.N) val[j] = (p.mask[pix * p.mask_stride + col + j] > 0.f) ? val[j] : 0.f;
+          }
+        } else if (MODE == SININN_CONV_ADD) {
+          if (p.addend_map == nullptr && full) {
+            val += *reinterpret_cast<const f32x4*>(p.addend + pix * p.addend_stride + col);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (col + j < p.N) {
+                const int ac = p.addend_map ? p.addend_map[col + j] : (col + j);
+                val[j] += p.addend[pix * p.addend_stride + ac];
+              }
+          }
+        }
+        if (full) {
+          *reinterpret_cast<f32x4*>(p.out + pix * p.out_stride + col) = val;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (col + j < p.N) p.out[pix * p.out_stride + col + j] = val[j];
+        }
+      }
+    }
+  }
+}
+
 template <int KS, int TH, int WM, int WN, int MT, int NT, int CK>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvDev p) {
   constexpr int HALO = KS / 2;
@@ -171,6 +279,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvDev p) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) bf[nxt][n] = *reinterpret_cast<const float2*>(Bw + b_base[n] + (ks + 1) * 8);
       }
+      // keep the next k-step's LDS reads ahead of this k-step's MFMAs (hipcc otherwise sinks them next to their
+      // first use and the wave eats the LDS latency on every k-step)
+      __builtin_amdgcn_sched_barrier(0);
       // two passes so that consecutive MFMAs never hit the same accumulator (16x16x4 f32: 32-cycle issue,
       // 40-cycle dependent latency)
 #pragma unroll
@@ -192,81 +303,23 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvDev p) {
     if (last_tap) { tap = 0; ++chunk; } else { ++tap; }
   }
 
-  const int MODE = p.mode;
-  // ---- epilogue: lane holds D[row = 4*kq + r][col = li] of every 16x16 tile ---------------------
-  float ld_acc = 0.f;
+  // ---- epilogue phase 1: accumulators -> LDS tile T[pixel][BN+4] (lane holds D[row = 4*kq + r][col = li]) ----
+  // (the last main-loop barrier guarantees nobody still reads the operand tiles that T overlays)
+  {
+    constexpr int TS = BN + 4;
+    float* const T = smem;
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const int gy = y0 + wm * MT + m;
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int tile = blockIdx.y * (WN * NT) + wn * NT + n;   // global 16-column tile index
-      const int col = tile * 16 + li;
-      if (MODE == SININN_CONV_COUPLE_FWD || MODE == SININN_CONV_COUPLE_INV) {
-        // tile = [ s[8*tile .. +7] | t[8*tile .. +7] ] : lanes li<8 hold s, their partner li+8 holds t.
-        const bool colok = col < p.Np;
-        const float bia = (colok && p.bias) ? p.bias[col] : 0.f;
-        float mine[4];
+      for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mine[r] = acc[m][n][r] + bia;
-        const bool lo = li < 8;
-        // low lanes finish rows r=0,1 ; high lanes finish rows r=2,3 (two shuffles instead of four)
-        const float send0 = lo ? mine[2] : mine[0];
-        const float send1 = lo ? mine[3] : mine[1];
-        const float recv0 = __shfl_xor(send0, 8);
-        const float recv1 = __shfl_xor(send1, 8);
-        const int c = tile * 8 + (li & 7);
-        const int rbase = lo ? 0 : 2;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const float s = lo ? mine[q] : (q == 0 ? recv0 : recv1);
-          const float t = lo ? (q == 0 ? recv0 : recv1) : mine[2 + q];
-          const int gx = x0 + 4 * kq + rbase + q;
-          if (c < p.Co && gy < p.H && gx < p.W) {
-            const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
-            const float vv = p.v[pix * p.v_stride + c];
-            const float L = glow_log_e(s, p.clamp);
-            const float e = expf(L);
-            float yv;
-            if (MODE == SININN_CONV_COUPLE_FWD) { yv = e * vv + t; ld_acc += L; }
-            else { yv = (vv - t) / e; ld_acc -= L; }
-            const int oc = p.out_map ? p.out_map[c] : c;
-            p.out[pix * p.out_stride + oc] = yv;
-            if (p.out2) p.out2[pix * p.out2_stride + c] = yv;
-            if (p.sbuf) p.sbuf[pix * p.Co + c] = s;
-          }
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int gx = x0 + 4 * kq + r;
-          if (col < p.N && gy < p.H && gx < p.W) {
-            const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
-            float val = acc[m][n][r];
-            if (MODE == SININN_CONV_RELU) {
-              val = fmaxf(val + p.bias[col], 0.f);
-            } else if (MODE == SININN_CONV_LINEAR) {
-              val = val + (p.bias ? p.bias[col] : 0.f);
-            } else if (MODE == SININN_CONV_MASK) {
-              val = (p.mask[pix * p.mask_stride + col] > 0.f) ? val : 0.f;
-            } else if (MODE == SININN_CONV_ADD) {
-              const int ac = p.addend_map ? p.addend_map[col] : col;
-              val += p.addend[pix * p.addend_stride + ac];
-            }
-            p.out[pix * p.out_stride + col] = val;
-          }
-        }
-      }
-    }
-  }
-  if (MODE == SININN_CONV_COUPLE_FWD || MODE == SININN_CONV_COUPLE_INV) {
-    if (p.logdet) {
-      const float tot = wave_sum(ld_acc);
-      if (lane == 0) atomicAdd(p.logdet + b, tot);
-    }
+        for (int r = 0; r < 4; ++r)
+          T[((wm * MT + m) * 16 + 4 * kq + r) * TS + (wn * NT + n) * 16 + li] = acc[m][n][r];
+    __syncthreads();
+    __shared__ float red[4];
+    conv_epilogue_tile<TH, BN, 8>(p, T, b, y0, x0, n0, tid, red);
   }
 }
-
 
 template <int KS, int TH, int WM, int WN, int MT, int NT, int CK>
 static int launch_cfg_ck(const ConvDev& d, hipStream_t st) {
@@ -274,7 +327,9 @@ static int launch_cfg_ck(const ConvDev& d, hipStream_t st) {
   constexpr int NPIX_IN = (TH + 2 * HALO) * (16 + 2 * HALO);
   constexpr int BN = WN * NT * 16;
   constexpr int S = CK + 4;
-  constexpr size_t lds = (size_t)(NPIX_IN + 2 * BN) * S * sizeof(float);
+  constexpr size_t lds_main = (size_t)(NPIX_IN + 2 * BN) * S * sizeof(float);
+  constexpr size_t lds_epi = (size_t)TH * 16 * (BN + 4) * sizeof(float);
+  constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   static_assert(lds <= 160 * 1024, "LDS tile too large");
   dim3 grid(d.tiles_x * d.tiles_y * d.B, (d.Np + BN - 1) / BN);
   auto k = conv_mfma_kernel<KS, TH, WM, WN, MT, NT, CK>;

@@ -1,4 +1,5 @@
-#include "conv_mfma_impl.h"
+#include "conv32_impl.h"
 namespace sininn {
 int conv_dispatch_k3(ConvDev& d, hipStream_t st, int force_cfg) { return dispatch<3>(d, st, force_cfg); }
+int conv32_dispatch_k3(ConvDev& d, hipStream_t st, int force_cfg, bool must) { return dispatch32<3>(d, st, force_cfg, must); }
 }

@@ -168,37 +168,42 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradDev p) {
   }
 }
 
-// Reduce S slabs in order and accumulate into the OIHW gradient:  gw[n][c][tap] += sum_s partial[s][tap][n][c]
+// Reduce S slabs in a fixed order and accumulate into the OIHW gradient:  gw[n][c][tap] += sum_s partial[s][tap][n][c]
+// A thread owns 4 consecutive c of one (tap, n) row (16-byte loads); the S slabs are split over the block's 4 waves,
+// 4 loads in flight each; the 4 partial sums are combined through LDS in a fixed order -> bitwise reproducible.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial,
                                     int S, int taps, int Nr, int Cc, int N, int Cin,
                                     float* __restrict__ gw, float* __restrict__ gb) {
-  // block = 64 outputs x 4 slab groups: group g sums slabs g, g+4, ... (8 loads in flight), then a fixed-order
-  // 4-way combine through LDS -> bitwise reproducible
-  __shared__ float red[4][64];
-  const int total = taps * N * Cin;
+  __shared__ f32x4 red[4][64];
+  const int c4n = Cc >> 2;
+  const int total4 = taps * Nr * c4n;                 // float4 columns of one slab
   const int o = blockIdx.x * 64 + (threadIdx.x & 63);
   const int grp = threadIdx.x >> 6;
-  float s = 0.f;
-  size_t base = 0, stride = (size_t)taps * Nr * Cc;
-  int c = 0, n = 0, t = 0;
-  const bool live = o < total;
+  const bool live = o < total4;
+  const size_t stride4 = (size_t)total4;
+  const f32x4* p4 = reinterpret_cast<const f32x4*>(partial);
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
   if (live) {
-    c = o % Cin; n = (o / Cin) % N; t = o / (Cin * N);
-    base = ((size_t)t * Nr + n) * Cc + c;
-    float s0 = 0.f, s1 = 0.f;
     int k = grp;
-    for (; k + 4 < S; k += 8) {
-      s0 += partial[base + (size_t)k * stride];
-      s1 += partial[base + (size_t)(k + 4) * stride];
+    for (; k + 12 < S; k += 16) {
+      s0 += p4[o + (size_t)k * stride4];
+      s1 += p4[o + (size_t)(k + 4) * stride4];
+      s2 += p4[o + (size_t)(k + 8) * stride4];
+      s3 += p4[o + (size_t)(k + 12) * stride4];
     }
-    if (k < S) s0 += partial[base + (size_t)k * stride];
-    s = s0 + s1;
+    for (; k < S; k += 4) s0 += p4[o + (size_t)k * stride4];
   }
-  red[grp][threadIdx.x & 63] = s;
+  red[grp][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (grp == 0 && live) {
     const int l = threadIdx.x;
-    gw[((size_t)n * Cin + c) * taps + t] += (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    const f32x4 tot = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    const int c0 = (o % c4n) * 4, n = (o / c4n) % Nr, t = o / (c4n * Nr);
+    if (n < N) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c0 + j < Cin) gw[((size_t)n * Cin + c0 + j) * taps + t] += tot[j];
+    }
   }
   if (gb != nullptr && blockIdx.x == 0) {
     for (int i = threadIdx.x; i < N; i += 256) {
@@ -265,8 +270,8 @@ int wgrad_launch(const float* in, int in_stride, int Cin, const float* dout, int
   d.bpartial = d.partial + (size_t)pl.S * taps * pl.Nr * pl.Cc;
   if (ksize == 3) launch_wgrad<3>(pl, d, st); else launch_wgrad<1>(pl, d, st);
   SININN_LAUNCH_CHECK("wgrad_mfma");
-  const int total = taps * N * Cin;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st,
+  const int total4 = taps * pl.Nr * (pl.Cc / 4);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total4 + 63) / 64), dim3(256), 0, st,
                      d.partial, d.bpartial, pl.S, taps, pl.Nr, pl.Cc, N, Cin, gw, gb);
   SININN_LAUNCH_CHECK("wgrad_reduce");
   return 0;

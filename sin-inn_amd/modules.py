@@ -150,7 +150,7 @@ class _GlowFn(torch.autograd.Function):
             ops.conv(in_=_vp(hbuf), in_stride=HIDDEN, Cin=HIDDEN, w=_vp(w2), bias=_vp(b2), Np=2 * co,
                      B=b, H=h, W=w, ksize=k, mode=mode, out=o_ptr, out_stride=c, out_map=o_map,
                      v=_vp(x, vbase), v_stride=c, out2=_vp(y_compact), out2_stride=co, sbuf=_vp(sbuf),
-                     logdet=_vp(logdet), Co=co, clamp=block.clamp)
+                     logdet=_vp(logdet), Co=co, clamp=block.clamp, col_tile=ops.coupling_tile(co))
             if i == 0:
                 ybuf = y_compact
             saved[i] = (hbuf, sbuf)

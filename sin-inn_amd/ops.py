@@ -45,12 +45,17 @@ def pad16(n):
 _colmap_cache = {}
 
 
+def coupling_tile(co):
+    """MFMA column-tile width the coupling conv of a `co`-channel half runs with (32 when co % 16 == 0)."""
+    return 32 if co % 16 == 0 else 16
+
+
 def coupling_colmap(co, device):
-    """Device int32 [2*co]: packed column -> subnet output channel, (s|t) interleaved per 16-col tile."""
+    """Device int32 [2*co]: packed column -> subnet output channel, (s|t) interleaved per MFMA column tile."""
     key = (co, str(device))
     if key not in _colmap_cache:
         host = (C.c_int * (2 * co))()
-        _lib.lib().sininn_coupling_colmap(co, host)
+        _lib.lib().sininn_coupling_colmap(co, coupling_tile(co), host)
         _colmap_cache[key] = torch.tensor(list(host), dtype=torch.int32, device=device)
     return _colmap_cache[key]
 

@@ -40,10 +40,15 @@ def test_coupling_colmap_layout():
     import sin_inn_amd
     from sin_inn_amd import _lib
     buf = (C.c_int * 48)()
-    _lib.lib().sininn_coupling_colmap(24, buf)
+    _lib.lib().sininn_coupling_colmap(24, 16, buf)
     m = list(buf)
     assert m[:8] == list(range(8)) and m[8:16] == list(range(24, 32)) and m[16:24] == list(range(8, 16))
     assert sorted(m) == list(range(48))
+    buf = (C.c_int * 192)()
+    _lib.lib().sininn_coupling_colmap(96, 32, buf)
+    m = list(buf)
+    assert m[:16] == list(range(16)) and m[16:32] == list(range(96, 112)) and m[32:48] == list(range(16, 32))
+    assert sorted(m) == list(range(192))
 
 
 def _opt(**kw):

@@ -61,7 +61,7 @@ def main():
                 if mode == _lib.CONV_COUPLE_FWD:
                     sb = torch.empty(m, co, device=dev); ld = torch.zeros(b, device=dev)
                     keep += [sb, ld]
-                    kw.update(out_stride=c, v=ops.ptr(v), v_stride=c, sbuf=ops.ptr(sb), logdet=ops.ptr(ld), Co=co, clamp=1.2)
+                    kw.update(out_stride=c, v=ops.ptr(v), v_stride=c, sbuf=ops.ptr(sb), logdet=ops.ptr(ld), Co=co, clamp=1.2, col_tile=ops.coupling_tile(co))
                 if mode == _lib.CONV_MASK:
                     mk = torch.randn(m, 256, device=dev); keep.append(mk)
                     kw.update(mask=ops.ptr(mk), mask_stride=256)
