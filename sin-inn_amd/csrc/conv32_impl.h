@@ -126,10 +126,12 @@ __global__ __launch_bounds__(256, 2) void conv32_kernel(ConvDev p) {
 
   int chunk = 0, tap = 0;
   for (int it = 0; it < nit; ++it) {
+    if (!(p.ablate & 1)) {
     if (it + 1 < nit) store_w(((it + 1) & 1) ? w_lds1 : w_lds0);
     if (it + 2 < nit) load_w(it + 2);
+    }
     const bool last_tap = (tap == TAPS - 1);
-    const bool next_in = last_tap && (chunk + 1 < nchunks);
+    const bool next_in = last_tap && (chunk + 1 < nchunks) && !(p.ablate & 1);
     if (next_in) load_in(chunk + 1);
 
     const float* Bw = (it & 1) ? w_lds1 : w_lds0;
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv32_kernel(ConvDev p) {
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       const int cur = ks & 1, nxt = cur ^ 1;
-      if (ks + 1 < KSTEPS) {
+      if (ks + 1 < KSTEPS && !(p.ablate & 4)) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) af[nxt][m] = *reinterpret_cast<const float2*>(A + a_base[m] + (ks + 1) * 4);
 #pragma unroll
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void conv32_kernel(ConvDev p) {
         for (int n = 0; n < NT; ++n)
           acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][m].y, bf[cur][n].y, acc[m][n], 0, 0, 0);
     }
-    __syncthreads();
+    if (!(p.ablate & 2)) __syncthreads();
     if (next_in) {
       store_in();
       __syncthreads();

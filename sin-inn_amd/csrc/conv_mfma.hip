@@ -10,7 +10,8 @@ int conv32_dispatch_k3(ConvDev& d, hipStream_t st, int force_cfg, bool must);
 int conv32_dispatch_k1(ConvDev& d, hipStream_t st, int force_cfg, bool must);
 
 static int g_force_cfg = 0;   // test hook: 0 auto, 1 force 8-row tiles, 2 force 4-row tiles
-static int g_force_ck = 0;    // test hook: override the channel chunk
+static int g_force_ck = 0;
+static int g_ablate = 0;     // diagnostic: see ConvDev::ablate (results are wrong when set)    // test hook: override the channel chunk
 
 int conv_launch(const sininn_conv_args* a, hipStream_t st) {
   SININN_CHECK(a != nullptr, "conv: null args");
@@ -57,6 +58,7 @@ int conv_launch(const sininn_conv_args* a, hipStream_t st) {
   d.mask = a->mask; d.mask_stride = a->mask_stride;
   d.addend = a->addend; d.addend_stride = a->addend_stride; d.addend_map = a->addend_map;
   d.mode = a->mode;
+  d.ablate = g_ablate;
   SININN_CHECK(a->mode >= 0 && a->mode <= SININN_CONV_LINEAR, "conv: unknown mode %d", a->mode);
   // channel chunk: the largest of 32/24/16/8 that divides Cin
   int ck = 8;
@@ -76,6 +78,6 @@ int conv_launch(const sininn_conv_args* a, hipStream_t st) {
   return conv_dispatch_k1(d, st, fc);
 }
 
-void conv_set_test_hooks(int force_cfg, int force_ck) { g_force_cfg = force_cfg; g_force_ck = force_ck; }
+void conv_set_test_hooks(int force_cfg, int force_ck) { g_force_cfg = force_cfg % 1000; g_force_ck = force_ck; g_ablate = force_cfg / 1000; }
 
 }  // namespace sininn
