@@ -205,12 +205,31 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         if (c0 + j < Cin) gw[((size_t)n * Cin + c0 + j) * taps + t] += tot[j];
     }
   }
-  if (gb != nullptr && blockIdx.x == 0) {
-    for (int i = threadIdx.x; i < N; i += 256) {
-      float b = 0.f;
-      for (int k = 0; k < S; ++k) b += bpartial[(size_t)k * Nr + i];
-      gb[i] += b;
+}
+
+// db[n] += sum_s bpartial[s][n]: same 4-way slab split / fixed-order combine, one block per 64 bias entries
+// (a serial loop over S dependent loads used to dominate the reduce kernel's run time)
+__global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __restrict__ bpartial, int S, int Nr, int N,
+                                                                float* __restrict__ gb) {
+  __shared__ float red[4][64];
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int grp = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < N) {
+    int k = grp;
+    for (; k + 12 < S; k += 16) {
+      s0 += bpartial[(size_t)k * Nr + i];
+      s1 += bpartial[(size_t)(k + 4) * Nr + i];
+      s2 += bpartial[(size_t)(k + 8) * Nr + i];
+      s3 += bpartial[(size_t)(k + 12) * Nr + i];
     }
+    for (; k < S; k += 4) s0 += bpartial[(size_t)k * Nr + i];
+  }
+  red[grp][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp == 0 && i < N) {
+    const int l = threadIdx.x;
+    gb[i] += (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
   }
 }
 
@@ -274,6 +293,10 @@ int wgrad_launch(const float* in, int in_stride, int Cin, const float* dout, int
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total4 + 63) / 64), dim3(256), 0, st,
                      d.partial, d.bpartial, pl.S, taps, pl.Nr, pl.Cc, N, Cin, gw, gb);
   SININN_LAUNCH_CHECK("wgrad_reduce");
+  if (gb != nullptr) {
+    hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((N + 63) / 64), dim3(256), 0, st, d.bpartial, pl.S, pl.Nr, N, gb);
+    SININN_LAUNCH_CHECK("wgrad_bias_reduce");
+  }
   return 0;
 }
 
