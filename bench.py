@@ -157,6 +157,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_issue = time.perf_counter() - t0      # host time to enqueue the steps (GPU still running)
     barrier()
     dt = time.perf_counter() - t0
     timer.enabled = False
@@ -167,7 +168,7 @@ def main():
 
     if rank != 0:
         return
-    print(f'[bench] timed region {dt:.3f}s for {args.steps} steps', file=sys.stderr, flush=True)
+    print(f'[bench] timed region {dt:.3f}s for {args.steps} steps (host enqueue time {t_issue:.3f}s)', file=sys.stderr, flush=True)
     ms_per_step = dt / args.steps * 1e3
     value = ws * b * args.steps / dt
     # roofline of the dominant kernel: algorithmic FLOPs (2 * pixels * 9*256 * 2*Co) per launch

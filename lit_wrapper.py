@@ -21,6 +21,16 @@ from archs import InvRescaleNet, UncondSRFlow
 from tcr import TCR
 
 
+_SECOND = {}
+
+
+def _second_stream(device):
+    key = str(device)
+    if key not in _SECOND:
+        _SECOND[key] = torch.cuda.Stream(device=device)
+    return _SECOND[key]
+
+
 def _latent(b, z_dims, h, w, device, temp=1.0):
     """z ~ N(0, temp^2), shape (b, z_dims, h, w), stored pixel-major (channels_last) like every other activation."""
     z = torch.randn(b, h, w, z_dims, device=device)
@@ -44,6 +54,7 @@ class SingleVideoINN(pl.LightningModule):
         logging.info(f'Created model with {n_params / 1e6:.2f}M parameters. Using GPUs {opt.gpu_ids}')
         self.tcr = TCR(opt.rotation, opt.translation)
         self.automatic_optimization = False        # several backward() calls per step
+        self.overlap_passes = True                 # forward / reverse pass on two HIP streams
 
     # ---- training --------------------------------------------------------------------------------
     def training_step(self, batch, batch_idx):
@@ -62,11 +73,21 @@ class SingleVideoINN(pl.LightningModule):
         fwd_loss = fwd_loss + o.lambda_latent_nll * loss.latent_nll(lr_z_hat[:, o.lr_dims:])
         self.manual_backward(fwd_loss)
 
-        # reverse pass: (LR | z) -> HR
-        hr_hat = self.inn(lr_z, rev=True)
-        bwd_loss = o.lambda_bwd_rec * loss.reconstruction(hr_hat, hr)
-        bwd_loss = bwd_loss + o.lambda_bwd_mmd * loss.mmd(hr_hat, hr, rev=True)
-        self.manual_backward(bwd_loss)
+        # reverse pass: (LR | z) -> HR.  It is independent of the forward pass until the optimizer step, so it is
+        # queued on a second HIP stream: kernels of the two passes interleave on the GPU and fill each other's
+        # prologue / epilogue / tail bubbles (weight-gradient accumulation stays ordered on its own stream).
+        main = torch.cuda.current_stream()
+        second = _second_stream(hr.device) if self.overlap_passes else main
+        second.wait_stream(main)
+        with torch.cuda.stream(second):
+            hr_hat = self.inn(lr_z, rev=True)
+            bwd_loss = o.lambda_bwd_rec * loss.reconstruction(hr_hat, hr)
+            bwd_loss = bwd_loss + o.lambda_bwd_mmd * loss.mmd(hr_hat, hr, rev=True)
+            self.manual_backward(bwd_loss)
+        if second is not main:
+            for t in (hr, lr_z):
+                t.record_stream(second)
+            main.wait_stream(second)
 
         tcr_loss = 0
         if o.lambda_bwd_tcr > 0:

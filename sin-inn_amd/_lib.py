@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsininn.so')
+LIB_PATH = os.environ.get('SININN_LIB', os.path.join(_HERE, 'libsininn.so'))   # override: A/B two builds on one box
 
 c_f = C.c_void_p      # device float*
 c_i = C.c_void_p      # device int*

@@ -49,6 +49,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvDev& p, const float
   constexpr int TS = BN + 4;
   constexpr int NPIX = TH * 16;
   const int MODE = p.mode;
+  if (p.ablate & 8) return;
   if (MODE == SININN_CONV_COUPLE_FWD || MODE == SININN_CONV_COUPLE_INV) {
     constexpr int CB = BN / 2;                       // channels of this block
     constexpr int Q = CB / 4;                        // channel quads per pixel

@@ -92,6 +92,42 @@ class _PackCache:
         return hit[1]
 
 
+# ------------------------------------------------------------------------------------------------
+# side stream for the weight-gradient kernels: wgrad(conv2) / wgrad(conv1) of a half-coupling only depend on
+# dr / dh, not on each other's results or on the data-gradient chain, so they run on a second HIP stream and fill
+# the prologue / epilogue / tail bubbles of the dgrad convs (and vice versa).  Joined before the optimiser step.
+# ------------------------------------------------------------------------------------------------
+_SIDE = {}
+USE_SIDE_STREAM = [True]
+
+
+def _side_stream(device):
+    key = str(device)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
+def join_side_streams():
+    """Make the current stream wait for all outstanding weight-gradient kernels (call before reading .grad)."""
+    for st in _SIDE.values():
+        torch.cuda.current_stream(st.device).wait_stream(st)
+
+
+def _wgrad_async(tensors, *args):
+    """ops.wgrad on the side stream, ordered after everything already queued on the current stream."""
+    if not USE_SIDE_STREAM[0]:
+        ops.wgrad(*args)
+        return
+    main = torch.cuda.current_stream()
+    side = _side_stream(tensors[0].device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        ops.wgrad(*args)
+    for t in tensors:                      # keep the caching allocator from recycling them under the side stream
+        t.record_stream(side)
+
+
 def _grad_buf(p):
     """The tensor parameter gradients are accumulated into (created on first use, like autograd would)."""
     if p.grad is None:
@@ -197,14 +233,14 @@ class _GlowFn(torch.autograd.Function):
             ops.coupling_bwd(dy_t, dy_off, dy_stride, dy_map, vy_t, vy_off, vy_stride, vy_map, sbuf, gld, b, hw, co,
                              block.clamp, inv, dr, dx, dv_off, c)
             if conv2.weight.requires_grad:
-                ops.wgrad(hbuf, 0, HIDDEN, HIDDEN, dr, 2 * co, 2 * co, b, h, w, k, _grad_buf(conv2.weight),
-                          _grad_buf(conv2.bias))
+                _wgrad_async((hbuf, dr), hbuf, 0, HIDDEN, HIDDEN, dr, 2 * co, 2 * co, b, h, w, k,
+                             _grad_buf(conv2.weight), _grad_buf(conv2.bias))
             dh = torch.empty((m, HIDDEN), device=dev, dtype=torch.float32)
             ops.conv(in_=_vp(dr), in_stride=2 * co, Cin=2 * co, w=_vp(wd2), Np=HIDDEN, B=b, H=h, W=w, ksize=k,
                      mode=CONV_MASK, out=_vp(dh), out_stride=HIDDEN, N=HIDDEN, mask=_vp(hbuf), mask_stride=HIDDEN)
             if conv1.weight.requires_grad:
-                ops.wgrad(cond_t, cond_off, cond_stride, cond_cin, dh, HIDDEN, HIDDEN, b, h, w, k,
-                          _grad_buf(conv1.weight), _grad_buf(conv1.bias))
+                _wgrad_async((cond_t, dh), cond_t, cond_off, cond_stride, cond_cin, dh, HIDDEN, HIDDEN, b, h, w, k,
+                             _grad_buf(conv1.weight), _grad_buf(conv1.bias))
             ops.conv(in_=_vp(dh), in_stride=HIDDEN, Cin=HIDDEN, w=_vp(wd1), Np=ops.pad16(cond_cin), B=b, H=h, W=w,
                      ksize=k, mode=CONV_ADD, out=_vp(dcond_t, dcond_off), out_stride=dcond_stride, N=cond_cin,
                      addend=_vp(add_t, add_off), addend_stride=add_stride, addend_map=add_map)

@@ -9,7 +9,7 @@ the sqrt); parity is tested against torch.optim.Adam itself.
 import torch
 
 from . import ops
-from .modules import bump_weights_epoch
+from .modules import bump_weights_epoch, join_side_streams
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -44,10 +44,12 @@ class FusedAdam(torch.optim.Optimizer):
 
     # the flat gradient buffer must survive zero_grad (views would be lost with set_to_none=True)
     def zero_grad(self, set_to_none=False):
+        join_side_streams()
         for fl in self._flat:
             fl['g'].zero_()
 
     def flat_grads(self):
+        join_side_streams()                 # weight-gradient kernels run on a side stream
         return [fl['g'] for fl in self._flat]
 
     def flat_params(self):
@@ -56,6 +58,7 @@ class FusedAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
         loss = closure() if closure is not None else None
+        join_side_streams()
         for group, fl in zip(self.param_groups, self._flat):
             lo, hi = fl['g'].data_ptr(), fl['g'].data_ptr() + fl['g'].numel() * 4
             for p in fl['params']:

@@ -61,6 +61,7 @@ def test_glow_block(ksize, rev, channels, hw):
     (yc * wgt).sum().add((ref.last_jac * ld_w).sum()).backward()
     ((yg * wgt.cuda()).sum() + (blk.last_jac * ld_w.cuda()).sum()).backward()
     assert relerr(xg.grad, xc.grad) < RTOL
+    S.modules.join_side_streams()
     for (n, pg), (_, pc) in zip(blk.named_parameters(), ref.named_parameters()):
         assert relerr(pg.grad, pc.grad) < 2e-4, n
     # round trip through the HIP kernels alone
@@ -87,6 +88,8 @@ def test_srflow_network_and_gradients(num_coupling):
     wgt = torch.randn_like(yc)
     (yc * wgt).sum().backward(); (yg * wgt.cuda()).sum().backward()
     assert relerr(xg.grad, xc.grad) < RTOL
+    import sin_inn_amd
+    sin_inn_amd.modules.join_side_streams()
     for (n, pg), (_, pc) in zip(net.named_parameters(), ref.named_parameters()):
         assert relerr(pg.grad, pc.grad) < 2e-4, n
     # reverse direction (input NCHW-contiguous, permutes folded into the producers)
@@ -97,6 +100,7 @@ def test_srflow_network_and_gradients(num_coupling):
     assert relerr(hg, hc) < RTOL
     (hc * hc).sum().backward(); (hg * hg).sum().backward()
     assert relerr(zg.grad, zc.grad) < RTOL
+    sin_inn_amd.modules.join_side_streams()
     for (n, pg), (_, pc) in zip(net.named_parameters(), ref.named_parameters()):
         assert relerr(pg.grad, pc.grad) < 2e-4, n
     with torch.no_grad():
