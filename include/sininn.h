@@ -112,6 +112,39 @@ int sininn_coupling_bwd(const float* dy, int dy_stride, const int* dy_map,
                         int inverse, float* dr, float* dv, int dv_stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * One GLOW coupling block per call (FrEIA GLOWCouplingBlock.forward / its autograd, SURVEY Appendix A;
+ * wired at archs.py:61-64): host-side launch sequence of the kernels above.
+ *   forward : (rev==0)  r2=s2(x2); y1=e(s2)*x1+t2; r1=s1(y1); y2=e(s1)*x2+t1      logdet += sum log_e
+ *             (rev==1)  r1=s1(x1); y2=(x2-t1)/e(s1); r2=s2(y2); y1=(x1-t2)/e(s2)  logdet -= sum log_e
+ *             out channel c is stored at dst_map[c] (folds the following / preceding PermuteRandom).
+ *   backward: dx, and (+=) the OIHW weight / bias gradients of the four convs; weight-gradient kernels are
+ *             queued on wgrad_stream (ordered after their inputs with events), everything else on stream.
+ * `saved` (sininn_glow_saved_floats floats) is written by forward and read by backward: hidden activations of
+ * both subnets, both s tensors, the first half's compact output.  `scratch` is backward-only.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sininn_subnet {
+  const float* w1; const float* b1;      /* conv1 packed [taps][256][Cin] + bias[256]                          */
+  const float* w2; const float* b2;      /* conv2 packed [taps][2*Co][256] (s|t interleaved), bias packed alike */
+  const float* w1_dgrad;                 /* [taps][pad16(Cin)][256]  (backward only)                           */
+  const float* w2_dgrad;                 /* [taps][256][2*Co]        (backward only)                           */
+  float* gw1; float* gb1; float* gw2; float* gb2;   /* OIHW gradient accumulators (NULL: skip)                 */
+} sininn_subnet;
+
+typedef struct sininn_glow_args {
+  int B, H, W, C, ksize, rev; float clamp;
+  const float* x; float* out; const int* dst_map; float* logdet;
+  sininn_subnet s1, s2;
+  float* saved;
+  void* scratch; size_t scratch_bytes;
+  const float* dout; const float* gld; float* dx;
+} sininn_glow_args;
+
+size_t sininn_glow_saved_floats(int B, int H, int W, int C);
+size_t sininn_glow_scratch_bytes(int B, int H, int W, int C, int ksize);
+int sininn_glow_forward(const sininn_glow_args* args, void* stream);
+int sininn_glow_backward(const sininn_glow_args* args, void* stream, void* wgrad_stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Index maps: FrEIA IRevNetDownsampling (archs.py:28-31,35-38) and PermuteRandom (archs.py:65-68),
  * plus NCHW<->NHWC import/export, as ONE strided gather:
  *   levels==0 : out[b,y,x,cm(c)] = in[b,c,y,x]

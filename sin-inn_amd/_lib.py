@@ -35,6 +35,22 @@ class ConvArgs(C.Structure):
     ]
 
 
+class SubnetArgs(C.Structure):
+    """Mirror of sininn_subnet."""
+    _fields_ = [('w1', c_f), ('b1', c_f), ('w2', c_f), ('b2', c_f), ('w1_dgrad', c_f), ('w2_dgrad', c_f),
+                ('gw1', c_f), ('gb1', c_f), ('gw2', c_f), ('gb2', c_f)]
+
+
+class GlowArgs(C.Structure):
+    """Mirror of sininn_glow_args."""
+    _fields_ = [('B', C.c_int), ('H', C.c_int), ('W', C.c_int), ('C', C.c_int), ('ksize', C.c_int), ('rev', C.c_int),
+                ('clamp', C.c_float),
+                ('x', c_f), ('out', c_f), ('dst_map', c_i), ('logdet', c_f),
+                ('s1', SubnetArgs), ('s2', SubnetArgs),
+                ('saved', c_f), ('scratch', C.c_void_p), ('scratch_bytes', C.c_size_t),
+                ('dout', c_f), ('gld', c_f), ('dx', c_f)]
+
+
 CONV_RELU, CONV_COUPLE_FWD, CONV_COUPLE_INV, CONV_MASK, CONV_ADD, CONV_LINEAR = range(6)
 
 _SIGS = {
@@ -49,6 +65,10 @@ _SIGS = {
                                c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]),
     'sininn_coupling_bwd': (C.c_int, [c_f, C.c_int, c_i, c_f, C.c_int, c_i, c_f, c_f, C.c_int, C.c_int, C.c_int,
                                       C.c_float, C.c_int, c_f, c_f, C.c_int, C.c_void_p]),
+    'sininn_glow_saved_floats': (C.c_size_t, [C.c_int] * 4),
+    'sininn_glow_scratch_bytes': (C.c_size_t, [C.c_int] * 5),
+    'sininn_glow_forward': (C.c_int, [C.POINTER(GlowArgs), C.c_void_p]),
+    'sininn_glow_backward': (C.c_int, [C.POINTER(GlowArgs), C.c_void_p, C.c_void_p]),
     'sininn_squeeze': (C.c_int, [c_f, I64x4, c_f, I64x4, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i,
                                  C.c_int, C.c_void_p]),
     'sininn_permute_channels': (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int64, C.c_int, c_i, C.c_void_p]),

@@ -53,6 +53,10 @@ int sample_windows_launch(const uint8_t* hr_clip, const uint8_t* lr_clip, const 
                           const int64_t ls[4], hipStream_t st);
 int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
                 float wd, int step, float gscale, hipStream_t st);
+size_t glow_saved_floats(int B, int H, int W, int C);
+size_t glow_scratch_bytes(int B, int H, int W, int C, int ksize);
+int glow_forward(const sininn_glow_args* a, hipStream_t st);
+int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst);
 }  // namespace sininn
 
 using namespace sininn;
@@ -95,6 +99,13 @@ int sininn_coupling_bwd(const float* dy, int dy_stride, const int* dy_map, const
                         int inverse, float* dr, float* dv, int dv_stride, void* stream) {
   return coupling_bwd_launch(dy, dy_stride, dy_map, vy, vy_stride, vy_map, s, gld, B, HW, Co, clamp, inverse, dr, dv,
                              dv_stride, ST(stream));
+}
+
+size_t sininn_glow_saved_floats(int B, int H, int W, int C) { return glow_saved_floats(B, H, W, C); }
+size_t sininn_glow_scratch_bytes(int B, int H, int W, int C, int ksize) { return glow_scratch_bytes(B, H, W, C, ksize); }
+int sininn_glow_forward(const sininn_glow_args* args, void* stream) { return glow_forward(args, ST(stream)); }
+int sininn_glow_backward(const sininn_glow_args* args, void* stream, void* wgrad_stream) {
+  return glow_backward(args, ST(stream), ST(wgrad_stream));
 }
 
 int sininn_squeeze(const float* in, const int64_t in_strides[4], float* out, const int64_t out_strides[4], int B, int C,

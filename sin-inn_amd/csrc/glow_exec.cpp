@@ -1,0 +1,225 @@
+// Host-side executor of one GLOW coupling block (forward / inverse and their backward): the launch sequence of
+// FrEIA's GLOWCouplingBlock (wired at archs.py:61-64) as ONE C-ABI call, so the Python layer
+// costs one ctypes call per block pass instead of one per kernel (the training step is ~450 launches; issued from
+// Python they made the host the bottleneck).  Weight-gradient kernels go to a second stream (they depend on dr / dh
+// only) so they overlap the data-gradient chain.
+#include <mutex>
+
+#include "common.h"
+
+namespace sininn {
+
+int conv_launch(const sininn_conv_args* a, hipStream_t st);
+size_t wgrad_workspace_bytes(int N, int Cin, int ksize, int B, int H, int W);
+int wgrad_launch(const float* in, int in_stride, int Cin, const float* dout, int dout_stride, int N, int B, int H, int W,
+                 int ksize, float* gw, float* gb, void* ws, size_t ws_bytes, hipStream_t st);
+int coupling_bwd_launch(const float* dy, int dy_stride, const int* dy_map, const float* vy, int vy_stride,
+                        const int* vy_map, const float* s, const float* gld, int B, int HW, int Co, float clamp,
+                        int inverse, float* dr, float* dv, int dv_stride, hipStream_t st);
+
+static inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }   // floats -> keeps 256-byte alignment
+static inline int pad16i(int n) { return (n + 15) / 16 * 16; }
+
+// ---- cross-stream ordering: a small ring of timing-less events ------------------------------------
+static std::mutex g_ev_mutex;
+static hipEvent_t g_events[64];
+static bool g_events_ready = false;
+static unsigned g_ev_next = 0;
+
+static int order_after(hipStream_t waiter, hipStream_t producer) {
+  if (waiter == producer) return 0;
+  hipEvent_t ev;
+  {
+    std::lock_guard<std::mutex> lock(g_ev_mutex);
+    if (!g_events_ready) {
+      for (auto& e : g_events)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { set_error("glow: cannot create events"); return 1; }
+      g_events_ready = true;
+    }
+    ev = g_events[g_ev_next++ % 64];
+  }
+  if (hipEventRecord(ev, producer) != hipSuccess || hipStreamWaitEvent(waiter, ev, 0) != hipSuccess) {
+    set_error("glow: stream ordering failed");
+    return 1;
+  }
+  return 0;
+}
+
+struct Half {                 // one half-coupling in execution order
+  const sininn_subnet* net;
+  int cond_off;               // offset of the conditioning channels in x (-1: the first half's compact output)
+  int base;                   // offset of the transformed channels v in x == output channel base
+  int co;                     // channels transformed
+};
+
+static void halves_of(const sininn_glow_args* a, Half h[2]) {
+  const int l1 = a->C / 2, l2 = a->C - l1;
+  if (!a->rev) { h[0] = Half{&a->s2, l1, 0, l1}; h[1] = Half{&a->s1, -1, l1, l2}; }
+  else { h[0] = Half{&a->s1, 0, l1, l2}; h[1] = Half{&a->s2, -1, 0, l1}; }
+}
+
+struct Saved { float *h_a, *h_b, *s_a, *s_b, *ybuf; size_t total; };
+static Saved saved_layout(float* base, size_t M, int co_a, int co_b) {
+  Saved s;
+  size_t o = 0;
+  s.h_a = base + o; o += align64(M * SININN_HIDDEN);
+  s.h_b = base + o; o += align64(M * SININN_HIDDEN);
+  s.s_a = base + o; o += align64(M * co_a);
+  s.s_b = base + o; o += align64(M * co_b);
+  s.ybuf = base + o; o += align64(M * co_a);
+  s.total = o;
+  return s;
+}
+
+size_t glow_saved_floats(int B, int H, int W, int C) {
+  const size_t M = (size_t)B * H * W;
+  const int big = C - C / 2;
+  return 2 * align64(M * SININN_HIDDEN) + 3 * align64(M * big) + 64;
+}
+
+struct Scratch { float *dr_b, *dh_b, *dy_first, *dr_a, *dh_a; void* ws; size_t ws_bytes; size_t total_bytes; };
+static Scratch scratch_layout(void* basep, int B, int H, int W, int C, int ksize, int co_a, int co_b) {
+  const size_t M = (size_t)B * H * W;
+  float* base = static_cast<float*>(basep);
+  Scratch s;
+  size_t o = 0;
+  s.dr_b = base + o; o += align64(M * 2 * co_b);
+  s.dh_b = base + o; o += align64(M * SININN_HIDDEN);
+  s.dy_first = base + o; o += align64(M * co_a);
+  s.dr_a = base + o; o += align64(M * 2 * co_a);
+  s.dh_a = base + o; o += align64(M * SININN_HIDDEN);
+  size_t w = 0;
+  const int cond_a = C - co_a;
+  const size_t cands[4] = {wgrad_workspace_bytes(2 * co_b, SININN_HIDDEN, ksize, B, H, W),
+                           wgrad_workspace_bytes(SININN_HIDDEN, co_a, ksize, B, H, W),
+                           wgrad_workspace_bytes(2 * co_a, SININN_HIDDEN, ksize, B, H, W),
+                           wgrad_workspace_bytes(SININN_HIDDEN, cond_a, ksize, B, H, W)};
+  for (size_t c : cands) w = c > w ? c : w;
+  s.ws = base + o;
+  s.ws_bytes = w;
+  s.total_bytes = o * sizeof(float) + w;
+  return s;
+}
+
+size_t glow_scratch_bytes(int B, int H, int W, int C, int ksize) {
+  const int big = C - C / 2;
+  // upper bound over both directions (co_a / co_b are C/2 and C - C/2 in some order)
+  Scratch s = scratch_layout(nullptr, B, H, W, C, ksize, big, big);
+  return s.total_bytes + 256;
+}
+
+static int check_common(const sininn_glow_args* a, const char* who) {
+  SININN_CHECK(a != nullptr, "%s: null args", who);
+  SININN_CHECK(a->B > 0 && a->H > 0 && a->W > 0 && a->C >= 16, "%s: bad shape", who);
+  SININN_CHECK((a->C / 2) % 8 == 0 && (a->C - a->C / 2) % 8 == 0, "%s: both channel halves must be multiples of 8 (C=%d)", who, a->C);
+  SININN_CHECK(a->ksize == 1 || a->ksize == 3, "%s: ksize %d", who, a->ksize);
+  SININN_CHECK(a->x && a->out && a->saved, "%s: null tensor", who);
+  SININN_CHECK(a->s1.w1 && a->s1.w2 && a->s2.w1 && a->s2.w2 && a->s1.b1 && a->s1.b2 && a->s2.b1 && a->s2.b2, "%s: missing packed weights", who);
+  return 0;
+}
+
+static int col_tile_of(int co) { return (co % 16 == 0) ? 32 : 16; }
+
+int glow_forward(const sininn_glow_args* a, hipStream_t st) {
+  if (int rc = check_common(a, "glow_forward")) return rc;
+  const size_t M = (size_t)a->B * a->H * a->W;
+  const int C = a->C;
+  Half hv[2];
+  halves_of(a, hv);
+  Saved sv = saved_layout(a->saved, M, hv[0].co, hv[1].co);
+  const int mode = a->rev ? SININN_CONV_COUPLE_INV : SININN_CONV_COUPLE_FWD;
+  for (int i = 0; i < 2; ++i) {
+    const Half& h = hv[i];
+    float* hbuf = i == 0 ? sv.h_a : sv.h_b;
+    float* sbuf = i == 0 ? sv.s_a : sv.s_b;
+    sininn_conv_args c1 = {};
+    if (i == 0) { c1.in = a->x + h.cond_off; c1.in_stride = C; c1.Cin = C - h.co; }
+    else { c1.in = sv.ybuf; c1.in_stride = hv[0].co; c1.Cin = hv[0].co; }
+    c1.w = h.net->w1; c1.bias = h.net->b1; c1.Np = SININN_HIDDEN;
+    c1.B = a->B; c1.H = a->H; c1.W = a->W; c1.ksize = a->ksize; c1.mode = SININN_CONV_RELU;
+    c1.out = hbuf; c1.out_stride = SININN_HIDDEN; c1.N = SININN_HIDDEN;
+    if (int rc = conv_launch(&c1, st)) return rc;
+    sininn_conv_args c2 = {};
+    c2.in = hbuf; c2.in_stride = SININN_HIDDEN; c2.Cin = SININN_HIDDEN;
+    c2.w = h.net->w2; c2.bias = h.net->b2; c2.Np = 2 * h.co;
+    c2.B = a->B; c2.H = a->H; c2.W = a->W; c2.ksize = a->ksize; c2.mode = mode;
+    if (a->dst_map) { c2.out = a->out; c2.out_map = a->dst_map + h.base; }
+    else { c2.out = a->out + h.base; c2.out_map = nullptr; }
+    c2.out_stride = C;
+    c2.v = a->x + h.base; c2.v_stride = C;
+    c2.out2 = (i == 0) ? sv.ybuf : nullptr; c2.out2_stride = h.co;
+    c2.sbuf = sbuf; c2.logdet = a->logdet; c2.Co = h.co; c2.clamp = a->clamp; c2.col_tile = col_tile_of(h.co);
+    if (int rc = conv_launch(&c2, st)) return rc;
+  }
+  return 0;
+}
+
+int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
+  if (int rc = check_common(a, "glow_backward")) return rc;
+  SININN_CHECK(a->dout && a->dx && a->scratch, "glow_backward: null tensor");
+  SININN_CHECK(a->s1.w1_dgrad && a->s1.w2_dgrad && a->s2.w1_dgrad && a->s2.w2_dgrad, "glow_backward: missing dgrad weights");
+  const size_t M = (size_t)a->B * a->H * a->W;
+  const int C = a->C, HW = a->H * a->W, B = a->B, H = a->H, W = a->W, k = a->ksize;
+  Half hv[2];
+  halves_of(a, hv);
+  const int co_a = hv[0].co, co_b = hv[1].co, base_a = hv[0].base, base_b = hv[1].base;
+  Saved sv = saved_layout(a->saved, M, co_a, co_b);
+  Scratch sc = scratch_layout(a->scratch, B, H, W, C, k, co_a, co_b);
+  SININN_CHECK(a->scratch_bytes >= sc.total_bytes, "glow_backward: scratch too small (%zu < %zu)", a->scratch_bytes, sc.total_bytes);
+  const int inv = a->rev ? 1 : 0;
+  const int* map_a = a->dst_map ? a->dst_map + base_a : nullptr;
+  const int* map_b = a->dst_map ? a->dst_map + base_b : nullptr;
+
+  auto half_bwd = [&](const Half& h, const float* hbuf, const float* sbuf, float* dr, float* dh,
+                      const float* dy, int dy_stride, const int* dy_map, const float* vy, int vy_stride, const int* vy_map,
+                      const float* cond, int cond_stride, int cond_cin,
+                      const float* addend, int add_stride, const int* add_map, float* dcond, int dcond_stride) -> int {
+    const sininn_subnet* net = h.net;
+    if (int rc = coupling_bwd_launch(dy, dy_stride, dy_map, vy, vy_stride, vy_map, sbuf, a->gld, B, HW, h.co, a->clamp, inv,
+                                     dr, a->dx + h.base, C, st)) return rc;
+    if (net->gw2) {
+      if (int rc = order_after(wst, st)) return rc;
+      if (int rc = wgrad_launch(hbuf, SININN_HIDDEN, SININN_HIDDEN, dr, 2 * h.co, 2 * h.co, B, H, W, k, net->gw2, net->gb2,
+                                sc.ws, sc.ws_bytes, wst)) return rc;
+    }
+    sininn_conv_args d2 = {};
+    d2.in = dr; d2.in_stride = 2 * h.co; d2.Cin = 2 * h.co; d2.w = net->w2_dgrad; d2.Np = SININN_HIDDEN;
+    d2.B = B; d2.H = H; d2.W = W; d2.ksize = k; d2.mode = SININN_CONV_MASK;
+    d2.out = dh; d2.out_stride = SININN_HIDDEN; d2.N = SININN_HIDDEN; d2.mask = hbuf; d2.mask_stride = SININN_HIDDEN;
+    if (int rc = conv_launch(&d2, st)) return rc;
+    if (net->gw1) {
+      if (int rc = order_after(wst, st)) return rc;
+      if (int rc = wgrad_launch(cond, cond_stride, cond_cin, dh, SININN_HIDDEN, SININN_HIDDEN, B, H, W, k, net->gw1, net->gb1,
+                                sc.ws, sc.ws_bytes, wst)) return rc;
+    }
+    sininn_conv_args d1 = {};
+    d1.in = dh; d1.in_stride = SININN_HIDDEN; d1.Cin = SININN_HIDDEN; d1.w = net->w1_dgrad; d1.Np = pad16i(cond_cin);
+    d1.B = B; d1.H = H; d1.W = W; d1.ksize = k; d1.mode = SININN_CONV_ADD;
+    d1.out = dcond; d1.out_stride = dcond_stride; d1.N = cond_cin;
+    d1.addend = addend; d1.addend_stride = add_stride; d1.addend_map = add_map;
+    return conv_launch(&d1, st);
+  };
+
+  // ---- second half first: its condition is the first half's compact output -------------------------
+  {
+    const float* dy = a->dst_map ? a->dout : a->dout + base_b;
+    const float* vy; int vy_stride; const int* vy_map = nullptr;
+    if (!a->rev) { vy = a->x + base_b; vy_stride = C; }
+    else if (a->dst_map) { vy = a->out; vy_stride = C; vy_map = map_b; }
+    else { vy = a->out + base_b; vy_stride = C; }
+    const float* addend = a->dst_map ? a->dout : a->dout + base_a;
+    if (int rc = half_bwd(hv[1], sv.h_b, sv.s_b, sc.dr_b, sc.dh_b, dy, C, map_b, vy, vy_stride, vy_map,
+                          sv.ybuf, co_a, co_a, addend, C, map_a, sc.dy_first, co_a)) return rc;
+  }
+  // ---- first half: condition = x[:, cond range]; its data gradient accumulates in place into dx ----
+  {
+    const int cond_off = hv[0].cond_off, cond_cin = C - co_a;
+    const float* vy = a->rev ? sv.ybuf : a->x + base_a;
+    const int vy_stride = a->rev ? co_a : C;
+    if (int rc = half_bwd(hv[0], sv.h_a, sv.s_a, sc.dr_a, sc.dh_a, sc.dy_first, co_a, nullptr, vy, vy_stride, nullptr,
+                          a->x + cond_off, C, cond_cin, a->dx + cond_off, C, nullptr, a->dx + cond_off, C)) return rc;
+  }
+  return 0;
+}
+
+}  // namespace sininn

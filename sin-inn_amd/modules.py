@@ -12,8 +12,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import ops
-from ._lib import CONV_ADD, CONV_COUPLE_FWD, CONV_COUPLE_INV, CONV_MASK, CONV_RELU
+from . import _lib, ops
+from ._lib import GlowArgs, SubnetArgs
 
 HIDDEN = ops.HIDDEN
 
@@ -114,20 +114,6 @@ def join_side_streams():
         torch.cuda.current_stream(st.device).wait_stream(st)
 
 
-def _wgrad_async(tensors, *args):
-    """ops.wgrad on the side stream, ordered after everything already queued on the current stream."""
-    if not USE_SIDE_STREAM[0]:
-        ops.wgrad(*args)
-        return
-    main = torch.cuda.current_stream()
-    side = _side_stream(tensors[0].device)
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        ops.wgrad(*args)
-    for t in tensors:                      # keep the caching allocator from recycling them under the side stream
-        t.record_stream(side)
-
-
 def _grad_buf(p):
     """The tensor parameter gradients are accumulated into (created on first use, like autograd would)."""
     if p.grad is None:
@@ -139,131 +125,79 @@ def _grad_buf(p):
 # ------------------------------------------------------------------------------------------------
 # GLOW coupling block: fused conv-subnet + affine + log-det
 # ------------------------------------------------------------------------------------------------
+def _pv(t, off=0):
+    return None if t is None else t.data_ptr() + 4 * off
+
+
+def _subnet_args(block, seq, co, dev, need_grad, with_grads):
+    conv1, conv2, _ = inspect_subnet(seq)
+    cmap = ops.coupling_colmap(co, dev)
+    w1, b1, wd1 = block._packs.get(conv1, None, need_grad)
+    w2, b2, wd2 = block._packs.get(conv2, cmap, need_grad)
+    a = SubnetArgs(w1=_pv(w1), b1=_pv(b1), w2=_pv(w2), b2=_pv(b2), w1_dgrad=_pv(wd1), w2_dgrad=_pv(wd2))
+    if with_grads:
+        if conv1.weight.requires_grad:
+            a.gw1, a.gb1 = _pv(_grad_buf(conv1.weight)), _pv(_grad_buf(conv1.bias))
+        if conv2.weight.requires_grad:
+            a.gw2, a.gb2 = _pv(_grad_buf(conv2.weight)), _pv(_grad_buf(conv2.bias))
+    return a, (w1, b1, wd1, w2, b2, wd2)
+
+
 class _GlowFn(torch.autograd.Function):
-    """x (B,H,W,C) pixel-major -> (out (B,H,W,C) with channel c stored at dst[c], logdet (B,))."""
+    """x (B,H,W,C) pixel-major -> (out (B,H,W,C) with channel c stored at dst[c], logdet (B,)).
+    One C-ABI call per pass (sininn_glow_forward / sininn_glow_backward)."""
 
     @staticmethod
     def forward(ctx, x, block, rev, dst, *params):
         x = x.detach()
-        assert x.is_contiguous() and x.dim() == 4
+        assert x.is_contiguous() and x.dim() == 4 and x.dtype == torch.float32
+        if not x.is_cuda:
+            raise NotImplementedError('sin-inn_amd ops run on the GPU only (got a CPU tensor)')
         b, h, w, c = x.shape
-        l1, l2 = block.split_len1, block.split_len2
-        m = b * h * w
         dev = x.device
-        need_grad = any(ctx.needs_input_grad)      # False under torch.no_grad(): nothing is saved then
-        k = block.ksize
+        lib = _lib.lib()
+        need_grad = any(ctx.needs_input_grad)      # False under torch.no_grad(): nothing is kept then
         out = torch.empty_like(x)
         logdet = torch.zeros(b, device=dev, dtype=torch.float32)
-        mode = CONV_COUPLE_INV if rev else CONV_COUPLE_FWD
-        # halves in execution order: (subnet, offset of the conditioning channels in x (None -> the first
-        # half's compact output), offset of the transformed channels v in x == output base, Co)
-        if not rev:
-            halves = [(block.s2, l1, 0, l1), (block.s1, None, l1, l2)]
-        else:
-            halves = [(block.s1, 0, l1, l2), (block.s2, None, 0, l1)]
-        saved = {}
-        ybuf = None
-        for i, (seq, cond_off, vbase, co) in enumerate(halves):
-            conv1, conv2, _ = inspect_subnet(seq)
-            cmap = ops.coupling_colmap(co, dev)
-            w1, b1, _ = block._packs.get(conv1, None, need_grad)
-            w2, b2, _ = block._packs.get(conv2, cmap, need_grad)
-            hbuf = torch.empty((m, HIDDEN), device=dev, dtype=torch.float32)
-            if i == 0:
-                cin = c - co
-                cond_t, cond_o, cond_s = x, cond_off, c
-            else:
-                cin = halves[0][3]
-                cond_t, cond_o, cond_s = ybuf, 0, cin
-            ops.conv(in_=_vp(cond_t, cond_o), in_stride=cond_s, Cin=cin, w=_vp(w1), bias=_vp(b1), Np=HIDDEN,
-                     B=b, H=h, W=w, ksize=k, mode=CONV_RELU, out=_vp(hbuf), out_stride=HIDDEN, N=HIDDEN)
-            sbuf = torch.empty((m, co), device=dev, dtype=torch.float32) if need_grad else None
-            y_compact = torch.empty((m, co), device=dev, dtype=torch.float32) if i == 0 else None
-            if dst is None:
-                o_ptr, o_map = _vp(out, vbase), None
-            else:
-                o_ptr, o_map = _vp(out), _vp(dst, vbase, torch.int32)
-            ops.conv(in_=_vp(hbuf), in_stride=HIDDEN, Cin=HIDDEN, w=_vp(w2), bias=_vp(b2), Np=2 * co,
-                     B=b, H=h, W=w, ksize=k, mode=mode, out=o_ptr, out_stride=c, out_map=o_map,
-                     v=_vp(x, vbase), v_stride=c, out2=_vp(y_compact), out2_stride=co, sbuf=_vp(sbuf),
-                     logdet=_vp(logdet), Co=co, clamp=block.clamp, col_tile=ops.coupling_tile(co))
-            if i == 0:
-                ybuf = y_compact
-            saved[i] = (hbuf, sbuf)
+        saved = torch.empty(lib.sininn_glow_saved_floats(b, h, w, c), device=dev, dtype=torch.float32)
+        s1, keep1 = _subnet_args(block, block.s1, block.split_len2, dev, need_grad, False)
+        s2, keep2 = _subnet_args(block, block.s2, block.split_len1, dev, need_grad, False)
+        a = GlowArgs(B=b, H=h, W=w, C=c, ksize=block.ksize, rev=1 if rev else 0, clamp=block.clamp, x=_pv(x),
+                     out=_pv(out), dst_map=_pv(dst), logdet=_pv(logdet), s1=s1, s2=s2, saved=_pv(saved))
+        _lib.check(lib.sininn_glow_forward(C.byref(a), ops._stream()))
         if need_grad:
             ctx.block, ctx.rev, ctx.dst = block, rev, dst
-            ctx.save_for_backward(x, out, ybuf, saved[0][0], saved[0][1], saved[1][0], saved[1][1])
+            ctx.save_for_backward(x, out, saved)
         ctx.set_materialize_grads(False)
         return out, logdet
 
     @staticmethod
     def backward(ctx, dout, gld):
         block, rev, dst = ctx.block, ctx.rev, ctx.dst
-        x, out, ybuf, h_a, s_a, h_b, s_b = ctx.saved_tensors
+        x, out, saved = ctx.saved_tensors
         b, h, w, c = x.shape
-        m, hw = b * h * w, h * w
         dev = x.device
-        l1, l2 = block.split_len1, block.split_len2
-        k = block.ksize
-        inv = 1 if rev else 0
+        lib = _lib.lib()
         if dout is None:
             dout = torch.zeros_like(x)
         dout = dout.contiguous()
         if gld is not None:
             gld = gld.contiguous()
         dx = torch.empty_like(x)
-        if not rev:
-            halves = [(block.s2, l1, 0, l1), (block.s1, None, l1, l2)]
-        else:
-            halves = [(block.s1, 0, l1, l2), (block.s2, None, 0, l1)]
-        co_a, co_b = halves[0][3], halves[1][3]
-        base_a, base_b = halves[0][2], halves[1][2]
-
-        def dmap(base):
-            return None if dst is None else _vp(dst, base, torch.int32)
-
-        def half_bwd(seq, hbuf, sbuf, co, dy_t, dy_off, dy_stride, dy_map, vy_t, vy_off, vy_stride, vy_map,
-                     dv_off, cond_t, cond_off, cond_stride, cond_cin, add_t, add_off, add_stride, add_map,
-                     dcond_t, dcond_off, dcond_stride):
-            conv1, conv2, _ = inspect_subnet(seq)
-            cmap = ops.coupling_colmap(co, dev)
-            _, _, wd1 = block._packs.get(conv1, None, True)
-            _, _, wd2 = block._packs.get(conv2, cmap, True)
-            dr = torch.empty((m, 2 * co), device=dev, dtype=torch.float32)
-            ops.coupling_bwd(dy_t, dy_off, dy_stride, dy_map, vy_t, vy_off, vy_stride, vy_map, sbuf, gld, b, hw, co,
-                             block.clamp, inv, dr, dx, dv_off, c)
-            if conv2.weight.requires_grad:
-                _wgrad_async((hbuf, dr), hbuf, 0, HIDDEN, HIDDEN, dr, 2 * co, 2 * co, b, h, w, k,
-                             _grad_buf(conv2.weight), _grad_buf(conv2.bias))
-            dh = torch.empty((m, HIDDEN), device=dev, dtype=torch.float32)
-            ops.conv(in_=_vp(dr), in_stride=2 * co, Cin=2 * co, w=_vp(wd2), Np=HIDDEN, B=b, H=h, W=w, ksize=k,
-                     mode=CONV_MASK, out=_vp(dh), out_stride=HIDDEN, N=HIDDEN, mask=_vp(hbuf), mask_stride=HIDDEN)
-            if conv1.weight.requires_grad:
-                _wgrad_async((cond_t, dh), cond_t, cond_off, cond_stride, cond_cin, dh, HIDDEN, HIDDEN, b, h, w, k,
-                             _grad_buf(conv1.weight), _grad_buf(conv1.bias))
-            ops.conv(in_=_vp(dh), in_stride=HIDDEN, Cin=HIDDEN, w=_vp(wd1), Np=ops.pad16(cond_cin), B=b, H=h, W=w,
-                     ksize=k, mode=CONV_ADD, out=_vp(dcond_t, dcond_off), out_stride=dcond_stride, N=cond_cin,
-                     addend=_vp(add_t, add_off), addend_stride=add_stride, addend_map=add_map)
-
-        # ---- second half first: its condition is the first half's output (compact ybuf) ----------
-        dy_first = torch.empty((m, co_a), device=dev, dtype=torch.float32)
-        if not rev:
-            vy = (x, base_b, c, None)                 # v = untouched input half
-        else:
-            vy = (out, 0, c, dmap(base_b)) if dst is not None else (out, base_b, c, None)   # y of this half
-        if dst is None:
-            dy_b = (dout, base_b, c, None)
-            add_a = (dout, base_a, c, None)
-        else:
-            dy_b = (dout, 0, c, dmap(base_b))
-            add_a = (dout, 0, c, dmap(base_a))
-        half_bwd(halves[1][0], h_b, s_b, co_b, *dy_b, *vy, base_b, ybuf, 0, co_a, co_a, *add_a, dy_first, 0, co_a)
-        # ---- first half: condition = x[:, cond range]; its dgrad accumulates in place into dx ------
-        cond_off = halves[0][1]
-        cond_cin = c - co_a
-        vy = (x, base_a, c, None) if not rev else (ybuf, 0, co_a, None)
-        half_bwd(halves[0][0], h_a, s_a, co_a, dy_first, 0, co_a, None, *vy, base_a, x, cond_off, c, cond_cin,
-                 dx, cond_off, c, None, dx, cond_off, c)
+        nbytes = lib.sininn_glow_scratch_bytes(b, h, w, c, block.ksize)
+        scratch = torch.empty((nbytes + 3) // 4, device=dev, dtype=torch.float32)
+        s1, keep1 = _subnet_args(block, block.s1, block.split_len2, dev, True, True)
+        s2, keep2 = _subnet_args(block, block.s2, block.split_len1, dev, True, True)
+        a = GlowArgs(B=b, H=h, W=w, C=c, ksize=block.ksize, rev=1 if rev else 0, clamp=block.clamp, x=_pv(x),
+                     out=_pv(out), dst_map=_pv(dst), s1=s1, s2=s2, saved=_pv(saved), scratch=_pv(scratch),
+                     scratch_bytes=nbytes, dout=_pv(dout), gld=_pv(gld), dx=_pv(dx))
+        main = torch.cuda.current_stream()
+        side = _side_stream(dev) if USE_SIDE_STREAM[0] else main
+        _lib.check(lib.sininn_glow_backward(C.byref(a), C.c_void_p(main.cuda_stream), C.c_void_p(side.cuda_stream)))
+        if side is not main:                # the weight-gradient kernels on the side stream still read these
+            for t in (scratch, saved, x) + keep1 + keep2:
+                if t is not None:
+                    t.record_stream(side)
         return (dx, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
 
 
