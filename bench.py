@@ -175,10 +175,14 @@ def main():
     kms = timer.mean_ms()
     flops = 2.0 * m0 * 9 * 256 * (2 * co0)
     roof = None
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'traffic_dominant.json')   # PMC pass is a separate rocprofv3 run (committed)
+    if os.path.isfile(tpath):
+        traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
     if kms:
         ach = flops / (kms * 1e-3) / 1e12
         roof = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
                 'kernel': 'conv_mfma_kernel<3,8,4,1,2,3> (3x3 coupling conv 256->48, level 0)',
                 'launches_timed': len(timer.events), 'avg_ms': kms, 'alg_flops_per_launch': flops,
                 'alg_bytes_per_launch': 4.0 * (m0 * 256 + m0 * 3 * co0 + 9 * 256 * 2 * co0)}
