@@ -60,6 +60,7 @@ _SIGS = {
     'sininn_coupling_colmap': (None, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
     'sininn_conv': (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     'sininn_conv_test_hooks': (None, [C.c_int, C.c_int]),
+    'sininn_wgrad_test_hooks': (None, [C.c_int]),
     'sininn_wgrad_workspace_bytes': (C.c_size_t, [C.c_int] * 6),
     'sininn_wgrad': (C.c_int, [c_f, C.c_int, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -16,6 +16,7 @@ void set_error(const char* fmt, ...) {
 
 int conv_launch(const sininn_conv_args* a, hipStream_t st);
 void conv_set_test_hooks(int force_cfg, int force_ck);
+void wgrad_set_force16(int on);
 size_t wgrad_workspace_bytes(int N, int Cin, int ksize, int B, int H, int W);
 int wgrad_launch(const float* in, int in_stride, int Cin, const float* dout, int dout_stride, int N, int B, int H, int W,
                  int ksize, float* gw, float* gb, void* ws, size_t ws_bytes, hipStream_t st);
@@ -84,6 +85,7 @@ int sininn_conv(const sininn_conv_args* args, void* stream) { return conv_launch
 
 /* test hook (not part of the documented surface): force tile configuration / channel chunk */
 void sininn_conv_test_hooks(int force_cfg, int force_ck) { conv_set_test_hooks(force_cfg, force_ck); }
+void sininn_wgrad_test_hooks(int force16) { wgrad_set_force16(force16); }
 
 size_t sininn_wgrad_workspace_bytes(int N, int Cin, int ksize, int B, int H, int W) {
   return wgrad_workspace_bytes(N, Cin, ksize, B, H, W);

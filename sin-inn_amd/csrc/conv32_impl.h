@@ -229,6 +229,9 @@ static int dispatch32(ConvDev& d, hipStream_t st, int force_cfg, bool must) {
   const int nt32 = d.Np / 32;
   const long tiles8 = (long)d.B * ((d.H + 7) / 8) * ((d.W + 15) / 16);
   auto set_tiles = [&](int th) { d.tiles_x = (d.W + 15) / 16; d.tiles_y = (d.H + th - 1) / th; };
+  if (force_cfg == 5) { set_tiles(8); return launch32<KS, 8, 4, 1, 1, 1>(d, st); }
+  if (nt32 % 2 == 0 && force_cfg == 6) { set_tiles(4); return launch32<KS, 4, 2, 2, 1, 1>(d, st); }
+  if (KS == 3 && nt32 % 2 == 0 && force_cfg == 4) { d.tiles_x = (d.W + 15) / 16; d.tiles_y = (d.H + 15) / 16; return launch32<KS, 16, 4, 1, 2, 2>(d, st); }
   if ((KS == 1 && nt32 % 2 == 0 && force_cfg == 0) || (nt32 % 8 == 0 && force_cfg == 0)) {
     // narrow column blocks (64): ~35-42 KB of LDS -> 3-4 blocks per CU and several rounds of blocks per launch, so
     // the load / MFMA / store phases of different blocks overlap (1x1: one K iteration per block, latency / HBM
@@ -243,6 +246,10 @@ static int dispatch32(ConvDev& d, hipStream_t st, int force_cfg, bool must) {
     set_tiles(4); return launch32<KS, 4, 2, 2, 1, 2>(d, st);
   }
   if (nt32 % 3 == 0) {
+    // small images (level-1 tensors): 32-column blocks when that gives >= 3 balanced blocks per CU (+11 % measured)
+    if (force_cfg == 0 && tiles8 * (nt32 / 3) < 512 && tiles8 * nt32 >= 768 && (tiles8 * nt32) % 256 == 0) {
+      set_tiles(8); return launch32<KS, 8, 4, 1, 1, 1>(d, st);
+    }
     if (!must && force_cfg == 0 && tiles8 * (nt32 / 3) < 256) return -1;
     set_tiles(8); return launch32<KS, 8, 4, 1, 1, 3>(d, st);
   }

@@ -48,28 +48,44 @@ int pack_launch(const float* w, const float* bias, int N, int Cin, int ksize, co
 // ------------------------------------------------------------------------------------------------
 // coupling backward tail
 // ------------------------------------------------------------------------------------------------
+// 4 channels per thread: s / dr / dv (and dy / vy when they are not gathered through a channel map) move as float4
 __global__ void coupling_bwd_kernel(const float* __restrict__ dy, int dy_stride, const int* __restrict__ dy_map,
                                     const float* __restrict__ vy, int vy_stride, const int* __restrict__ vy_map,
-                                    const float* __restrict__ s, const float* __restrict__ gld, int64_t total,
+                                    const float* __restrict__ s, const float* __restrict__ gld, int64_t total4,
                                     int HW, int Co, float clamp, int inverse, float* __restrict__ dr,
                                     float* __restrict__ dv, int dv_stride) {
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+  const int q = Co >> 2;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4;
        idx += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(idx % Co);
-    const int64_t pix = idx / Co;
-    const float g = dy[pix * dy_stride + (dy_map ? dy_map[c] : c)];
-    const float u = vy[pix * vy_stride + (vy_map ? vy_map[c] : c)];
-    const float sv = s[idx];
-    const float L = glow_log_e(sv, clamp);
-    const float dL = glow_dlog_e(sv, clamp);
+    const int c = (int)(idx % q) * 4;
+    const int64_t pix = idx / q;
+    f32x4 g, u;
+    if (dy_map) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] = dy[pix * dy_stride + dy_map[c + j]];
+    } else {
+      g = *reinterpret_cast<const f32x4*>(dy + pix * dy_stride + c);
+    }
+    if (vy_map) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) u[j] = vy[pix * vy_stride + vy_map[c + j]];
+    } else {
+      u = *reinterpret_cast<const f32x4*>(vy + pix * vy_stride + c);
+    }
+    const f32x4 sv = *reinterpret_cast<const f32x4*>(s + pix * Co + c);
     const float gl = gld ? gld[pix / HW] : 0.f;
-    const float e = expf(L);
-    float ds, dt, dvv;
-    if (!inverse) { dvv = g * e; dt = g; ds = (g * u * e + gl) * dL; }
-    else { dvv = g / e; dt = -dvv; ds = -(g * u + gl) * dL; }
-    dr[pix * (2 * Co) + c] = ds;
-    dr[pix * (2 * Co) + Co + c] = dt;
-    dv[pix * dv_stride + c] = dvv;
+    f32x4 ds, dt, dvv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float L = glow_log_e(sv[j], clamp);
+      const float dL = glow_dlog_e(sv[j], clamp);
+      const float e = expf(L);
+      if (!inverse) { dvv[j] = g[j] * e; dt[j] = g[j]; ds[j] = (g[j] * u[j] * e + gl) * dL; }
+      else { dvv[j] = g[j] / e; dt[j] = -dvv[j]; ds[j] = -(g[j] * u[j] + gl) * dL; }
+    }
+    *reinterpret_cast<f32x4*>(dr + pix * (2 * Co) + c) = ds;
+    *reinterpret_cast<f32x4*>(dr + pix * (2 * Co) + Co + c) = dt;
+    *reinterpret_cast<f32x4*>(dv + pix * dv_stride + c) = dvv;
   }
 }
 
@@ -79,7 +95,10 @@ int coupling_bwd_launch(const float* dy, int dy_stride, const int* dy_map, const
   SININN_CHECK(dy && vy && s && dr && dv, "coupling_bwd: null pointer");
   SININN_CHECK(B > 0 && HW > 0 && Co > 0 && clamp > 0.f, "coupling_bwd: bad shape");
   SININN_CHECK(dy_stride >= Co && vy_stride >= Co && dv_stride >= Co, "coupling_bwd: stride < Co");
-  const int64_t total = (int64_t)B * HW * Co;
+  SININN_CHECK(Co % 4 == 0 && dv_stride % 4 == 0 && aligned16(s) && aligned16(dr) && aligned16(dv), "coupling_bwd: Co %% 4 and 16-byte alignment required");
+  SININN_CHECK(dy_map || (dy_stride % 4 == 0 && aligned16(dy)), "coupling_bwd: dy must be 16-byte aligned");
+  SININN_CHECK(vy_map || (vy_stride % 4 == 0 && aligned16(vy)), "coupling_bwd: vy must be 16-byte aligned");
+  const int64_t total = (int64_t)B * HW * (Co / 4);
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(coupling_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, dy_stride, dy_map, vy, vy_stride,
                      vy_map, s, gld, total, HW, Co, clamp, inverse, dr, dv, dv_stride);

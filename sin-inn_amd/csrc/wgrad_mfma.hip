@@ -168,6 +168,144 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradDev p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// 32x32x2 variant (v_mfma_f32_32x32x2_f32 sustains ~155 TFLOP/s, the 16x16x4 shape ~125) for N % 32 == 0.
+// A block owns ONE 32(n) x 32(c) x all-taps output tile and the four waves split the PIXELS of every staged 8x16
+// pixel tile (wave w takes image rows 2w, 2w+1), so the number of distinct output tiles is large, the split-K
+// factor S small and the slab traffic about half of the 16x16x4 kernel's; the four per-wave accumulators are
+// summed through LDS in a fixed order before the slab is written.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void wgrad32_kernel(WgradDev p) {
+  constexpr int HALO = KS / 2;
+  constexpr int IW = 16 + 2 * HALO;
+  constexpr int IH = WG_TH + 2 * HALO;
+  constexpr int NPIX_IN = IH * IW;
+  constexpr int NPIX = WG_TH * 16;
+  constexpr int TAPS = KS * KS;
+  constexpr int SP = 36;                               // LDS row stride (floats)
+  constexpr int D_F4 = (NPIX * 8 + 255) / 256;         // 32 columns = 8 float4 per pixel
+  constexpr int I_F4 = (NPIX_IN * 8 + 255) / 256;
+  constexpr int STAGE = (NPIX + NPIX_IN) * SP;
+  constexpr int REDF = 4 * 16 * 64;                    // one tap of all four waves
+  __shared__ __attribute__((aligned(16))) float lds[STAGE > REDF ? STAGE : REDF];
+  float* const d_lds = lds;
+  float* const i_lds = lds + NPIX * SP;
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, kh = lane >> 5;
+  const int split = blockIdx.x;
+  const int n0 = blockIdx.y * 32, c0 = blockIdx.z * 32;
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+  float bsum = 0.f;
+
+  const int t_begin = split * p.tiles_per_split;
+  const int t_end = min(t_begin + p.tiles_per_split, p.ntiles);
+
+  f32x4 d_reg[D_F4], i_reg[I_F4];
+  auto load_tile = [&](int tile) {
+    int tt = tile;
+    const int tx = tt % p.tiles_x; tt /= p.tiles_x;
+    const int ty = tt % p.tiles_y;
+    const int b = tt / p.tiles_y;
+    const int y0 = ty * WG_TH, x0 = tx * 16;
+#pragma unroll
+    for (int r = 0; r < D_F4; ++r) {
+      const int f = tid + 256 * r;
+      const int pix = f >> 3, n4 = f & 7;
+      const int gy = y0 + (pix >> 4), gx = x0 + (pix & 15);
+      const int n = n0 + n4 * 4;
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (pix < NPIX && gy < p.H && gx < p.W && n < p.N)
+        val = *reinterpret_cast<const f32x4*>(p.dout + ((size_t)(b * p.H + gy) * p.W + gx) * p.dout_stride + n);
+      d_reg[r] = val;
+    }
+#pragma unroll
+    for (int r = 0; r < I_F4; ++r) {
+      const int f = tid + 256 * r;
+      const int pix = f >> 3, c4 = f & 7;
+      const int py = pix / IW, px = pix - py * IW;
+      const int gy = y0 + py - HALO, gx = x0 + px - HALO;
+      const int c = c0 + c4 * 4;
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (pix < NPIX_IN && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && c < p.Cin)
+        val = *reinterpret_cast<const f32x4*>(p.in + ((size_t)(b * p.H + gy) * p.W + gx) * p.in_stride + c);
+      i_reg[r] = val;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int r = 0; r < D_F4; ++r) {
+      const int f = tid + 256 * r;
+      const int pix = f >> 3, n4 = f & 7;
+      if (pix < NPIX) *reinterpret_cast<f32x4*>(d_lds + pix * SP + n4 * 4) = d_reg[r];
+    }
+#pragma unroll
+    for (int r = 0; r < I_F4; ++r) {
+      const int f = tid + 256 * r;
+      const int pix = f >> 3, c4 = f & 7;
+      if (pix < NPIX_IN) *reinterpret_cast<f32x4*>(i_lds + pix * SP + c4 * 4) = i_reg[r];
+    }
+  };
+
+  if (t_begin < t_end) load_tile(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+    if (tile + 1 < t_end) load_tile(tile + 1);
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ++ks) {
+      const int prow = 2 * wave + (ks >> 3), pcol = (ks & 7) * 2 + kh;   // this lane's pixel of the k-step
+      const float a = d_lds[(prow * 16 + pcol) * SP + li];
+      bsum += a;
+      const float* irow = i_lds + (prow * IW + pcol) * SP + li;
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        const int dy = t / KS, dx = t % KS;
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, irow[(dy * IW + dx) * SP], acc[t], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- in-block reduction over the four waves (fixed order), one tap at a time, then the slab write ----
+  // lane holds D[row n = (q&3) + 8*(q>>2) + 4*kh][col c = li] in register q
+  __syncthreads();
+#pragma unroll                       // must stay fully unrolled: a runtime index would push acc[] to scratch
+  for (int t = 0; t < TAPS; ++t) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) lds[(wave * 16 + q) * 64 + lane] = acc[t][q];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = wave * 4 + j;                       // this wave finishes registers 4w .. 4w+3
+      const float v = (lds[(0 * 16 + q) * 64 + lane] + lds[(1 * 16 + q) * 64 + lane]) +
+                      (lds[(2 * 16 + q) * 64 + lane] + lds[(3 * 16 + q) * 64 + lane]);
+      const int n = n0 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+      const int c = c0 + li;
+      if (n < p.Nr && c < p.Cc) p.partial[(((size_t)split * TAPS + t) * p.Nr + n) * p.Cc + c] = v;
+    }
+    __syncthreads();
+  }
+  // bias partial: lane (li, kh) holds the sum over its pixels of dout[.][n0 + li]
+  bsum += __shfl_xor(bsum, 32);
+  if (lane < 32) lds[wave * 32 + lane] = bsum;
+  __syncthreads();
+  if (blockIdx.z == 0 && tid < 32) {
+    const int n = n0 + tid;
+    if (n < p.Nr) p.bpartial[(size_t)split * p.Nr + n] = (lds[tid] + lds[32 + tid]) + (lds[64 + tid] + lds[96 + tid]);
+  }
+}
+
 // Reduce S slabs in a fixed order and accumulate into the OIHW gradient:  gw[n][c][tap] += sum_s partial[s][tap][n][c]
 // A thread owns 4 consecutive c of one (tap, n) row (16-byte loads); the S slabs are split over the block's 4 waves,
 // 4 loads in flight each; the 4 partial sums are combined through LDS in a fixed order -> bitwise reproducible.
@@ -233,13 +371,18 @@ __global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __r
   }
 }
 
-struct WgradPlan { int RT, CT, Nr, Cc, nblk, cblk, S, tiles_per_split, ntiles, tiles_x, tiles_y; size_t bytes; };
+struct WgradPlan { int RT, CT, Nr, Cc, nblk, cblk, S, tiles_per_split, ntiles, tiles_x, tiles_y; size_t bytes; bool use32; };
+
+static bool g_wgrad_force16 = false;   // test hook
+void wgrad_set_force16(int on) { g_wgrad_force16 = on != 0; }
 
 static WgradPlan make_plan(int N, int Cin, int ksize, int B, int H, int W) {
   WgradPlan pl;
+  pl.use32 = (N % 32 == 0) && !g_wgrad_force16;
   // row tiles: 3 when N is a multiple of 48 but not of 64 (N=48), else 4; col tiles 4 with RT=3, else 2 or 4
   if (N % 64 != 0 && N % 48 == 0) { pl.RT = 3; pl.CT = 4; }
   else { pl.RT = 4; pl.CT = (Cin >= 64 && ksize == 1) ? 4 : 2; }
+  if (pl.use32) { pl.RT = 2; pl.CT = 2; }              // 32 x 32 output tile per block
   const int bnw = pl.RT * 16, bcw = pl.CT * 16;
   pl.nblk = (N + bnw - 1) / bnw;
   pl.cblk = (Cin + bcw - 1) / bcw;
@@ -248,7 +391,9 @@ static WgradPlan make_plan(int N, int Cin, int ksize, int B, int H, int W) {
   pl.tiles_x = (W + 15) / 16;
   pl.tiles_y = (H + WG_TH - 1) / WG_TH;
   pl.ntiles = B * pl.tiles_x * pl.tiles_y;
-  int S = 512 / (pl.nblk * pl.cblk);
+  // the RT=3 tile (N=48) needs ~90 KB of LDS and >256 registers: one block per CU -> aim for one round of 256
+  // blocks (half the slab traffic of 512); the other tiles run two blocks per CU
+  int S = (pl.RT == 3 ? 256 : 512) / (pl.nblk * pl.cblk);
   if (S < 1) S = 1;
   if (S > pl.ntiles) S = pl.ntiles;
   pl.tiles_per_split = (pl.ntiles + S - 1) / S;
@@ -265,7 +410,8 @@ size_t wgrad_workspace_bytes(int N, int Cin, int ksize, int B, int H, int W) {
 template <int KS>
 static void launch_wgrad(const WgradPlan& pl, const WgradDev& d, hipStream_t st) {
   dim3 grid(pl.S, pl.nblk, pl.cblk);
-  if (pl.RT == 3) hipLaunchKernelGGL((wgrad_mfma_kernel<KS, 3, 4, 3, 1>), grid, dim3(256), 0, st, d);
+  if (pl.use32) hipLaunchKernelGGL((wgrad32_kernel<KS>), grid, dim3(256), 0, st, d);
+  else if (pl.RT == 3) hipLaunchKernelGGL((wgrad_mfma_kernel<KS, 3, 4, 3, 1>), grid, dim3(256), 0, st, d);
   else if (pl.CT == 4) hipLaunchKernelGGL((wgrad_mfma_kernel<KS, 4, 4, 2, 2>), grid, dim3(256), 0, st, d);
   else hipLaunchKernelGGL((wgrad_mfma_kernel<KS, 4, 2, 2, 1>), grid, dim3(256), 0, st, d);
 }

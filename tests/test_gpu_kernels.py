@@ -108,9 +108,11 @@ def test_conv_strided_input_and_mask_add(env, ksize):
 
 @pytest.mark.parametrize('ksize', [3, 1])
 @pytest.mark.parametrize('cin,n', [(256, 48), (24, 256), (96, 256), (256, 192)])
-def test_wgrad(env, ksize, cin, n):
+@pytest.mark.parametrize('force16', [0, 1])
+def test_wgrad(env, ksize, cin, n, force16):
     S, O, dev = env
-    from sin_inn_amd import ops
+    from sin_inn_amd import ops, _lib
+    _lib.lib().sininn_wgrad_test_hooks(force16)
     torch.manual_seed(cin * 3 + n)
     b, h, w = 3, 12, 20
     conv = torch.nn.Conv2d(cin, n, ksize, padding=ksize // 2)
@@ -119,7 +121,10 @@ def test_wgrad(env, ksize, cin, n):
     conv(x[:, 8:]).backward(g)
     gw = torch.ones_like(conv.weight).cuda()          # wgrad accumulates (+=)
     gb = torch.ones_like(conv.bias).cuda()
-    ops.wgrad(nhwc(x), 8, cin + 8, cin, nhwc(g), n, n, b, h, w, ksize, gw, gb)
+    try:
+        ops.wgrad(nhwc(x), 8, cin + 8, cin, nhwc(g), n, n, b, h, w, ksize, gw, gb)
+    finally:
+        _lib.lib().sininn_wgrad_test_hooks(0)
     assert relerr(gw.cpu() - 1, conv.weight.grad) < RTOL
     assert relerr(gb.cpu() - 1, conv.bias.grad) < RTOL
 

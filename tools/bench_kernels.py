@@ -33,9 +33,11 @@ def main():
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--ck', type=int, default=0)
     ap.add_argument('--cfg', type=int, default=0)
+    ap.add_argument('--wgrad16', type=int, default=0)
     a = ap.parse_args()
     dev = torch.device('cuda', 0)
     _lib.lib().sininn_conv_test_hooks(a.cfg, a.ck)
+    _lib.lib().sininn_wgrad_test_hooks(a.wgrad16)
     b = a.batch
     rows = []
     for level, (c, hw) in enumerate(((48, a.size // 4), (192, a.size // 8))):

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, unsigned long lo
 template <int VAR, int NACC>
 void run(const char* name, int blocks_per_cu, double flop_per_mfma) {
   float* out; unsigned long long* clk;
-  int blocks = 256 * blocks_per_cu, iters = 20000;
+  int blocks = 256 * blocks_per_cu, iters = getenv("PEAK_ITERS") ? atoi(getenv("PEAK_ITERS")) : 20000;
   hipMalloc(&out, blocks * 256 * 4); hipMalloc(&clk, 16);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipLaunchKernelGGL((k<VAR, NACC>), dim3(blocks), dim3(256), 0, 0, out, 100, clk);
