@@ -59,11 +59,6 @@ class UncondSRFlow:
         return Ff.ReversibleGraphNet(chain, verbose=False)
 
 
-class InvRescaleNet(nn.Module):
-    """IRN architecture (reference archs.py:201-233).  Its Haar/DenseBlock kernels are the next row of the scope
-    table and are not built yet: constructing it fails loudly rather than silently running on a
-    non-HIP path."""
-
-    def __init__(self, c, h, w, opt):
-        super().__init__()
-        raise NotImplementedError('architecture "IRN" has no HIP lowering yet (SURVEY.md 8f row 2); use -a SRF')
+# IRN architecture (reference archs.py:74-233): HIP implementation in sin-inn_amd/irn.py, same class names,
+# constructor signatures, parameter names and initialisation as the reference.
+from sin_inn_amd.irn import DenseBlock, HaarDownsampling, InvBlockExp, InvRescaleNet   # noqa: E402,F401

@@ -65,8 +65,14 @@ enum sininn_conv_mode {
   SININN_CONV_COUPLE_FWD = 1, /* y = exp(log_e(s)) * v + t ; logdet += sum log_e(s)                        */
   SININN_CONV_COUPLE_INV = 2, /* y = (v - t) / exp(log_e(s)) ; logdet -= sum log_e(s)                      */
   SININN_CONV_MASK = 3,       /* out = conv * (mask > 0)   (data gradient through the ReLU)                */
-  SININN_CONV_ADD = 4,        /* out = conv + addend[addend_map]            (data gradient + skip grad)    */
-  SININN_CONV_LINEAR = 5      /* out = conv + bias                                                          */
+  SININN_CONV_ADD = 4,        /* out = conv (+ bias if given) + addend[addend_map]   (data gradient + skip grad;
+                                 with bias: y1 = x1 + F(x2), archs.py:151)                                  */
+  SININN_CONV_LINEAR = 5,     /* out = conv + bias                                                          */
+  /* IRN architecture (archs.py:74-160): */
+  SININN_CONV_LRELU = 6,      /* out = leaky_relu(conv + bias, slope = clamp)        (DenseBlock conv1-4, archs.py:90-93) */
+  SININN_CONV_IRN_FWD = 7,    /* out = v * exp(clamp*(2*sigmoid(aux)-1)) + conv + bias  (InvBlockExp, archs.py:152-153;
+                                 aux = H(y1) is passed in the mask / mask_stride fields)                     */
+  SININN_CONV_IRN_INV = 8     /* out = (v - (conv + bias)) / exp(clamp*(2*sigmoid(aux)-1))   (archs.py:155-156)        */
 };
 
 typedef struct sininn_conv_args {
@@ -110,6 +116,21 @@ int sininn_coupling_bwd(const float* dy, int dy_stride, const int* dy_map,
                         const float* vy, int vy_stride, const int* vy_map,
                         const float* s, const float* gld, int B, int HW, int Co, float clamp,
                         int inverse, float* dr, float* dv, int dv_stride, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * IRN elementwise pieces (archs.py:135-199).
+ * haar: HaarDownsampling.forward / rev (archs.py:183-199): 2x2 Haar analysis (/4) with the band-major channel
+ *   regrouping out[:, k*C + c] = band k of channel c, or the synthesis (conv_transpose2d, no /4).  Element strides.
+ * lrelu_bwd: g[m][j] *= (f[m][j] > 0 ? 1 : slope)   (gradient through LeakyReLU, in place on a channel slot).
+ * irn_coupling_bwd: backward of y = v*exp(s)+G (inverse==0) or y = (v-G)/exp(s) (inverse==1), s = clamp*(2*sigmoid(h)-1):
+ *   dG, dh [M][Co] compact, dv [M][Co] at dv_stride.  vy = v (inverse==0) or y (inverse==1).
+ * ---------------------------------------------------------------------------------------------- */
+int sininn_haar(const float* in, const int64_t in_strides[4], float* out, const int64_t out_strides[4],
+                int B, int C, int H, int W, int inverse, void* stream);
+int sininn_lrelu_bwd(float* g, int g_stride, const float* f, int f_stride, int64_t M, int n, float slope, void* stream);
+int sininn_irn_coupling_bwd(const float* dy, int dy_stride, const float* vy, int vy_stride, const float* hval,
+                            int64_t M, int Co, float clamp, int inverse, float* dG, float* dh, float* dv,
+                            int dv_stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * One GLOW coupling block per call (FrEIA GLOWCouplingBlock.forward / its autograd, SURVEY Appendix A;

@@ -7,6 +7,7 @@ from . import _lib, ops                                                     # no
 from .modules import GLOWCouplingBlock, IRevNetDownsampling, PermuteRandom   # noqa: F401
 from .framework import InputNode, Node, OutputNode, ReversibleGraphNet      # noqa: F401
 from .optim import FusedAdam                                                 # noqa: F401
+from . import irn                                                             # noqa: F401
 from . import functional                                                     # noqa: F401
 
 __all__ = ['GLOWCouplingBlock', 'IRevNetDownsampling', 'PermuteRandom', 'InputNode', 'Node', 'OutputNode',

@@ -70,6 +70,10 @@ _SIGS = {
     'sininn_glow_scratch_bytes': (C.c_size_t, [C.c_int] * 5),
     'sininn_glow_forward': (C.c_int, [C.POINTER(GlowArgs), C.c_void_p]),
     'sininn_glow_backward': (C.c_int, [C.POINTER(GlowArgs), C.c_void_p, C.c_void_p]),
+    'sininn_haar': (C.c_int, [c_f, I64x4, c_f, I64x4, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'sininn_lrelu_bwd': (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
+    'sininn_irn_coupling_bwd': (C.c_int, [c_f, C.c_int, c_f, C.c_int, c_f, C.c_int64, C.c_int, C.c_float, C.c_int,
+                                          c_f, c_f, c_f, C.c_int, C.c_void_p]),
     'sininn_squeeze': (C.c_int, [c_f, I64x4, c_f, I64x4, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i,
                                  C.c_int, C.c_void_p]),
     'sininn_permute_channels': (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int64, C.c_int, c_i, C.c_void_p]),

@@ -54,6 +54,12 @@ int sample_windows_launch(const uint8_t* hr_clip, const uint8_t* lr_clip, const 
                           const int64_t ls[4], hipStream_t st);
 int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
                 float wd, int step, float gscale, hipStream_t st);
+int haar_launch(const float* in, const int64_t is[4], float* out, const int64_t os[4], int B, int C, int H, int W,
+                int inverse, hipStream_t st);
+int lrelu_bwd_launch(float* g, int g_stride, const float* f, int f_stride, int64_t M, int n, float slope, hipStream_t st);
+int irn_coupling_bwd_launch(const float* dy, int dy_stride, const float* vy, int vy_stride, const float* hval, int64_t M,
+                            int Co, float clamp, int inverse, float* dG, float* dh, float* dv, int dv_stride,
+                            hipStream_t st);
 size_t glow_saved_floats(int B, int H, int W, int C);
 size_t glow_scratch_bytes(int B, int H, int W, int C, int ksize);
 int glow_forward(const sininn_glow_args* a, hipStream_t st);
@@ -108,6 +114,20 @@ size_t sininn_glow_scratch_bytes(int B, int H, int W, int C, int ksize) { return
 int sininn_glow_forward(const sininn_glow_args* args, void* stream) { return glow_forward(args, ST(stream)); }
 int sininn_glow_backward(const sininn_glow_args* args, void* stream, void* wgrad_stream) {
   return glow_backward(args, ST(stream), ST(wgrad_stream));
+}
+
+int sininn_haar(const float* in, const int64_t in_strides[4], float* out, const int64_t out_strides[4], int B, int C, int H,
+                int W, int inverse, void* stream) {
+  return haar_launch(in, in_strides, out, out_strides, B, C, H, W, inverse, ST(stream));
+}
+int sininn_lrelu_bwd(float* g, int g_stride, const float* f, int f_stride, int64_t M, int n, float slope, void* stream) {
+  return lrelu_bwd_launch(g, g_stride, f, f_stride, M, n, slope, ST(stream));
+}
+int sininn_irn_coupling_bwd(const float* dy, int dy_stride, const float* vy, int vy_stride, const float* hval, int64_t M,
+                            int Co, float clamp, int inverse, float* dG, float* dh, float* dv, int dv_stride,
+                            void* stream) {
+  return irn_coupling_bwd_launch(dy, dy_stride, vy, vy_stride, hval, M, Co, clamp, inverse, dG, dh, dv, dv_stride,
+                                 ST(stream));
 }
 
 int sininn_squeeze(const float* in, const int64_t in_strides[4], float* out, const int64_t out_strides[4], int B, int C,

@@ -104,12 +104,25 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvDev& p, const float
         const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
         f32x4 val = *reinterpret_cast<const f32x4*>(T + pl * TS + q4 * 4);
         const bool full = (col + 3 < p.N);
-        if (MODE == SININN_CONV_RELU || MODE == SININN_CONV_LINEAR) {
+        if (MODE == SININN_CONV_RELU || MODE == SININN_CONV_LINEAR || MODE == SININN_CONV_LRELU) {
           if (p.bias) val += *reinterpret_cast<const f32x4*>(p.bias + col);   // packed bias has Np >= col+4 entries
           if (MODE == SININN_CONV_RELU) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) val[j] = fmaxf(val[j], 0.f);
+          } else if (MODE == SININN_CONV_LRELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) val[j] = val[j] > 0.f ? val[j] : val[j] * p.clamp;
           }
+        } else if (MODE == SININN_CONV_IRN_FWD || MODE == SININN_CONV_IRN_INV) {
+          if (p.bias) val += *reinterpret_cast<const f32x4*>(p.bias + col);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (col + j < p.N) {
+              const float hv = p.mask[pix * p.mask_stride + col + j];
+              const float sv = p.clamp * (2.f / (1.f + expf(-hv)) - 1.f);
+              const float vv = p.v[pix * p.v_stride + col + j];
+              val[j] = (MODE == SININN_CONV_IRN_FWD) ? vv * expf(sv) + val[j] : (vv - val[j]) / expf(sv);
+            }
         } else if (MODE == SININN_CONV_MASK) {
           if (full) {
             const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + pix * p.mask_stride + col);
@@ -121,6 +134,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvDev& p, const float
               if (col + j < p.N) val[j] = (p.mask[pix * p.mask_stride + col + j] > 0.f) ? val[j] : 0.f;
           }
         } else if (MODE == SININN_CONV_ADD) {
+          if (p.bias) val += *reinterpret_cast<const f32x4*>(p.bias + col);
           if (p.addend_map == nullptr && full) {
             val += *reinterpret_cast<const f32x4*>(p.addend + pix * p.addend_stride + col);
           } else {

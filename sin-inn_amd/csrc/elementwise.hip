@@ -697,4 +697,104 @@ int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float l
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// IRN pieces (archs.py:135-199)
+// ------------------------------------------------------------------------------------------------
+__global__ void haar_kernel(const float* __restrict__ in, Str4 is, float* __restrict__ out, Str4 os, int B, int C, int H,
+                            int W, int inverse, int c_fastest) {
+  // one thread per (b, c, i, j) of the COARSE grid; H, W are the fine sizes
+  const int h2 = H / 2, w2 = W / 2;
+  const int64_t total = (int64_t)B * C * h2 * w2;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int b, c, i, j;
+    int64_t r = idx;
+    if (c_fastest) { c = r % C; r /= C; j = r % w2; r /= w2; i = r % h2; b = (int)(r / h2); }
+    else { j = r % w2; r /= w2; i = r % h2; r /= h2; c = r % C; b = (int)(r / C); }
+    if (!inverse) {
+      const float* p = in + b * is.b + c * is.c + (2 * i) * is.h + (2 * j) * is.w;
+      const float a = p[0], bb = p[is.w], cc = p[is.h], d = p[is.h + is.w];
+      float* o = out + b * os.b + i * os.h + j * os.w;
+      o[(0 * C + c) * os.c] = (a + bb + cc + d) * 0.25f;
+      o[(1 * C + c) * os.c] = (a - bb + cc - d) * 0.25f;
+      o[(2 * C + c) * os.c] = (a + bb - cc - d) * 0.25f;
+      o[(3 * C + c) * os.c] = (a - bb - cc + d) * 0.25f;
+    } else {
+      const float* p = in + b * is.b + i * is.h + j * is.w;
+      const float ll = p[(0 * C + c) * is.c], b1 = p[(1 * C + c) * is.c], b2 = p[(2 * C + c) * is.c], b3 = p[(3 * C + c) * is.c];
+      float* o = out + b * os.b + c * os.c + (2 * i) * os.h + (2 * j) * os.w;
+      o[0] = ll + b1 + b2 + b3;
+      o[os.w] = ll - b1 + b2 - b3;
+      o[os.h] = ll + b1 - b2 - b3;
+      o[os.h + os.w] = ll - b1 - b2 + b3;
+    }
+  }
+}
+
+int haar_launch(const float* in, const int64_t is[4], float* out, const int64_t os[4], int B, int C, int H, int W,
+                int inverse, hipStream_t st) {
+  SININN_CHECK(in && out && is && os && B > 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "haar: bad arguments");
+  const int64_t total = (int64_t)B * C * (H / 2) * (W / 2);
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  const int64_t coarse_sc = inverse ? is[1] : os[1];
+  hipLaunchKernelGGL(haar_kernel, dim3(blocks), dim3(256), 0, st, in, mk(is), out, mk(os), B, C, H, W, inverse,
+                     coarse_sc == 1 ? 1 : 0);
+  SININN_LAUNCH_CHECK("haar");
+  return 0;
+}
+
+__global__ void lrelu_bwd_kernel(float* __restrict__ g, int g_stride, const float* __restrict__ f, int f_stride,
+                                 int64_t total, int n, float slope) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(idx % n);
+    const int64_t m = idx / n;
+    if (!(f[m * f_stride + j] > 0.f)) g[m * g_stride + j] *= slope;
+  }
+}
+
+int lrelu_bwd_launch(float* g, int g_stride, const float* f, int f_stride, int64_t M, int n, float slope, hipStream_t st) {
+  SININN_CHECK(g && f && M > 0 && n > 0 && g_stride >= n && f_stride >= n, "lrelu_bwd: bad arguments");
+  const int64_t total = M * n;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(blocks), dim3(256), 0, st, g, g_stride, f, f_stride, total, n, slope);
+  SININN_LAUNCH_CHECK("lrelu_bwd");
+  return 0;
+}
+
+__global__ void irn_coupling_bwd_kernel(const float* __restrict__ dy, int dy_stride, const float* __restrict__ vy,
+                                        int vy_stride, const float* __restrict__ hval, int64_t total, int Co, float clamp,
+                                        int inverse, float* __restrict__ dG, float* __restrict__ dh,
+                                        float* __restrict__ dv, int dv_stride) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % Co);
+    const int64_t m = idx / Co;
+    const float g = dy[m * dy_stride + c], u = vy[m * vy_stride + c], hv = hval[idx];
+    const float sg = 1.f / (1.f + expf(-hv));
+    const float s = clamp * (2.f * sg - 1.f);
+    const float ds_dh = clamp * 2.f * sg * (1.f - sg);
+    const float e = expf(s);
+    float gG, gs, gv;
+    if (!inverse) { gv = g * e; gG = g; gs = g * u * e; }      // y = v e + G
+    else { gv = g / e; gG = -gv; gs = -g * u; }                // y = (v - G)/e ; d/ds = -y
+    dG[idx] = gG;
+    dh[idx] = gs * ds_dh;
+    dv[m * dv_stride + c] = gv;
+  }
+}
+
+int irn_coupling_bwd_launch(const float* dy, int dy_stride, const float* vy, int vy_stride, const float* hval, int64_t M,
+                            int Co, float clamp, int inverse, float* dG, float* dh, float* dv, int dv_stride,
+                            hipStream_t st) {
+  SININN_CHECK(dy && vy && hval && dG && dh && dv && M > 0 && Co > 0, "irn_coupling_bwd: bad arguments");
+  SININN_CHECK(dy_stride >= Co && vy_stride >= Co && dv_stride >= Co, "irn_coupling_bwd: stride < Co");
+  const int64_t total = M * Co;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(irn_coupling_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, dy_stride, vy, vy_stride, hval, total,
+                     Co, clamp, inverse, dG, dh, dv, dv_stride);
+  SININN_LAUNCH_CHECK("irn_coupling_bwd");
+  return 0;
+}
+
 }  // namespace sininn

@@ -85,13 +85,13 @@ def conv(**kw):
     check(_lib.lib().sininn_conv(C.byref(a), _stream()))
 
 
-def wgrad(in_t, in_off, in_stride, cin, dout, dout_stride, n, b, h, w, ksize, gw, gb):
+def wgrad(in_t, in_off, in_stride, cin, dout, dout_stride, n, b, h, w, ksize, gw, gb, dout_off=0):
     """gw (OIHW, contiguous) += dW ; gb += db."""
     lib = _lib.lib()
     nbytes = lib.sininn_wgrad_workspace_bytes(n, cin, ksize, b, h, w)
     ws = torch.empty((nbytes + 3) // 4, device=dout.device, dtype=torch.float32)
     assert gw.is_contiguous() and (gb is None or gb.is_contiguous())
-    check(lib.sininn_wgrad(ptr(in_t, in_off), in_stride, cin, ptr(dout), dout_stride, n, b, h, w, ksize,
+    check(lib.sininn_wgrad(ptr(in_t, in_off), in_stride, cin, ptr(dout, dout_off), dout_stride, n, b, h, w, ksize,
                            ptr(gw), ptr(gb), ptr(ws), nbytes, _stream()))
 
 
