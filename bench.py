@@ -41,32 +41,25 @@ def make_opt(num_coupling, lr_window):
 
 
 class KernelTimer:
-    """HIP events around every launch of the dominant kernel (recorded on the stream the kernel is launched on)."""
+    """HIP events around every launch of the dominant kernel, recorded by the C++ block executor on the stream the
+    kernel is launched on (sininn_profile_begin / sininn_profile_end)."""
 
-    def __init__(self, match):
-        self.match, self.events, self.enabled = match, [], False
+    def __init__(self, level_height):
+        self.h, self.count, self.total_ms = level_height, 0, 0.0
 
-    def install(self):
-        from sin_inn_amd import ops
-        real = ops.conv
-        timer = self
+    def start(self):
+        from sin_inn_amd import _lib
+        _lib.lib().sininn_profile_begin(self.h)
 
-        def timed_conv(**kw):
-            if timer.enabled and timer.match(kw):
-                s = torch.cuda.current_stream()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(s)
-                real(**kw)
-                e1.record(s)
-                timer.events.append((e0, e1))
-            else:
-                real(**kw)
-        ops.conv = timed_conv
+    def stop(self):
+        import ctypes as C
+        from sin_inn_amd import _lib
+        n, ms = C.c_int(0), C.c_float(0.0)
+        _lib.check(_lib.lib().sininn_profile_end(C.byref(n), C.byref(ms)))
+        self.count, self.total_ms = n.value, ms.value
 
     def mean_ms(self):
-        if not self.events:
-            return None
-        return sum(a.elapsed_time(b) for a, b in self.events) / len(self.events)
+        return self.total_ms / self.count if self.count else None
 
 
 def cpu_baseline(args, opt, seconds_budget=30.0):
@@ -133,10 +126,7 @@ def main():
     b, m0 = args.batch, args.batch * (args.size // 4) ** 2
     co0 = 24
 
-    def is_dominant(kw):   # 3x3 coupling conv, 256 -> 2*24 columns, level-0 resolution
-        return kw.get('ksize') == 3 and kw.get('Cin') == 256 and kw.get('Np') == 2 * co0 and kw.get('H') == args.size // 4
-    timer = KernelTimer(is_dominant)
-    timer.install()
+    timer = KernelTimer(args.size // 4)      # forward 3x3 coupling conv (256 -> 2*24 columns) at level-0 resolution
 
     def step():
         idx = torch.randint(lo, hi, (b,), generator=gen).to(dev)
@@ -153,14 +143,14 @@ def main():
         step()
     barrier()
     print(f'[bench] rank {rank}: warm-up done', file=sys.stderr, flush=True)
-    timer.enabled = True
+    timer.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     t_issue = time.perf_counter() - t0      # host time to enqueue the steps (GPU still running)
     barrier()
     dt = time.perf_counter() - t0
-    timer.enabled = False
+    timer.stop()
     if ws > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -184,7 +174,7 @@ def main():
         roof = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
                 'kernel': 'conv_mfma_kernel<3,8,4,1,2,3> (3x3 coupling conv 256->48, level 0)',
-                'launches_timed': len(timer.events), 'avg_ms': kms, 'alg_flops_per_launch': flops,
+                'launches_timed': timer.count, 'avg_ms': kms, 'alg_flops_per_launch': flops,
                 'alg_bytes_per_launch': 4.0 * (m0 * 256 + m0 * 3 * co0 + 9 * 256 * 2 * co0)}
     out = {'metric': 'training frames/sec at 256x256 bs=16', 'value': value, 'unit': 'frames/s', 'n_gpus': ws,
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,

@@ -160,6 +160,12 @@ typedef struct sininn_glow_args {
   const float* dout; const float* gld; float* dx;
 } sininn_glow_args;
 
+/* Live timing for bench.py: between begin and end, every forward 3x3 coupling conv (conv2 + affine epilogue) of the
+ * level whose image height is `level_height` is bracketed by HIP events on its launch stream; end() synchronises on
+ * them and returns the number of launches timed and their summed duration. */
+void sininn_profile_begin(int level_height);
+int sininn_profile_end(int* count, float* total_ms);
+
 size_t sininn_glow_saved_floats(int B, int H, int W, int C);
 size_t sininn_glow_scratch_bytes(int B, int H, int W, int C, int ksize);
 int sininn_glow_forward(const sininn_glow_args* args, void* stream);

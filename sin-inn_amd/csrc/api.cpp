@@ -60,6 +60,8 @@ int lrelu_bwd_launch(float* g, int g_stride, const float* f, int f_stride, int64
 int irn_coupling_bwd_launch(const float* dy, int dy_stride, const float* vy, int vy_stride, const float* hval, int64_t M,
                             int Co, float clamp, int inverse, float* dG, float* dh, float* dv, int dv_stride,
                             hipStream_t st);
+void profile_begin(int h);
+int profile_end(int* count, float* total_ms);
 size_t glow_saved_floats(int B, int H, int W, int C);
 size_t glow_scratch_bytes(int B, int H, int W, int C, int ksize);
 int glow_forward(const sininn_glow_args* a, hipStream_t st);
@@ -109,6 +111,8 @@ int sininn_coupling_bwd(const float* dy, int dy_stride, const int* dy_map, const
                              dv_stride, ST(stream));
 }
 
+void sininn_profile_begin(int level_height) { profile_begin(level_height); }
+int sininn_profile_end(int* count, float* total_ms) { return profile_end(count, total_ms); }
 size_t sininn_glow_saved_floats(int B, int H, int W, int C) { return glow_saved_floats(B, H, W, C); }
 size_t sininn_glow_scratch_bytes(int B, int H, int W, int C, int ksize) { return glow_scratch_bytes(B, H, W, C, ksize); }
 int sininn_glow_forward(const sininn_glow_args* args, void* stream) { return glow_forward(args, ST(stream)); }

@@ -4,6 +4,8 @@
 // Python they made the host the bottleneck).  Weight-gradient kernels go to a second stream (they depend on dr / dh
 // only) so they overlap the data-gradient chain.
 #include <mutex>
+#include <utility>
+#include <vector>
 
 #include "common.h"
 
@@ -43,6 +45,50 @@ static int order_after(hipStream_t waiter, hipStream_t producer) {
     return 1;
   }
   return 0;
+}
+
+// ---- live timing of the dominant kernel (bench.py): HIP events on the launch stream around every forward 3x3
+// coupling conv (conv2 + affine epilogue) of the level whose image height is g_prof_h ----------------------------
+static int g_prof_h = 0;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
+
+void profile_begin(int h) {
+  std::lock_guard<std::mutex> lock(g_ev_mutex);
+  for (auto& p : g_prof_events) g_prof_pool.push_back(p);
+  g_prof_events.clear();
+  g_prof_h = h;
+}
+
+int profile_end(int* count, float* total_ms) {
+  std::lock_guard<std::mutex> lock(g_ev_mutex);
+  g_prof_h = 0;
+  float tot = 0.f;
+  int n = 0;
+  for (auto& p : g_prof_events) {
+    float ms = 0.f;
+    if (hipEventSynchronize(p.second) != hipSuccess || hipEventElapsedTime(&ms, p.first, p.second) != hipSuccess) {
+      set_error("profile_end: event query failed");
+      return 1;
+    }
+    tot += ms; ++n;
+    g_prof_pool.push_back(p);
+  }
+  g_prof_events.clear();
+  if (count) *count = n;
+  if (total_ms) *total_ms = tot;
+  return 0;
+}
+
+static bool prof_pair(hipEvent_t* a, hipEvent_t* b) {
+  std::lock_guard<std::mutex> lock(g_ev_mutex);
+  if (g_prof_events.size() >= 8192) return false;
+  std::pair<hipEvent_t, hipEvent_t> p;
+  if (!g_prof_pool.empty()) { p = g_prof_pool.back(); g_prof_pool.pop_back(); }
+  else if (hipEventCreate(&p.first) != hipSuccess || hipEventCreate(&p.second) != hipSuccess) return false;
+  g_prof_events.push_back(p);
+  *a = p.first; *b = p.second;
+  return true;
 }
 
 struct Half {                 // one half-coupling in execution order
@@ -149,7 +195,11 @@ int glow_forward(const sininn_glow_args* a, hipStream_t st) {
     c2.v = a->x + h.base; c2.v_stride = C;
     c2.out2 = (i == 0) ? sv.ybuf : nullptr; c2.out2_stride = h.co;
     c2.sbuf = sbuf; c2.logdet = a->logdet; c2.Co = h.co; c2.clamp = a->clamp; c2.col_tile = col_tile_of(h.co);
+    hipEvent_t e0, e1;
+    const bool timed = g_prof_h != 0 && a->ksize == 3 && a->H == g_prof_h && prof_pair(&e0, &e1);
+    if (timed) (void)hipEventRecord(e0, st);
     if (int rc = conv_launch(&c2, st)) return rc;
+    if (timed) (void)hipEventRecord(e1, st);
   }
   return 0;
 }
