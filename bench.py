@@ -101,6 +101,8 @@ def main():
     ap.add_argument('--frames', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=2)
+    ap.add_argument('--wgrad16', type=int, default=0, help='diagnostic: force the 16x16x4 weight-gradient kernel')
+    ap.add_argument('--no-overlap', action='store_true', help='diagnostic: single stream (no pass / wgrad overlap)')
     args = ap.parse_args()
 
     import sin_inn_amd
@@ -115,9 +117,15 @@ def main():
     from data import FrameStore
     from sin_inn_amd.functional import sample_windows
 
+    from sin_inn_amd import _lib as _l, modules as _m
+    _l.lib().sininn_wgrad_test_hooks(args.wgrad16)
+    if args.no_overlap:
+        _m.USE_SIDE_STREAM[0] = False
     opt = make_opt(args.num_coupling, args.lr_window)
     torch.manual_seed(0)                                   # identical random-init weights on every rank
     model = lit_wrapper.SingleVideoINN(3, args.size, args.size, opt).to(dev)
+    if args.no_overlap:
+        model.overlap_passes = False
     optim = model.attach_optimizer()
     store = FrameStore.synthetic(args.frames, args.size, args.size).to(dev)   # clip resident in HBM before timing
     lo, hi = args.lr_window, args.frames - args.lr_window

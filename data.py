@@ -48,6 +48,13 @@ class FrameStore:
         return cls(hr, lr)
 
     @classmethod
+    def from_hr_clip(cls, hr_u8, scale=4, reduction='mean'):
+        """Raw RGB video (T,H,W,3) u8 on the GPU -> frame store, LR frames synthesised on-device exactly as
+        datasets/prepare.py does offline (RGGB sampling + binning; HR/LR ratio = 2*scale), no PNG round trip."""
+        from sin_inn_amd.functional import bayer_bin
+        return cls(hr_u8, bayer_bin(hr_u8.contiguous(), scale, reduction))
+
+    @classmethod
     def from_directory(cls, dataset, scene):
         """``<dataset>/{hr_frames,lr_frames}/<scene>/frame_%05d.png`` (data.py:20-21,57-59); LR PNGs are RGBA-coded RGGB."""
         from PIL import Image

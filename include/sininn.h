@@ -243,6 +243,12 @@ int sininn_sample_windows(const uint8_t* hr_clip, const uint8_t* lr_clip, const 
                           float* hr_out, const int64_t hs[4], float* lr_out, const int64_t ls[4], void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * On-device LR synthesis (datasets/prepare.py:35-82,147-165): RGGB sampling + scale x scale binning per Bayer plane
+ * with the reference's float64 arithmetic and uint8 truncation.  hr (T,H,W,3) u8 -> lr (T,H/(2s),W/(2s),4) u8.
+ * ---------------------------------------------------------------------------------------------- */
+int sininn_bayer_bin(const uint8_t* hr, uint8_t* lr, int T, int H, int W, int scale, int reduce_sum, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Adam exactly as torch.optim.Adam (lit_wrapper.py:131-138: L2 weight decay, not AdamW):
  *   g = grad*grad_scale + wd*p ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
  *   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)

@@ -475,3 +475,28 @@ def load_reference_irn_state(oracle_net, ref_state):
             continue                                   # haar_weights buffers
         new[f'blocks.{remap[int(parts[1])]}.{parts[2]}.convs.{int(parts[3][4:]) - 1}.{parts[4]}'] = v
     oracle_net.load_state_dict(new)
+
+
+# ----------------------------------------------------------------------------------------------
+# LR synthesis of datasets/prepare.py (extract_bayer :35-52 without the optional Lanczos resize, binning :54-82,
+# quantisation :127-128,164) in numpy float64, the reference's own dtype
+# ----------------------------------------------------------------------------------------------
+def bayer_bin(hr_u8, scale=4, reduction='mean'):
+    """hr (T,H,W,3) uint8 numpy -> lr (T,H/(2s),W/(2s),4) uint8."""
+    red = {'mean': np.mean, 'sum': np.sum}[reduction]
+    out = []
+    for frame in hr_u8:
+        f = frame / 255
+        bayer = np.empty(f.shape[:2])
+        bayer[::2, ::2] = f[::2, ::2, 0]
+        bayer[::2, 1::2] = f[::2, 1::2, 1]
+        bayer[1::2, ::2] = f[1::2, ::2, 1]
+        bayer[1::2, 1::2] = f[1::2, 1::2, 2]
+        h, w = bayer.shape
+        binned = np.empty((h // scale // 2, w // scale // 2, 4))
+        for k, plane in enumerate((bayer[::2, ::2], bayer[::2, 1::2], bayer[1::2, ::2], bayer[1::2, 1::2])):
+            ph, pw = plane.shape
+            blocks = plane[:, :, None].reshape(ph // scale, scale, pw // scale, scale, 1)
+            binned[..., k] = red(red(blocks, 1), -2).squeeze()
+        out.append((np.clip(binned, 0, 1) * 255).astype(np.uint8))
+    return np.stack(out)

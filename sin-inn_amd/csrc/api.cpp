@@ -62,6 +62,7 @@ int irn_coupling_bwd_launch(const float* dy, int dy_stride, const float* vy, int
                             hipStream_t st);
 void profile_begin(int h);
 int profile_end(int* count, float* total_ms);
+int bayer_bin_launch(const uint8_t* hr, uint8_t* lr, int T, int H, int W, int scale, int reduce_sum, hipStream_t st);
 size_t glow_saved_floats(int B, int H, int W, int C);
 size_t glow_scratch_bytes(int B, int H, int W, int C, int ksize);
 int glow_forward(const sininn_glow_args* a, hipStream_t st);
@@ -188,6 +189,10 @@ int sininn_sample_windows(const uint8_t* hr_clip, const uint8_t* lr_clip, const 
                           int h, int w, int win, float* hr_out, const int64_t hs[4], float* lr_out, const int64_t ls[4],
                           void* stream) {
   return sample_windows_launch(hr_clip, lr_clip, idx, n, T, H, W, h, w, win, hr_out, hs, lr_out, ls, ST(stream));
+}
+
+int sininn_bayer_bin(const uint8_t* hr, uint8_t* lr, int T, int H, int W, int scale, int reduce_sum, void* stream) {
+  return bayer_bin_launch(hr, lr, T, H, W, scale, reduce_sum, ST(stream));
 }
 
 int sininn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

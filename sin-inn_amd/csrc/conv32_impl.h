@@ -229,6 +229,7 @@ static int dispatch32(ConvDev& d, hipStream_t st, int force_cfg, bool must) {
   const int nt32 = d.Np / 32;
   const long tiles8 = (long)d.B * ((d.H + 7) / 8) * ((d.W + 15) / 16);
   auto set_tiles = [&](int th) { d.tiles_x = (d.W + 15) / 16; d.tiles_y = (d.H + th - 1) / th; };
+  if (force_cfg == 7 && nt32 == 1) { d.tiles_x = (d.W + 15) / 16; d.tiles_y = (d.H + 15) / 16; return launch32<KS, 16, 4, 1, 2, 1>(d, st); }
   if (force_cfg == 5) { set_tiles(8); return launch32<KS, 8, 4, 1, 1, 1>(d, st); }
   if (nt32 % 2 == 0 && force_cfg == 6) { set_tiles(4); return launch32<KS, 4, 2, 2, 1, 1>(d, st); }
   if (KS == 3 && nt32 % 2 == 0 && force_cfg == 4) { d.tiles_x = (d.W + 15) / 16; d.tiles_y = (d.H + 15) / 16; return launch32<KS, 16, 4, 1, 2, 2>(d, st); }

@@ -797,4 +797,48 @@ int irn_coupling_bwd_launch(const float* dy, int dy_stride, const float* vy, int
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// On-device LR synthesis (datasets/prepare.py:35-82,147-165): RGGB Bayer sampling of an RGB frame followed by
+// `scale` x `scale` binning of each Bayer plane, quantised exactly like the reference: v/255 in float64, mean (or sum)
+// over the block rows then over the block columns (numpy's order), clip to [0,1], *255, truncate to uint8.
+//   hr (T,H,W,3) u8  ->  lr (T, H/(2*scale), W/(2*scale), 4) u8, channel k = Bayer plane (R, G1, G2, B)
+// ------------------------------------------------------------------------------------------------
+__global__ void bayer_bin_kernel(const uint8_t* __restrict__ hr, uint8_t* __restrict__ lr, int T, int H, int W, int scale,
+                                 int reduce_sum) {
+  const int h = H / (2 * scale), w = W / (2 * scale);
+  const int64_t total = (int64_t)T * h * w * 4;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx & 3);
+    int64_t r = idx >> 2;
+    const int x = (int)(r % w); r /= w;
+    const int y = (int)(r % h);
+    const int t = (int)(r / h);
+    const int py = k >> 1, px = k & 1;                    // position inside the 2x2 RGGB cell
+    const int ch = (k == 0) ? 0 : ((k == 3) ? 2 : 1);     // R, G, G, B
+    double acc_cols = 0.0;
+    for (int j = 0; j < scale; ++j) {                     // second reduction: over block columns
+      double acc_rows = 0.0;
+      for (int i = 0; i < scale; ++i) {                   // first reduction: over block rows
+        const int yy = 2 * (y * scale + i) + py, xx = 2 * (x * scale + j) + px;
+        acc_rows += (double)hr[(((int64_t)t * H + yy) * W + xx) * 3 + ch] / 255.0;
+      }
+      acc_cols += reduce_sum ? acc_rows : acc_rows / (double)scale;
+    }
+    double v = reduce_sum ? acc_cols : acc_cols / (double)scale;
+    v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+    lr[idx] = (uint8_t)(v * 255.0);
+  }
+}
+
+int bayer_bin_launch(const uint8_t* hr, uint8_t* lr, int T, int H, int W, int scale, int reduce_sum, hipStream_t st) {
+  SININN_CHECK(hr && lr && T > 0 && H > 0 && W > 0 && scale > 0, "bayer_bin: bad arguments");
+  SININN_CHECK(H % (2 * scale) == 0 && W % (2 * scale) == 0, "bayer_bin: H and W must be multiples of 2*scale (prepare.py:152)");
+  const int64_t total = (int64_t)T * (H / (2 * scale)) * (W / (2 * scale)) * 4;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(bayer_bin_kernel, dim3(blocks), dim3(256), 0, st, hr, lr, T, H, W, scale, reduce_sum);
+  SININN_LAUNCH_CHECK("bayer_bin");
+  return 0;
+}
+
 }  // namespace sininn

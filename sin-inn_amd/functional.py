@@ -159,3 +159,16 @@ def sample_windows(hr_clip, lr_clip, idx, lr_window):
     lr = torch.empty((n, h, w, lrc), device=hr_clip.device, dtype=torch.float32).permute(0, 3, 1, 2)
     ops.sample_windows(hr_clip, lr_clip, idx.to(torch.int32), lr_window, hr, lr)
     return hr, lr
+
+
+def bayer_bin(hr_clip, scale=4, reduction='mean'):
+    """datasets/prepare.py LR synthesis on the GPU: hr (T,H,W,3) u8 -> lr (T, H/(2*scale), W/(2*scale), 4) u8 (RGGB planes)."""
+    from . import _lib
+    assert hr_clip.dtype == torch.uint8 and hr_clip.dim() == 4 and hr_clip.shape[-1] == 3 and hr_clip.is_contiguous()
+    if not hr_clip.is_cuda:
+        raise NotImplementedError('sin-inn_amd ops run on the GPU only (got a CPU tensor)')
+    t, h, w, _ = hr_clip.shape
+    lr = torch.empty((t, h // (2 * scale), w // (2 * scale), 4), device=hr_clip.device, dtype=torch.uint8)
+    _lib.check(_lib.lib().sininn_bayer_bin(hr_clip.data_ptr(), lr.data_ptr(), t, h, w, scale,
+                                           1 if reduction == 'sum' else 0, ops._stream()))
+    return lr

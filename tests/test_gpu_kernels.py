@@ -270,3 +270,20 @@ def test_fused_adam_matches_torch(env):
         o_ref.step(); o_mine.step()
     for r, m in zip(ref, mine):
         assert relerr(m, r) < 1e-5
+
+
+@pytest.mark.parametrize('scale,reduction', [(4, 'mean'), (2, 'mean'), (2, 'sum')])
+def test_bayer_bin_bit_exact(env, scale, reduction):
+    """datasets/prepare.py LR synthesis: byte-exact against the float64 numpy restatement."""
+    S, O, dev = env
+    from sin_inn_amd.functional import bayer_bin
+    from data import FrameStore
+    g = torch.Generator().manual_seed(9)
+    hr = torch.randint(0, 256, (3, 32, 48, 3), generator=g, dtype=torch.uint8)
+    if reduction == 'sum':
+        hr = hr // 4
+    lr = bayer_bin(hr.cuda(), scale, reduction)
+    want = O.bayer_bin(hr.numpy(), scale, reduction)
+    assert np.array_equal(lr.cpu().numpy(), want)
+    st = FrameStore.from_hr_clip(hr.cuda(), scale, reduction)
+    assert st.lr.shape == (3, 32 // (2 * scale), 48 // (2 * scale), 4)

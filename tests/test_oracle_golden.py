@@ -175,3 +175,13 @@ def test_g5_irn_full_net(golden):
     assert torch.allclose(y[:, ::16, ::2, ::2], T(golden['g5_out_slice']), rtol=1e-4, atol=1e-5)
     assert torch.allclose(y.norm(), T(golden['g5_out_norm']), rtol=1e-5)
     assert (xr - x).abs().max() < 1e-4
+
+
+def test_bayer_bin_oracle_hand_case():
+    # one 8x8 frame, scale 2: R plane = channel 0 at even rows / even cols
+    hr = np.zeros((1, 8, 8, 3), np.uint8)
+    hr[0, ::2, ::2, 0] = np.array([[10, 20, 30, 40], [50, 60, 70, 80], [1, 2, 3, 4], [5, 6, 7, 9]])
+    lr = O.bayer_bin(hr, scale=2)
+    assert lr.shape == (1, 2, 2, 4)
+    assert lr[0, :, :, 0].tolist() == [[35, 55], [3, 5]]          # floor(mean); (1+2+5+6)/4=3.5 -> 3, (3+4+7+9)/4=5.75 -> 5
+    assert int(lr[0, :, :, 1:].sum()) == 0
