@@ -72,7 +72,13 @@ enum sininn_conv_mode {
   SININN_CONV_LRELU = 6,      /* out = leaky_relu(conv + bias, slope = clamp)        (DenseBlock conv1-4, archs.py:90-93) */
   SININN_CONV_IRN_FWD = 7,    /* out = v * exp(clamp*(2*sigmoid(aux)-1)) + conv + bias  (InvBlockExp, archs.py:152-153;
                                  aux = H(y1) is passed in the mask / mask_stride fields)                     */
-  SININN_CONV_IRN_INV = 8     /* out = (v - (conv + bias)) / exp(clamp*(2*sigmoid(aux)-1))   (archs.py:155-156)        */
+  SININN_CONV_IRN_INV = 8,    /* out = (v - (conv + bias)) / exp(clamp*(2*sigmoid(aux)-1))   (archs.py:155-156)        */
+  /* data gradient of a subnet's first conv fused with the NEXT coupling tail's backward (saves a launch and the
+   * round trip of the intermediate gradient): g = conv + addend[addend_map]; then exactly sininn_coupling_bwd on g:
+   *   out  [M][2*Co] = (ds | dt), out_stride = 2*Co;  out2 = dv (stride out2_stride);  v = v (FWD) or y (INV);
+   *   sbuf = s [M][Co] (read);  logdet = optional per-sample log-det gradient [B] (read);  N = Co. */
+  SININN_CONV_ADD_CBWD_FWD = 9,
+  SININN_CONV_ADD_CBWD_INV = 10
 };
 
 typedef struct sininn_conv_args {

@@ -35,7 +35,9 @@ int conv_launch(const sininn_conv_args* a, hipStream_t st) {
     SININN_CHECK(a->N > 0 && a->N <= a->Np && a->out_stride >= a->N, "conv: bad N=%d (Np=%d, out_stride=%d)", a->N, a->Np, a->out_stride);
     if (a->mode == SININN_CONV_RELU) SININN_CHECK(a->bias != nullptr, "conv: RELU mode needs bias");
     if (a->mode == SININN_CONV_MASK) SININN_CHECK(a->mask != nullptr && a->mask_stride >= a->N, "conv: MASK mode needs mask");
-    if (a->mode == SININN_CONV_ADD) SININN_CHECK(a->addend != nullptr, "conv: ADD mode needs addend");
+    const bool cbwd = a->mode == SININN_CONV_ADD_CBWD_FWD || a->mode == SININN_CONV_ADD_CBWD_INV;
+    if (a->mode == SININN_CONV_ADD || cbwd) SININN_CHECK(a->addend != nullptr, "conv: ADD mode needs addend");
+    if (cbwd) SININN_CHECK(a->v && a->sbuf && a->out2 && a->Co == a->N && a->out_stride >= 2 * a->Co && a->clamp > 0.f, "conv: ADD_CBWD needs v, sbuf, out2, Co == N, out_stride >= 2*Co");
     if (a->mode == SININN_CONV_IRN_FWD || a->mode == SININN_CONV_IRN_INV)
       SININN_CHECK(a->mask && a->v && a->mask_stride >= a->N && a->v_stride >= a->N && a->clamp > 0.f, "conv: IRN modes need aux (mask), v and clamp");
   }
@@ -49,7 +51,7 @@ int conv_launch(const sininn_conv_args* a, hipStream_t st) {
   }
   if (a->mode == SININN_CONV_MASK) SININN_CHECK(aligned16(a->mask) && a->mask_stride % 4 == 0, "conv: mask must be 16-byte aligned");
   SININN_CHECK(a->N % 4 == 0 || couple, "conv: N must be a multiple of 4");
-  if (a->mode == SININN_CONV_ADD && !a->addend_map)
+  if ((a->mode == SININN_CONV_ADD || a->mode == SININN_CONV_ADD_CBWD_FWD || a->mode == SININN_CONV_ADD_CBWD_INV) && !a->addend_map)
     SININN_CHECK(aligned16(a->addend) && a->addend_stride % 4 == 0, "conv: addend must be 16-byte aligned");
   ConvDev d;
   d.in = a->in; d.in_stride = a->in_stride; d.Cin = a->Cin;
@@ -62,7 +64,7 @@ int conv_launch(const sininn_conv_args* a, hipStream_t st) {
   d.addend = a->addend; d.addend_stride = a->addend_stride; d.addend_map = a->addend_map;
   d.mode = a->mode;
   d.ablate = g_ablate;
-  SININN_CHECK(a->mode >= 0 && a->mode <= SININN_CONV_IRN_INV, "conv: unknown mode %d", a->mode);
+  SININN_CHECK(a->mode >= 0 && a->mode <= SININN_CONV_ADD_CBWD_INV, "conv: unknown mode %d", a->mode);
   // channel chunk: the largest of 32/24/16/8 that divides Cin
   int ck = 8;
   for (int c : {32, 24, 16, 8}) if (a->Cin % c == 0) { ck = c; break; }

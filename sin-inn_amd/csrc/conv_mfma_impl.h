@@ -133,7 +133,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvDev& p, const float
             for (int j = 0; j < 4; ++j)
               if (col + j < p.N) val[j] = (p.mask[pix * p.mask_stride + col + j] > 0.f) ? val[j] : 0.f;
           }
-        } else if (MODE == SININN_CONV_ADD) {
+        } else if (MODE == SININN_CONV_ADD || MODE == SININN_CONV_ADD_CBWD_FWD || MODE == SININN_CONV_ADD_CBWD_INV) {
           if (p.bias) val += *reinterpret_cast<const f32x4*>(p.bias + col);
           if (p.addend_map == nullptr && full) {
             val += *reinterpret_cast<const f32x4*>(p.addend + pix * p.addend_stride + col);
@@ -146,7 +146,26 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvDev& p, const float
               }
           }
         }
-        if (full) {
+        if (MODE == SININN_CONV_ADD_CBWD_FWD || MODE == SININN_CONV_ADD_CBWD_INV) {
+          // val = gradient w.r.t. the first half's output y; emit (ds | dt) and dv of that half's coupling tail
+          const float gl = p.logdet ? p.logdet[b] : 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (col + j < p.N) {
+              const int c = col + j;
+              const float g = val[j];
+              const float u = p.v[pix * p.v_stride + c];
+              const float sv = p.sbuf[pix * p.Co + c];
+              const float L = glow_log_e(sv, p.clamp), dL = glow_dlog_e(sv, p.clamp);
+              const float e = expf(L);
+              float ds, dt, dvv;
+              if (MODE == SININN_CONV_ADD_CBWD_FWD) { dvv = g * e; dt = g; ds = (g * u * e + gl) * dL; }
+              else { dvv = g / e; dt = -dvv; ds = -(g * u + gl) * dL; }
+              p.out[pix * p.out_stride + c] = ds;
+              p.out[pix * p.out_stride + p.Co + c] = dt;
+              p.out2[pix * p.out2_stride + c] = dvv;
+            }
+        } else if (full) {
           *reinterpret_cast<f32x4*>(p.out + pix * p.out_stride + col) = val;
         } else {
 #pragma unroll

@@ -220,13 +220,18 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
   const int* map_a = a->dst_map ? a->dst_map + base_a : nullptr;
   const int* map_b = a->dst_map ? a->dst_map + base_b : nullptr;
 
+  // fuse: when set, the dgrad of this half's first conv also performs the coupling-tail backward of the OTHER
+  // (first-executed) half in its epilogue, writing dr_a / dx instead of the intermediate gradient
+  struct Fuse { const float* vy; int vy_stride; const float* s; float* dr; };
   auto half_bwd = [&](const Half& h, const float* hbuf, const float* sbuf, float* dr, float* dh,
                       const float* dy, int dy_stride, const int* dy_map, const float* vy, int vy_stride, const int* vy_map,
                       const float* cond, int cond_stride, int cond_cin,
-                      const float* addend, int add_stride, const int* add_map, float* dcond, int dcond_stride) -> int {
+                      const float* addend, int add_stride, const int* add_map, float* dcond, int dcond_stride,
+                      bool do_coupling, const Fuse* fuse) -> int {
     const sininn_subnet* net = h.net;
-    if (int rc = coupling_bwd_launch(dy, dy_stride, dy_map, vy, vy_stride, vy_map, sbuf, a->gld, B, HW, h.co, a->clamp, inv,
-                                     dr, a->dx + h.base, C, st)) return rc;
+    if (do_coupling)
+      if (int rc = coupling_bwd_launch(dy, dy_stride, dy_map, vy, vy_stride, vy_map, sbuf, a->gld, B, HW, h.co, a->clamp, inv,
+                                       dr, a->dx + h.base, C, st)) return rc;
     if (net->gw2) {
       if (int rc = order_after(wst, st)) return rc;
       if (int rc = wgrad_launch(hbuf, SININN_HIDDEN, SININN_HIDDEN, dr, 2 * h.co, 2 * h.co, B, H, W, k, net->gw2, net->gb2,
@@ -247,6 +252,13 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
     d1.B = B; d1.H = H; d1.W = W; d1.ksize = k; d1.mode = SININN_CONV_ADD;
     d1.out = dcond; d1.out_stride = dcond_stride; d1.N = cond_cin;
     d1.addend = addend; d1.addend_stride = add_stride; d1.addend_map = add_map;
+    if (fuse) {
+      d1.mode = inv ? SININN_CONV_ADD_CBWD_INV : SININN_CONV_ADD_CBWD_FWD;
+      d1.out = fuse->dr; d1.out_stride = 2 * cond_cin;
+      d1.v = fuse->vy; d1.v_stride = fuse->vy_stride; d1.sbuf = const_cast<float*>(fuse->s);
+      d1.out2 = a->dx + hv[0].base; d1.out2_stride = C;
+      d1.logdet = const_cast<float*>(a->gld); d1.Co = cond_cin; d1.clamp = a->clamp;
+    }
     return conv_launch(&d1, st);
   };
 
@@ -258,8 +270,13 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
     else if (a->dst_map) { vy = a->out; vy_stride = C; vy_map = map_b; }
     else { vy = a->out + base_b; vy_stride = C; }
     const float* addend = a->dst_map ? a->dout : a->dout + base_a;
+    Fuse fz;
+    fz.vy = a->rev ? sv.ybuf : a->x + base_a;
+    fz.vy_stride = a->rev ? co_a : C;
+    fz.s = sv.s_a;
+    fz.dr = sc.dr_a;
     if (int rc = half_bwd(hv[1], sv.h_b, sv.s_b, sc.dr_b, sc.dh_b, dy, C, map_b, vy, vy_stride, vy_map,
-                          sv.ybuf, co_a, co_a, addend, C, map_a, sc.dy_first, co_a)) return rc;
+                          sv.ybuf, co_a, co_a, addend, C, map_a, sc.dy_first, co_a, true, &fz)) return rc;
   }
   // ---- first half: condition = x[:, cond range]; its data gradient accumulates in place into dx ----
   {
@@ -267,7 +284,8 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
     const float* vy = a->rev ? sv.ybuf : a->x + base_a;
     const int vy_stride = a->rev ? co_a : C;
     if (int rc = half_bwd(hv[0], sv.h_a, sv.s_a, sc.dr_a, sc.dh_a, sc.dy_first, co_a, nullptr, vy, vy_stride, nullptr,
-                          a->x + cond_off, C, cond_cin, a->dx + cond_off, C, nullptr, a->dx + cond_off, C)) return rc;
+                          a->x + cond_off, C, cond_cin, a->dx + cond_off, C, nullptr, a->dx + cond_off, C, false,
+                          nullptr)) return rc;
   }
   return 0;
 }

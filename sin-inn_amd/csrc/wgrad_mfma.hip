@@ -315,8 +315,32 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   __shared__ f32x4 red[4][64];
   const int c4n = Cc >> 2;
   const int total4 = taps * Nr * c4n;                 // float4 columns of one slab
-  const int o = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int wblocks = (total4 + 63) / 64;
   const int grp = threadIdx.x >> 6;
+  if ((int)blockIdx.x >= wblocks) {
+    // ---- bias: db[n] += sum_s bpartial[s][n]; same 4-way slab split and fixed-order combine ----
+    if (gb == nullptr) return;
+    const int i = ((int)blockIdx.x - wblocks) * 64 + (threadIdx.x & 63);
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    if (i < N) {
+      int k = grp;
+      for (; k + 12 < S; k += 16) {
+        b0 += bpartial[(size_t)k * Nr + i];
+        b1 += bpartial[(size_t)(k + 4) * Nr + i];
+        b2 += bpartial[(size_t)(k + 8) * Nr + i];
+        b3 += bpartial[(size_t)(k + 12) * Nr + i];
+      }
+      for (; k < S; k += 4) b0 += bpartial[(size_t)k * Nr + i];
+    }
+    red[grp][threadIdx.x & 63][0] = (b0 + b1) + (b2 + b3);
+    __syncthreads();
+    if (grp == 0 && i < N) {
+      const int l = threadIdx.x;
+      gb[i] += (red[0][l][0] + red[1][l][0]) + (red[2][l][0] + red[3][l][0]);
+    }
+    return;
+  }
+  const int o = blockIdx.x * 64 + (threadIdx.x & 63);
   const bool live = o < total4;
   const size_t stride4 = (size_t)total4;
   const f32x4* p4 = reinterpret_cast<const f32x4*>(partial);
@@ -342,32 +366,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       for (int j = 0; j < 4; ++j)
         if (c0 + j < Cin) gw[((size_t)n * Cin + c0 + j) * taps + t] += tot[j];
     }
-  }
-}
-
-// db[n] += sum_s bpartial[s][n]: same 4-way slab split / fixed-order combine, one block per 64 bias entries
-// (a serial loop over S dependent loads used to dominate the reduce kernel's run time)
-__global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __restrict__ bpartial, int S, int Nr, int N,
-                                                                float* __restrict__ gb) {
-  __shared__ float red[4][64];
-  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int grp = threadIdx.x >> 6;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (i < N) {
-    int k = grp;
-    for (; k + 12 < S; k += 16) {
-      s0 += bpartial[(size_t)k * Nr + i];
-      s1 += bpartial[(size_t)(k + 4) * Nr + i];
-      s2 += bpartial[(size_t)(k + 8) * Nr + i];
-      s3 += bpartial[(size_t)(k + 12) * Nr + i];
-    }
-    for (; k < S; k += 4) s0 += bpartial[(size_t)k * Nr + i];
-  }
-  red[grp][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (grp == 0 && i < N) {
-    const int l = threadIdx.x;
-    gb[i] += (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
   }
 }
 
@@ -436,13 +434,10 @@ int wgrad_launch(const float* in, int in_stride, int Cin, const float* dout, int
   if (ksize == 3) launch_wgrad<3>(pl, d, st); else launch_wgrad<1>(pl, d, st);
   SININN_LAUNCH_CHECK("wgrad_mfma");
   const int total4 = taps * pl.Nr * (pl.Cc / 4);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total4 + 63) / 64), dim3(256), 0, st,
+  const int bias_blocks = gb ? (N + 63) / 64 : 0;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total4 + 63) / 64 + bias_blocks), dim3(256), 0, st,
                      d.partial, d.bpartial, pl.S, taps, pl.Nr, pl.Cc, N, Cin, gw, gb);
   SININN_LAUNCH_CHECK("wgrad_reduce");
-  if (gb != nullptr) {
-    hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((N + 63) / 64), dim3(256), 0, st, d.bpartial, pl.S, pl.Nr, N, gb);
-    SININN_LAUNCH_CHECK("wgrad_bias_reduce");
-  }
   return 0;
 }
 
