@@ -109,7 +109,7 @@ def main():
     from sin_inn_amd import dist as sdist
     rank, ws = sdist.init_from_env()
     assert ws == args.gpus or (ws == 1 and args.gpus == 1), f'--gpus {args.gpus} but WORLD_SIZE={ws}'
-    local = int(os.environ.get('LOCAL_RANK', 0))
+    local = sdist.local_device_index()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
@@ -160,7 +160,7 @@ def main():
     dt = time.perf_counter() - t0
     timer.stop()
     if ws > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if torch.distributed.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 

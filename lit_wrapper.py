@@ -27,7 +27,7 @@ _SECOND = {}
 def _second_stream(device):
     key = str(device)
     if key not in _SECOND:
-        _SECOND[key] = torch.cuda.Stream(device=device)
+        _SECOND[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get('SININN_PASS2_PRIO', '0')))
     return _SECOND[key]
 
 

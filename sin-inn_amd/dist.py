@@ -8,6 +8,13 @@ import torch
 import torch.distributed as dist
 
 
+def local_device_index():
+    """GPU of this rank: LOCAL_RANK, unless SININN_FORCE_DEVICE pins every rank to one device (rehearsals of the
+    multi-rank path on a single-GPU box, together with SININN_DIST_BACKEND=gloo)."""
+    forced = os.environ.get('SININN_FORCE_DEVICE')
+    return int(forced) if forced is not None else int(os.environ.get('LOCAL_RANK', '0'))
+
+
 def world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
@@ -22,9 +29,9 @@ def init_from_env(backend=None):
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        backend = os.environ.get('SININN_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
     if backend == 'nccl':
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        torch.cuda.set_device(local_device_index())
     dist.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=ws)
     return world()
 

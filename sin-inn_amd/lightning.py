@@ -141,7 +141,7 @@ class Trainer:
     def _device(self):
         rank, ws = sdist.init_from_env()
         if ws > 1:
-            return torch.device('cuda', int(os.environ.get('LOCAL_RANK', rank)))
+            return torch.device('cuda', sdist.local_device_index())
         return torch.device('cuda', self.gpus[0])
 
     def save_checkpoint(self, model, path):

@@ -104,7 +104,8 @@ USE_SIDE_STREAM = [True]
 def _side_stream(device):
     key = str(device)
     if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=device)
+        import os
+        _SIDE[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get('SININN_WGRAD_PRIO', '0')))
     return _SIDE[key]
 
 
