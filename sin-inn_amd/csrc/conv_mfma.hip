@@ -9,6 +9,7 @@ int conv_dispatch_k1(ConvDev& d, hipStream_t st, int force_cfg);
 int conv32_dispatch_k3(ConvDev& d, hipStream_t st, int force_cfg, bool must);
 int conv32_dispatch_k1(ConvDev& d, hipStream_t st, int force_cfg, bool must);
 
+int g_conv_dma = 0;
 static int g_force_cfg = 0;   // test hook: 0 auto, 1 force 8-row tiles, 2 force 4-row tiles
 static int g_force_ck = 0;
 static int g_ablate = 0;     // diagnostic: see ConvDev::ablate (results are wrong when set)    // test hook: override the channel chunk
@@ -83,6 +84,11 @@ int conv_launch(const sininn_conv_args* a, hipStream_t st) {
   return conv_dispatch_k1(d, st, fc);
 }
 
-void conv_set_test_hooks(int force_cfg, int force_ck) { g_force_cfg = force_cfg % 1000; g_force_ck = force_ck; g_ablate = force_cfg / 1000; }
+void conv_set_test_hooks(int force_cfg, int force_ck) {
+  // force_cfg = ablate*1000 + dma*100 + cfg   (cfg >= 10 pins the 16-wide kernel; dma: 1 on, 2 off, 0 default)
+  g_force_cfg = force_cfg % 100; g_force_ck = force_ck; g_ablate = force_cfg / 1000;
+  const int dma = (force_cfg / 100) % 10;
+  if (dma) g_conv_dma = (dma == 1);
+}
 
 }  // namespace sininn

@@ -37,7 +37,7 @@ def nchw(t):           # (B,H,W,C) cuda -> (B,C,H,W) cpu
 @pytest.mark.parametrize('ksize', [3, 1])
 @pytest.mark.parametrize('cin,n,hw', [(24, 256, (16, 32)), (96, 256, (8, 16)), (256, 48, (16, 16)),
                                       (256, 192, (12, 20)), (48, 256, (9, 17)), (8, 24, (5, 7))])
-@pytest.mark.parametrize('force', [(0, 0), (1, 8), (2, 16), (10, 0), (12, 16)])   # >=10: pin the 16-wide MFMA kernel
+@pytest.mark.parametrize('force', [(0, 0), (1, 8), (2, 16), (10, 0), (12, 16), (100, 0), (200, 0)])   # >=10: pin the 16-wide MFMA kernel
 def test_conv_relu_and_linear(env, ksize, cin, n, hw, force):
     S, O, dev = env
     from sin_inn_amd import ops, _lib

@@ -183,3 +183,44 @@ def test_full_size_properties():
     assert relerr(back, x) < RTOL
     assert relerr(ld_r, -ld_f) < 1e-3
     assert torch.isfinite(y).all()
+
+
+@pytest.mark.parametrize('shape,b,c', [((40, 56), 1, 1), ((24, 136), 3, 2), ((72, 80), 2, 1)])
+def test_ragged_sizes_round_trip_and_oracle(shape, b, c):
+    """image sizes whose level-0 / level-1 grids are not multiples of the 8x16 pixel tile (boundary masking), B=1."""
+    import archs
+    from oracle import sininn_oracle as O
+    torch.manual_seed(shape[0] + b)
+    h, w = shape
+    opt = make_opt(num_coupling=c)
+    net = archs.UncondSRFlow(3, h, w, opt)
+    ref = O.SRFlowOracle(3, h, w, scale=4, num_coupling=c)
+    copy_weights(ref, net)
+    net.cuda()
+    x = torch.rand(b, 3, h, w)
+    xg = x.cuda().requires_grad_(True); xc = x.clone().requires_grad_(True)
+    yg, yc = net(xg), ref(xc)
+    assert relerr(yg, yc) < RTOL
+    (yg ** 2).sum().backward(); (yc ** 2).sum().backward()
+    assert relerr(xg.grad, xc.grad) < RTOL
+    import sin_inn_amd
+    sin_inn_amd.modules.join_side_streams()
+    for (n, pg), (_, pc) in zip(net.named_parameters(), ref.named_parameters()):
+        assert relerr(pg.grad, pc.grad) < 3e-4, n
+    with torch.no_grad():
+        assert relerr(net(yg.detach(), rev=True), x) < RTOL
+
+
+def test_bigger_configs_properties():
+    """BASELINE configs 4/5 shapes in fp32 (512x512 -c 4; 720p -c 2): round trip + log-det antisymmetry."""
+    import archs
+    for (h, w, b, c) in ((512, 512, 2, 4), (720, 1280, 1, 2)):
+        torch.manual_seed(1)
+        net = archs.UncondSRFlow(3, h, w, make_opt(num_coupling=c, lr_window=10)).cuda()
+        x = torch.rand(b, 3, h, w, device='cuda')
+        with torch.no_grad():
+            y = net(x); ld = net.log_jacobian(); back = net(y, rev=True); ld2 = net.log_jacobian()
+        assert y.shape == (b, 192, h // 8, w // 8) and torch.isfinite(y).all()
+        assert relerr(back, x) < RTOL and relerr(ld2, -ld) < 1e-3
+        del net, x, y, back
+        torch.cuda.empty_cache()
