@@ -49,6 +49,12 @@ int sininn_pack_conv_weights(const float* w_oihw, const float* bias, int N, int 
                              const int* colmap, int Np, float* w_fwd, float* b_fwd,
                              int Cdp, float* w_dgrad, void* stream);
 
+/* Winograd F(2x2,3x3) filter transform of a 3x3 conv weight (U = G g G^T), same row / column conventions as
+ * sininn_pack_conv_weights with the tap axis replaced by the 16 transform positions:
+ *   u_fwd [16][Np][Cin], u_dgrad [16][Cdp][N] (flipped taps).  Either destination may be NULL. */
+int sininn_pack_winograd(const float* w_oihw, int N, int Cin, const int* colmap, int Np, float* u_fwd,
+                         int Cdp, float* u_dgrad, void* stream);
+
 /* Packed column order used by the coupling epilogue for a subnet with 2*Co outputs (s | t):
  * `tile`-column MFMA tile q = [ s[h*q .. h*q+h-1] | t[h*q .. h*q+h-1] ], h = tile/2, tile in {16, 32}
  * (tile 32 needs Co % 16 == 0).  Writes 2*Co ints (host memory).  The same `tile` must be passed as
@@ -84,6 +90,7 @@ enum sininn_conv_mode {
 typedef struct sininn_conv_args {
   const float* in;   int in_stride;  int Cin;      /* Cin % 8 == 0                                         */
   const float* w;    const float* bias; int Np;    /* packed weights [taps][Np][Cin], Np % 16 == 0         */
+  int winograd;                                    /* 1: w is the Winograd pack U[16][Np][Cin] (ksize 3, Np % 32 == 0) */
   int B, H, W, ksize;                              /* ksize 1 or 3, zero padding ksize/2                   */
   int mode;
   float* out;        int out_stride; int N;        /* generic modes: N valid output columns                */
@@ -155,6 +162,8 @@ typedef struct sininn_subnet {
   const float* w1_dgrad;                 /* [taps][pad16(Cin)][256]  (backward only)                           */
   const float* w2_dgrad;                 /* [taps][256][2*Co]        (backward only)                           */
   float* gw1; float* gb1; float* gw2; float* gb2;   /* OIHW gradient accumulators (NULL: skip)                 */
+  int winograd;                          /* bit 0: w1, bit 1: w2, bit 2: w1_dgrad (rows padded to 32), bit 3: w2_dgrad
+                                            hold Winograd packs (sininn_pack_winograd) instead of tap-major packs   */
 } sininn_subnet;
 
 typedef struct sininn_glow_args {

@@ -20,7 +20,7 @@ class ConvArgs(C.Structure):
     """Mirror of sininn_conv_args (include/sininn.h)."""
     _fields_ = [
         ('inp', c_f), ('in_stride', C.c_int), ('Cin', C.c_int),
-        ('w', c_f), ('bias', c_f), ('Np', C.c_int),
+        ('w', c_f), ('bias', c_f), ('Np', C.c_int), ('winograd', C.c_int),
         ('B', C.c_int), ('H', C.c_int), ('W', C.c_int), ('ksize', C.c_int),
         ('mode', C.c_int),
         ('out', c_f), ('out_stride', C.c_int), ('N', C.c_int),
@@ -38,7 +38,7 @@ class ConvArgs(C.Structure):
 class SubnetArgs(C.Structure):
     """Mirror of sininn_subnet."""
     _fields_ = [('w1', c_f), ('b1', c_f), ('w2', c_f), ('b2', c_f), ('w1_dgrad', c_f), ('w2_dgrad', c_f),
-                ('gw1', c_f), ('gb1', c_f), ('gw2', c_f), ('gb2', c_f)]
+                ('gw1', c_f), ('gb1', c_f), ('gw2', c_f), ('gb2', c_f), ('winograd', C.c_int)]
 
 
 class GlowArgs(C.Structure):
@@ -57,6 +57,7 @@ _SIGS = {
     'sininn_version': (C.c_int, []),
     'sininn_last_error': (C.c_char_p, []),
     'sininn_pack_conv_weights': (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, c_i, C.c_int, c_f, c_f, C.c_int, c_f, C.c_void_p]),
+    'sininn_pack_winograd': (C.c_int, [c_f, C.c_int, C.c_int, c_i, C.c_int, c_f, C.c_int, c_f, C.c_void_p]),
     'sininn_coupling_colmap': (None, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
     'sininn_conv': (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     'sininn_conv_test_hooks': (None, [C.c_int, C.c_int]),

@@ -62,6 +62,8 @@ int irn_coupling_bwd_launch(const float* dy, int dy_stride, const float* vy, int
                             hipStream_t st);
 void profile_begin(int h);
 int profile_end(int* count, float* total_ms);
+int pack_winograd_launch(const float* w, int N, int Cin, const int* colmap, int Np, float* u_fwd, int Cdp,
+                         float* u_dgrad, hipStream_t st);
 int bayer_bin_launch(const uint8_t* hr, uint8_t* lr, int T, int H, int W, int scale, int reduce_sum, hipStream_t st);
 size_t glow_saved_floats(int B, int H, int W, int C);
 size_t glow_scratch_bytes(int B, int H, int W, int C, int ksize);
@@ -80,6 +82,11 @@ const char* sininn_last_error(void) { return g_err; }
 int sininn_pack_conv_weights(const float* w_oihw, const float* bias, int N, int Cin, int ksize, const int* colmap,
                              int Np, float* w_fwd, float* b_fwd, int Cdp, float* w_dgrad, void* stream) {
   return pack_launch(w_oihw, bias, N, Cin, ksize, colmap, Np, w_fwd, b_fwd, Cdp, w_dgrad, ST(stream));
+}
+
+int sininn_pack_winograd(const float* w_oihw, int N, int Cin, const int* colmap, int Np, float* u_fwd, int Cdp,
+                         float* u_dgrad, void* stream) {
+  return pack_winograd_launch(w_oihw, N, Cin, colmap, Np, u_fwd, Cdp, u_dgrad, ST(stream));
 }
 
 void sininn_coupling_colmap(int Co, int tile, int* colmap_host) {

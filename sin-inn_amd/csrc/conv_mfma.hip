@@ -8,6 +8,7 @@ int conv_dispatch_k3(ConvDev& d, hipStream_t st, int force_cfg);
 int conv_dispatch_k1(ConvDev& d, hipStream_t st, int force_cfg);
 int conv32_dispatch_k3(ConvDev& d, hipStream_t st, int force_cfg, bool must);
 int conv32_dispatch_k1(ConvDev& d, hipStream_t st, int force_cfg, bool must);
+int wino_dispatch_k3(ConvDev& d, hipStream_t st);
 
 int g_conv_dma = 0;
 static int g_force_cfg = 0;   // test hook: 0 auto, 1 force 8-row tiles, 2 force 4-row tiles
@@ -64,6 +65,7 @@ int conv_launch(const sininn_conv_args* a, hipStream_t st) {
   d.mask = a->mask; d.mask_stride = a->mask_stride;
   d.addend = a->addend; d.addend_stride = a->addend_stride; d.addend_map = a->addend_map;
   d.mode = a->mode;
+  d.col_tile = a->col_tile;
   d.ablate = g_ablate;
   SININN_CHECK(a->mode >= 0 && a->mode <= SININN_CONV_ADD_CBWD_INV, "conv: unknown mode %d", a->mode);
   // channel chunk: the largest of 32/24/16/8 that divides Cin
@@ -71,6 +73,12 @@ int conv_launch(const sininn_conv_args* a, hipStream_t st) {
   for (int c : {32, 24, 16, 8}) if (a->Cin % c == 0) { ck = c; break; }
   if (g_force_ck && a->Cin % g_force_ck == 0 && g_force_ck % 8 == 0 && g_force_ck <= 32) ck = g_force_ck;
   d.CK = ck;
+  if (a->winograd) {
+    SININN_CHECK(a->ksize == 3, "conv: the Winograd pack needs ksize 3");
+    d.col_tile = (couple && a->col_tile == 32) ? 32 : 16;
+    if (couple && d.col_tile == 32) SININN_CHECK(a->Co % 16 == 0, "conv: col_tile 32 needs Co %% 16 == 0");
+    return wino_dispatch_k3(d, st);
+  }
   // column-tile width: coupling weights are packed for one specific width (col_tile); other modes take the
   // 32-wide MFMA shape whenever the column count allows (g_force_cfg >= 10 pins the 16-wide kernel for tests)
   const int tile = couple ? (a->col_tile == 32 ? 32 : 16) : ((a->Np % 32 == 0 && g_force_cfg < 10) ? 32 : 16);

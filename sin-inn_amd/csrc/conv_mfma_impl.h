@@ -32,6 +32,7 @@ struct ConvDev {
   const float* addend; int addend_stride; const int* addend_map;
   int tiles_x, tiles_y;
   int mode;
+  int col_tile;   // coupling (s|t) interleave width of the packed weights (16 or 32)
   int ablate;   // diagnostic only (tools/bench_kernels.py --ablate): 1 skip staging, 2 skip loop barrier, 4 skip LDS reads
 };
 

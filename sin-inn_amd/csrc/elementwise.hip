@@ -841,4 +841,67 @@ int bayer_bin_launch(const uint8_t* hr, uint8_t* lr, int T, int H, int W, int sc
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Winograd F(2x2,3x3) filter transform U = G g G^T (G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]), packed like the
+// direct weights with the tap axis replaced by the 16 transform positions:
+//   u_fwd  [16][Np ][Cin]  g[a][b] = w[colmap[q]][c][a][b]
+//   u_dgrad[16][Cdp][N  ]  g[a][b] = w[n][c][2-a][2-b]   (data-gradient conv: flipped taps, channel roles swapped)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wino_filter(const float* g, float* u) {   // g[9] row-major -> u[16]
+  float t[4][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    t[0][b] = g[b];
+    t[1][b] = 0.5f * (g[b] + g[3 + b] + g[6 + b]);
+    t[2][b] = 0.5f * (g[b] - g[3 + b] + g[6 + b]);
+    t[3][b] = g[6 + b];
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    u[a * 4 + 0] = t[a][0];
+    u[a * 4 + 1] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
+    u[a * 4 + 2] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
+    u[a * 4 + 3] = t[a][2];
+  }
+}
+
+__global__ void pack_winograd_kernel(const float* __restrict__ w, int N, int Cin, const int* __restrict__ colmap,
+                                     int Np, float* __restrict__ u_fwd, int Cdp, float* __restrict__ u_dgrad) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nf = u_fwd ? Np * Cin : 0;
+  const int nd = u_dgrad ? Cdp * N : 0;
+  float g[9], u[16];
+  if (idx < nf) {
+    const int c = idx % Cin, q = idx / Cin;
+    const int n = colmap ? colmap[q] : q;
+    const bool ok = n >= 0 && n < N;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t] = ok ? w[((size_t)n * Cin + c) * 9 + t] : 0.f;
+    wino_filter(g, u);
+#pragma unroll
+    for (int pz = 0; pz < 16; ++pz) u_fwd[((size_t)pz * Np + q) * Cin + c] = u[pz];
+  } else if (idx < nf + nd) {
+    const int k = idx - nf;
+    const int n = k % N, c = k / N;
+    const bool ok = c < Cin;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t] = ok ? w[((size_t)n * Cin + c) * 9 + (8 - t)] : 0.f;
+    wino_filter(g, u);
+#pragma unroll
+    for (int pz = 0; pz < 16; ++pz) u_dgrad[((size_t)pz * Cdp + c) * N + n] = u[pz];
+  }
+}
+
+int pack_winograd_launch(const float* w, int N, int Cin, const int* colmap, int Np, float* u_fwd, int Cdp,
+                         float* u_dgrad, hipStream_t st) {
+  SININN_CHECK(w != nullptr && N > 0 && Cin > 0 && (u_fwd || u_dgrad), "pack_winograd: bad arguments");
+  SININN_CHECK(!u_fwd || Np >= 1, "pack_winograd: bad Np");
+  SININN_CHECK(!u_dgrad || Cdp >= Cin, "pack_winograd: Cdp < Cin");
+  const int total = (u_fwd ? Np * Cin : 0) + (u_dgrad ? Cdp * N : 0);
+  hipLaunchKernelGGL(pack_winograd_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, N, Cin, colmap, Np, u_fwd,
+                     Cdp, u_dgrad);
+  SININN_LAUNCH_CHECK("pack_winograd");
+  return 0;
+}
+
 }  // namespace sininn

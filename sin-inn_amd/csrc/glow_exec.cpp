@@ -181,13 +181,13 @@ int glow_forward(const sininn_glow_args* a, hipStream_t st) {
     sininn_conv_args c1 = {};
     if (i == 0) { c1.in = a->x + h.cond_off; c1.in_stride = C; c1.Cin = C - h.co; }
     else { c1.in = sv.ybuf; c1.in_stride = hv[0].co; c1.Cin = hv[0].co; }
-    c1.w = h.net->w1; c1.bias = h.net->b1; c1.Np = SININN_HIDDEN;
+    c1.w = h.net->w1; c1.bias = h.net->b1; c1.Np = SININN_HIDDEN; c1.winograd = (h.net->winograd & 1) && a->ksize == 3;
     c1.B = a->B; c1.H = a->H; c1.W = a->W; c1.ksize = a->ksize; c1.mode = SININN_CONV_RELU;
     c1.out = hbuf; c1.out_stride = SININN_HIDDEN; c1.N = SININN_HIDDEN;
     if (int rc = conv_launch(&c1, st)) return rc;
     sininn_conv_args c2 = {};
     c2.in = hbuf; c2.in_stride = SININN_HIDDEN; c2.Cin = SININN_HIDDEN;
-    c2.w = h.net->w2; c2.bias = h.net->b2; c2.Np = 2 * h.co;
+    c2.w = h.net->w2; c2.bias = h.net->b2; c2.Np = 2 * h.co; c2.winograd = (h.net->winograd & 2) && a->ksize == 3;
     c2.B = a->B; c2.H = a->H; c2.W = a->W; c2.ksize = a->ksize; c2.mode = mode;
     if (a->dst_map) { c2.out = a->out; c2.out_map = a->dst_map + h.base; }
     else { c2.out = a->out + h.base; c2.out_map = nullptr; }
@@ -239,6 +239,7 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
     }
     sininn_conv_args d2 = {};
     d2.in = dr; d2.in_stride = 2 * h.co; d2.Cin = 2 * h.co; d2.w = net->w2_dgrad; d2.Np = SININN_HIDDEN;
+    d2.winograd = (net->winograd & 8) && k == 3;
     d2.B = B; d2.H = H; d2.W = W; d2.ksize = k; d2.mode = SININN_CONV_MASK;
     d2.out = dh; d2.out_stride = SININN_HIDDEN; d2.N = SININN_HIDDEN; d2.mask = hbuf; d2.mask_stride = SININN_HIDDEN;
     if (int rc = conv_launch(&d2, st)) return rc;
@@ -248,7 +249,9 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
                                 sc.ws, sc.ws_bytes, wst)) return rc;
     }
     sininn_conv_args d1 = {};
-    d1.in = dh; d1.in_stride = SININN_HIDDEN; d1.Cin = SININN_HIDDEN; d1.w = net->w1_dgrad; d1.Np = pad16i(cond_cin);
+    d1.in = dh; d1.in_stride = SININN_HIDDEN; d1.Cin = SININN_HIDDEN; d1.w = net->w1_dgrad;
+    d1.winograd = (net->winograd & 4) && k == 3;
+    d1.Np = d1.winograd ? (cond_cin + 31) / 32 * 32 : pad16i(cond_cin);
     d1.B = B; d1.H = H; d1.W = W; d1.ksize = k; d1.mode = SININN_CONV_ADD;
     d1.out = dcond; d1.out_stride = dcond_stride; d1.N = cond_cin;
     d1.addend = addend; d1.addend_stride = add_stride; d1.addend_map = add_map;

@@ -1,0 +1,215 @@
+// Winograd F(2x2, 3x3) convolution on v_mfma_f32_16x16x4_f32: 2.25x fewer MFMA FLOPs than the direct
+// implicit GEMM for the 3x3 subnet convs (archs.py:11-13) and their data gradients.
+//
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A      d: 4x4 input patch, g: 3x3 filter, Y: 2x2 outputs
+//
+//   * block  = 16x16 output pixels (8x8 Winograd tiles) x 32 packed columns; 4 waves = 4 groups of 16 tiles.
+//   * the filter transform U = G g G^T is done once per weight update by the pack kernel:
+//     U[pos 16][column][cin] (k-contiguous rows), so per position the kernel runs a plain
+//     [16 tiles x K] x [K x 16 columns] MFMA product, accumulating all 16 positions in registers
+//     (16 pos x 2 column tiles x 4 regs = 128 accumulator VGPRs per lane).
+//   * the input transform V = B^T d B is done PER LANE in registers: the MFMA A operand of lane (tile i, k-lane kq)
+//     for position p is V_p[tile i][channel kq] -- exactly what the lane obtains by transforming the 4x4 patch of its
+//     own (tile, channel pair) read from the LDS halo tile; no transformed tile is ever stored.
+//   * the output transform Y = A^T M A is also per lane: the D layout keeps all 16 positions of a (tile, column) pair
+//     in the same lane.  The 2x2 results go through the LDS tile T[pixel][32+4] and the shared float4 epilogue
+//     (ReLU / coupling / mask / add), exactly like the direct kernels.
+//   * K loop: channel chunks of 8 (one ds_read_b64 = channels 2kq, 2kq+1 -> two MFMAs), halo tile and U chunk
+//     double-buffered through VGPRs -> LDS, one barrier per chunk.
+#pragma once
+#include "conv_mfma_impl.h"
+
+namespace sininn {
+
+template <int NT, int HT>
+__global__ __launch_bounds__(256, 2) void wino_kernel(ConvDev p) {
+  constexpr int CK = 8;
+  constexpr int IW = 18, NPIX_IN = 18 * 18;
+  constexpr int BN = NT * 16;
+  constexpr int SI = 12, SU = 12;                       // LDS row strides (floats): 8 channels + 4 pad
+  constexpr int IN_F4 = (NPIX_IN * 2 + 255) / 256;      // 2 float4 per pixel
+  constexpr int U_F4 = (16 * BN * 2 + 255) / 256;
+  constexpr int IN_BUF = NPIX_IN * SI, U_BUF = 16 * BN * SU;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const in_lds0 = smem;
+  float* const in_lds1 = smem + IN_BUF;
+  float* const u_lds0 = smem + 2 * IN_BUF;
+  float* const u_lds1 = u_lds0 + U_BUF;
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, kq = lane >> 4;
+
+  int bid = blockIdx.x;
+  const int tx = bid % p.tiles_x; bid /= p.tiles_x;
+  const int ty = bid % p.tiles_y;
+  const int b = bid / p.tiles_y;
+  const int y0 = ty * 16, x0 = tx * 16;
+  const int n0 = blockIdx.y * BN;
+
+  // ---- staging descriptors ---------------------------------------------------------------------
+  int in_goff[IN_F4], in_loff[IN_F4];
+#pragma unroll
+  for (int r = 0; r < IN_F4; ++r) {
+    const int f = tid + 256 * r;
+    const int pix = f >> 1, c4 = f & 1;
+    const int py = pix / IW, px = pix - py * IW;
+    const int gy = y0 + py - 1, gx = x0 + px - 1;
+    const bool inside = pix < NPIX_IN;
+    const bool inimg = inside && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    in_loff[r] = inside ? (pix * SI + c4 * 4) : -1;
+    in_goff[r] = inimg ? (((b * p.H + gy) * p.W + gx) * p.in_stride + c4 * 4) : -1;
+  }
+  int u_goff[U_F4], u_loff[U_F4];
+#pragma unroll
+  for (int r = 0; r < U_F4; ++r) {
+    const int f = tid + 256 * r;
+    const int c4 = f & 1, col = (f >> 1) % BN, pos = (f >> 1) / BN;
+    const bool inside = pos < 16;
+    u_loff[r] = inside ? ((pos * BN + col) * SU + c4 * 4) : -1;
+    u_goff[r] = (inside && (n0 + col) < p.Np) ? ((pos * p.Np + n0 + col) * p.Cin + c4 * 4) : -1;
+  }
+  const int nchunks = p.Cin / CK;
+
+  f32x4 in_reg[IN_F4], u_reg[U_F4];
+  auto load_chunk = [&](int chunk) {
+#pragma unroll
+    for (int r = 0; r < IN_F4; ++r) {
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      in_reg[r] = (in_goff[r] >= 0) ? *reinterpret_cast<const f32x4*>(p.in + in_goff[r] + chunk * CK) : z;
+    }
+#pragma unroll
+    for (int r = 0; r < U_F4; ++r) {
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      u_reg[r] = (u_goff[r] >= 0) ? *reinterpret_cast<const f32x4*>(p.w + u_goff[r] + chunk * CK) : z;
+    }
+  };
+  auto store_chunk = [&](float* idst, float* udst) {
+#pragma unroll
+    for (int r = 0; r < IN_F4; ++r)
+      if (in_loff[r] >= 0) *reinterpret_cast<f32x4*>(idst + in_loff[r]) = in_reg[r];
+#pragma unroll
+    for (int r = 0; r < U_F4; ++r)
+      if (u_loff[r] >= 0) *reinterpret_cast<f32x4*>(udst + u_loff[r]) = u_reg[r];
+  };
+
+  // this lane's Winograd tile for the A operand (tile = 16*wave + li) and its patch origin in the halo tile
+  const int a_ty = 2 * wave + (li >> 3), a_tx = li & 7;
+  const int a_base = ((2 * a_ty) * IW + 2 * a_tx) * SI + 2 * kq;
+  const int b_base = li * SU + 2 * kq;
+
+  f32x4 acc[16][NT];
+#pragma unroll
+  for (int q = 0; q < 16; ++q)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[q][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  load_chunk(0);
+  store_chunk(in_lds0, u_lds0);
+  if (nchunks > 1) load_chunk(1);
+  __syncthreads();
+
+  for (int it = 0; it < nchunks; ++it) {
+    if (!(p.ablate & 1)) {
+      if (it + 1 < nchunks) store_chunk(((it + 1) & 1) ? in_lds1 : in_lds0, ((it + 1) & 1) ? u_lds1 : u_lds0);
+      if (it + 2 < nchunks) load_chunk(it + 2);
+    }
+    const float* A = ((it & 1) ? in_lds1 : in_lds0) + a_base;
+    const float* Uc = ((it & 1) ? u_lds1 : u_lds0) + b_base;
+
+    // ---- input transform V = B^T d B for (this lane's tile, channels 2kq / 2kq+1) -----------------
+    float2 v[4][4];
+    if (p.ablate & 4) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[a][c] = make_float2(1.f + a, 2.f + c);
+    } else {
+      float2 d[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[a][c] = *reinterpret_cast<const float2*>(A + (a * IW + c) * SI);
+      float2 t[4][4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        t[0][c] = make_float2(d[0][c].x - d[2][c].x, d[0][c].y - d[2][c].y);
+        t[1][c] = make_float2(d[1][c].x + d[2][c].x, d[1][c].y + d[2][c].y);
+        t[2][c] = make_float2(d[2][c].x - d[1][c].x, d[2][c].y - d[1][c].y);
+        t[3][c] = make_float2(d[1][c].x - d[3][c].x, d[1][c].y - d[3][c].y);
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        v[a][0] = make_float2(t[a][0].x - t[a][2].x, t[a][0].y - t[a][2].y);
+        v[a][1] = make_float2(t[a][1].x + t[a][2].x, t[a][1].y + t[a][2].y);
+        v[a][2] = make_float2(t[a][2].x - t[a][1].x, t[a][2].y - t[a][1].y);
+        v[a][3] = make_float2(t[a][1].x - t[a][3].x, t[a][1].y - t[a][3].y);
+      }
+    }
+    // ---- 16 positions x NT column tiles x 2 k-steps -----------------------------------------------
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      float2 bf[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const float2*>(Uc + ((q * BN + n * 16) * SU));
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q >> 2][q & 3].x, bf[n].x, acc[q][n], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q >> 2][q & 3].y, bf[n].y, acc[q][n], 0, 0, 0);
+    }
+    if (!(p.ablate & 2)) __syncthreads();
+  }
+
+  // ---- output transform Y = A^T M A per lane, 2x2 results -> LDS tile T[pixel][BN+4] ---------------
+  // lane holds M_q[tile = 16*wave + 4*kq + r][col = li] in acc[q][n][r]
+  {
+    constexpr int TS = BN + 4;
+    float* const T = smem;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float m[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) m[q] = acc[q][n][r];
+        float r0[4], r1[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          r0[c] = m[0 * 4 + c] + m[1 * 4 + c] + m[2 * 4 + c];
+          r1[c] = m[1 * 4 + c] - m[2 * 4 + c] - m[3 * 4 + c];
+        }
+        const int tl = 4 * kq + r;
+        const int oy = 2 * (2 * wave + (tl >> 3)), ox = 2 * (tl & 7);
+        float* t00 = T + (oy * 16 + ox) * TS + n * 16 + li;
+        t00[0] = r0[0] + r0[1] + r0[2];
+        t00[TS] = r0[1] - r0[2] - r0[3];
+        t00[16 * TS] = r1[0] + r1[1] + r1[2];
+        t00[17 * TS] = r1[1] - r1[2] - r1[3];
+      }
+    __syncthreads();
+    __shared__ float red[4];
+    conv_epilogue_tile<16, BN, HT>(p, T, b, y0, x0, n0, tid, red);
+  }
+}
+
+static int wino_dispatch(ConvDev& d, hipStream_t st) {
+  constexpr int NT = 2, BN = NT * 16;
+  constexpr size_t lds_main = (size_t)(2 * 18 * 18 * 12 + 2 * 16 * BN * 12) * sizeof(float);
+  constexpr size_t lds_epi = (size_t)256 * (BN + 4) * sizeof(float);
+  constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  d.tiles_x = (d.W + 15) / 16;
+  d.tiles_y = (d.H + 15) / 16;
+  dim3 grid(d.tiles_x * d.tiles_y * d.B, (d.Np + BN - 1) / BN);
+  // HT = half-width of the coupling (s|t) column interleave the weights were packed with (16 or 8)
+  auto k = (d.col_tile == 16) ? wino_kernel<NT, 8> : wino_kernel<NT, 16>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) { set_error("wino: cannot raise LDS limit to %zu", lds); return 1; }
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, d);
+  SININN_LAUNCH_CHECK("wino");
+  return 0;
+}
+
+}  // namespace sininn

@@ -78,15 +78,21 @@ def inspect_subnet(seq):
     return seq[0], seq[2], k
 
 
+# Winograd F(2x2,3x3) for the 3x3 convs whose packed column count is a multiple of 32 (SININN_WINOGRAD=0 disables)
+import os as _os
+USE_WINOGRAD = [_os.environ.get('SININN_WINOGRAD', '1') != '0']
+
+
 class _PackCache:
     def __init__(self):
         self.store = {}
 
-    def get(self, conv, colmap, want_dgrad):
-        key = (conv.weight.data_ptr(), conv.weight._version, conv.bias._version, WEIGHTS_EPOCH[0], want_dgrad)
+    def get(self, conv, colmap, want_dgrad, wino_fwd=False, wino_dgrad=False):
+        key = (conv.weight.data_ptr(), conv.weight._version, conv.bias._version, WEIGHTS_EPOCH[0], want_dgrad,
+               wino_fwd, wino_dgrad)
         hit = self.store.get(id(conv))
         if hit is None or hit[0] != key:
-            packs = ops.pack_conv(conv.weight.detach(), conv.bias.detach(), colmap, want_dgrad)
+            packs = ops.pack_conv(conv.weight.detach(), conv.bias.detach(), colmap, want_dgrad, wino_fwd, wino_dgrad)
             hit = (key, packs)
             self.store[id(conv)] = hit
         return hit[1]
@@ -131,11 +137,14 @@ def _pv(t, off=0):
 
 
 def _subnet_args(block, seq, co, dev, need_grad, with_grads):
-    conv1, conv2, _ = inspect_subnet(seq)
+    conv1, conv2, k = inspect_subnet(seq)
     cmap = ops.coupling_colmap(co, dev)
-    w1, b1, wd1 = block._packs.get(conv1, None, need_grad)
-    w2, b2, wd2 = block._packs.get(conv2, cmap, need_grad)
-    a = SubnetArgs(w1=_pv(w1), b1=_pv(b1), w2=_pv(w2), b2=_pv(b2), w1_dgrad=_pv(wd1), w2_dgrad=_pv(wd2))
+    wino = USE_WINOGRAD[0] and k == 3
+    wino_w2 = wino                                  # conv2 forward: (s|t) interleave of either width
+    w1, b1, wd1 = block._packs.get(conv1, None, need_grad, wino, wino)
+    w2, b2, wd2 = block._packs.get(conv2, cmap, need_grad, wino_w2, wino)
+    a = SubnetArgs(w1=_pv(w1), b1=_pv(b1), w2=_pv(w2), b2=_pv(b2), w1_dgrad=_pv(wd1), w2_dgrad=_pv(wd2),
+                   winograd=(1 if wino else 0) | (2 if wino_w2 else 0) | (12 if wino else 0))
     if with_grads:
         if conv1.weight.requires_grad:
             a.gw1, a.gb1 = _pv(_grad_buf(conv1.weight)), _pv(_grad_buf(conv1.bias))

@@ -60,19 +60,36 @@ def coupling_colmap(co, device):
     return _colmap_cache[key]
 
 
-def pack_conv(weight, bias, colmap=None, want_dgrad=True):
-    """OIHW conv weight -> (w_fwd [taps][Np][Cin], b_fwd [Np], w_dgrad [taps][Cdp][N])."""
+def pad32(n):
+    return (n + 31) // 32 * 32
+
+
+def pack_conv(weight, bias, colmap=None, want_dgrad=True, wino_fwd=False, wino_dgrad=False):
+    """OIHW conv weight -> (w_fwd, b_fwd, w_dgrad).
+    tap-major packs: w_fwd [taps][Np][Cin], w_dgrad [taps][pad16(Cin)][N];
+    Winograd packs (3x3 only): w_fwd [16][Np][Cin], w_dgrad [16][pad32(Cin)][N]  (U = G g G^T)."""
     _chk(weight)
     n, cin, k, _ = weight.shape
     assert weight.is_contiguous() and (bias is None or bias.is_contiguous())
+    assert not (wino_fwd or wino_dgrad) or k == 3
+    lib = _lib.lib()
+    dev = weight.device
     npk = colmap.numel() if colmap is not None else pad16(n)
-    cdp = pad16(cin)
     taps = k * k
-    w_fwd = torch.empty(taps * npk * cin, device=weight.device, dtype=torch.float32)
-    b_fwd = torch.empty(npk, device=weight.device, dtype=torch.float32)
-    w_dg = torch.empty(taps * cdp * n, device=weight.device, dtype=torch.float32) if want_dgrad else None
-    check(_lib.lib().sininn_pack_conv_weights(ptr(weight), ptr(bias), n, cin, k, ptr(colmap, dtype=torch.int32), npk,
-                                              ptr(w_fwd), ptr(b_fwd), cdp, ptr(w_dg), _stream()))
+    cmap = ptr(colmap, dtype=torch.int32)
+    b_fwd = torch.empty(npk, device=dev, dtype=torch.float32)
+    w_fwd = torch.empty((16 if wino_fwd else taps) * npk * cin, device=dev, dtype=torch.float32)
+    w_dg = None
+    if want_dgrad:
+        cdp = pad32(cin) if wino_dgrad else pad16(cin)
+        w_dg = torch.empty((16 if wino_dgrad else taps) * cdp * n, device=dev, dtype=torch.float32)
+    # tap-major parts (+ the packed bias) in one launch, Winograd parts in another
+    check(lib.sininn_pack_conv_weights(ptr(weight), ptr(bias), n, cin, k, cmap, npk,
+                                       None if wino_fwd else ptr(w_fwd), ptr(b_fwd),
+                                       pad16(cin), None if (wino_dgrad or not want_dgrad) else ptr(w_dg), _stream()))
+    if wino_fwd or (want_dgrad and wino_dgrad):
+        check(lib.sininn_pack_winograd(ptr(weight), n, cin, cmap, npk, ptr(w_fwd) if wino_fwd else None,
+                                       pad32(cin), ptr(w_dg) if (want_dgrad and wino_dgrad) else None, _stream()))
     return w_fwd, b_fwd, w_dg
 
 

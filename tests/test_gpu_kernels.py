@@ -287,3 +287,34 @@ def test_bayer_bin_bit_exact(env, scale, reduction):
     assert np.array_equal(lr.cpu().numpy(), want)
     st = FrameStore.from_hr_clip(hr.cuda(), scale, reduction)
     assert st.lr.shape == (3, 32 // (2 * scale), 48 // (2 * scale), 4)
+
+
+@pytest.mark.parametrize('cin,n,hw', [(24, 256, (16, 32)), (256, 96, (12, 20)), (48, 256, (9, 17)), (8, 24, (5, 7)),
+                                      (256, 48, (16, 16)), (192, 256, (40, 24))])
+def test_winograd_conv(env, cin, n, hw):
+    """Winograd F(2x2,3x3) kernel against torch conv2d: forward pack + LINEAR/RELU, data-gradient pack + ADD."""
+    S, O, dev = env
+    from sin_inn_amd import ops, _lib
+    torch.manual_seed(cin + n)
+    h, w = hw
+    conv = torch.nn.Conv2d(cin, n, 3, padding=1)
+    x = torch.randn(2, cin, h, w)
+    want = conv(x)
+    wf, bf, wd = ops.pack_conv(conv.weight.detach().cuda().contiguous(), conv.bias.detach().cuda().contiguous(), None, True,
+                               wino_fwd=True, wino_dgrad=True)
+    npk = ops.pad16(n)
+    xg = nhwc(x)
+    for mode, ref in ((_lib.CONV_LINEAR, want), (_lib.CONV_RELU, F.relu(want))):
+        out = torch.full((2, h, w, n), float('nan'), device=dev)
+        ops.conv(in_=ops.ptr(xg), in_stride=cin, Cin=cin, w=ops.ptr(wf), bias=ops.ptr(bf), Np=npk, winograd=1,
+                 B=2, H=h, W=w, ksize=3, mode=mode, out=ops.ptr(out), out_stride=n, N=n)
+        assert relerr(nchw(out), ref) < RTOL
+    # data gradient: d/dx sum(conv(x) * g) + addend
+    g = torch.randn(2, n, h, w)
+    xin = x.clone().requires_grad_(True)
+    conv(xin).backward(g)
+    add = torch.randn(2, h, w, cin, device=dev)
+    dx = torch.empty((2, h, w, cin), device=dev)
+    ops.conv(in_=ops.ptr(nhwc(g)), in_stride=n, Cin=n, w=ops.ptr(wd), Np=ops.pad32(cin), winograd=1, B=2, H=h, W=w, ksize=3,
+             mode=_lib.CONV_ADD, out=ops.ptr(dx), out_stride=cin, N=cin, addend=ops.ptr(add), addend_stride=cin)
+    assert relerr(nchw(dx), xin.grad + nchw(add)) < RTOL

@@ -34,6 +34,7 @@ def main():
     ap.add_argument('--ck', type=int, default=0)
     ap.add_argument('--cfg', type=int, default=0)
     ap.add_argument('--wgrad16', type=int, default=0)
+    ap.add_argument('--wino', type=int, default=0, help='1: run 3x3 convs with 32-multiple columns through the Winograd kernel')
     a = ap.parse_args()
     dev = torch.device('cuda', 0)
     _lib.lib().sininn_conv_test_hooks(a.cfg, a.ck)
@@ -51,14 +52,17 @@ def main():
                 if a.only and a.only != 'conv':
                     continue
                 npk = ops.pad16(n)
+                wino = a.wino and k == 3 and ops.pad32(n) % 32 == 0 and (mode != _lib.CONV_COUPLE_FWD or co % 16 == 0)
+                if wino:
+                    npk = ops.pad32(n)
                 x = torch.randn(m, cin, device=dev)
-                w = torch.randn(taps * npk * cin, device=dev) * 0.05
+                w = torch.randn((16 if wino else taps) * npk * cin, device=dev) * 0.05
                 bias = torch.randn(npk, device=dev) * 0.1
                 ostr = max(n, 256)
                 out = torch.empty(m, ostr, device=dev)
                 v = torch.randn(m, c, device=dev)
                 kw = dict(in_=ops.ptr(x), in_stride=cin, Cin=cin, w=ops.ptr(w), bias=ops.ptr(bias), Np=npk, B=b, H=hw, W=hw,
-                          ksize=k, mode=mode, out=ops.ptr(out), out_stride=ostr, N=n)
+                          ksize=k, mode=mode, out=ops.ptr(out), out_stride=ostr, N=n, winograd=1 if wino else 0)
                 keep = [x, w, bias, out, v]
                 if mode == _lib.CONV_COUPLE_FWD:
                     sb = torch.empty(m, co, device=dev); ld = torch.zeros(b, device=dev)
