@@ -23,6 +23,9 @@ struct WgradDev {
   int Nr, Cc;
 };
 
+#ifndef WGW_ABLATE
+#define WGW_ABLATE 0   // timing experiments only: 1 no MFMA, 2 no transforms, 4 no tile reloads
+#endif
 constexpr int WG_TH = 8;   // pixel tile 8 x 16
 
 template <int KS, int RT, int CT, int WR, int WC>
@@ -306,6 +309,237 @@ __global__ __launch_bounds__(256, 2) void wgrad32_kernel(WgradDev p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Winograd weight gradient for 3x3 convs:   dU[pos][n][c] = sum_tiles W_pos[tile][n] * V_pos[tile][c]
+//   W = A dY A^T (4x4 from the 2x2 output-gradient patch of a Winograd tile),  V = B^T d B (4x4 input patch),
+//   dg = G^T dU G is applied by the reduce kernel.  16 positions x (tiles x N x C) instead of 9 taps x (pixels x N x C):
+//   2.25x fewer MFMA FLOPs.  Both transforms are done per lane in registers (lane = (n or c, tile)); MFMA rows = n,
+//   cols = c, k = 4 Winograd tiles.  Block = 64 n x 32 c, waves 2 x 2, wave tile 32 n x 16 c x 16 positions
+//   (128 accumulator VGPRs); pixel tiles of 8x16 (32 Winograd tiles = 8 k-steps) are walked split-K style.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgradDev p) {
+  constexpr int IW = 18, IH = WG_TH + 2, NPIX_IN = IH * IW, NPIX = WG_TH * 16;
+  constexpr int BNW = 64, BCW = 32;
+  constexpr int SD = BNW + 8, SI = BCW + 8;            // 2*SD == 2*SI == 16 (mod 32): the 4 k-lanes hit disjoint banks
+  constexpr int D_F4 = (NPIX * BNW / 4 + 255) / 256;
+  constexpr int I_F4 = (NPIX_IN * BCW / 4 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float d_lds[NPIX * SD];
+  __shared__ __attribute__((aligned(16))) float i_lds[NPIX_IN * SI];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, kq = lane >> 4;
+  const int wr = wave & 1, wc = wave >> 1;
+  const int split = blockIdx.x;
+  const int n0 = blockIdx.y * BNW, c0 = blockIdx.z * BCW;
+
+  f32x4 acc[16][2];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { acc[q][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[q][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  float bsum[2] = {0.f, 0.f};
+
+  const int t_begin = split * p.tiles_per_split;
+  const int t_end = min(t_begin + p.tiles_per_split, p.ntiles);
+
+  f32x4 d_reg[D_F4], i_reg[I_F4];
+  auto load_tile = [&](int tile) {
+    int tt = tile;
+    const int tx = tt % p.tiles_x; tt /= p.tiles_x;
+    const int ty = tt % p.tiles_y;
+    const int b = tt / p.tiles_y;
+    const int y0 = ty * WG_TH, x0 = tx * 16;
+#pragma unroll
+    for (int r = 0; r < D_F4; ++r) {
+      const int f = tid + 256 * r;
+      const int pix = f / (BNW / 4), n4 = f % (BNW / 4);
+      const int gy = y0 + pix / 16, gx = x0 + (pix & 15);
+      const int n = n0 + n4 * 4;
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (pix < NPIX && gy < p.H && gx < p.W && n < p.N)
+        val = *reinterpret_cast<const f32x4*>(p.dout + ((size_t)(b * p.H + gy) * p.W + gx) * p.dout_stride + n);
+      d_reg[r] = val;
+    }
+#pragma unroll
+    for (int r = 0; r < I_F4; ++r) {
+      const int f = tid + 256 * r;
+      const int pix = f / (BCW / 4), c4 = f % (BCW / 4);
+      const int py = pix / IW, px = pix - py * IW;
+      const int gy = y0 + py - 1, gx = x0 + px - 1;
+      const int c = c0 + c4 * 4;
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (pix < NPIX_IN && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && c < p.Cin)
+        val = *reinterpret_cast<const f32x4*>(p.in + ((size_t)(b * p.H + gy) * p.W + gx) * p.in_stride + c);
+      i_reg[r] = val;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int r = 0; r < D_F4; ++r) {
+      const int f = tid + 256 * r;
+      const int pix = f / (BNW / 4), n4 = f % (BNW / 4);
+      if (pix < NPIX) *reinterpret_cast<f32x4*>(d_lds + pix * SD + n4 * 4) = d_reg[r];
+    }
+#pragma unroll
+    for (int r = 0; r < I_F4; ++r) {
+      const int f = tid + 256 * r;
+      const int pix = f / (BCW / 4), c4 = f % (BCW / 4);
+      if (pix < NPIX_IN) *reinterpret_cast<f32x4*>(i_lds + pix * SI + c4 * 4) = i_reg[r];
+    }
+  };
+
+  if (t_begin < t_end) load_tile(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    if (!(WGW_ABLATE & 4) || tile == t_begin) {
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+    if (tile + 1 < t_end && !(WGW_ABLATE & 4)) load_tile(tile + 1);
+    }
+#pragma unroll 1                                     // unroll 2 needs > 256 VGPRs (acc 128 + 56 tile prefetch)
+    for (int ks = 0; ks < 8; ++ks) {
+      const int t = 4 * ks + kq;                       // this lane's Winograd tile (k index)
+      const int ty2 = 2 * (t >> 3), tx2 = 2 * (t & 7);
+      // ---- V = B^T d B for (input channel c = 16*wc + li, tile t) ---------------------------------
+      float v[16];
+      {
+        const float* ip = i_lds + (ty2 * IW + tx2) * SI + 16 * wc + li;
+        float tt[4][4];
+        if (WGW_ABLATE & 2) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) v[q] = ip[q];
+        } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float d0 = ip[(0 * IW + c) * SI], d1 = ip[(1 * IW + c) * SI], d2 = ip[(2 * IW + c) * SI], d3 = ip[(3 * IW + c) * SI];
+          tt[0][c] = d0 - d2; tt[1][c] = d1 + d2; tt[2][c] = d2 - d1; tt[3][c] = d1 - d3;
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          v[a * 4 + 0] = tt[a][0] - tt[a][2];
+          v[a * 4 + 1] = tt[a][1] + tt[a][2];
+          v[a * 4 + 2] = tt[a][2] - tt[a][1];
+          v[a * 4 + 3] = tt[a][1] - tt[a][3];
+        }
+        }
+      }
+      // ---- W = A dY A^T for (output channel n = 32*wr + 16*a + li, tile t), a = 0, 1 ---------------
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const float* dp = d_lds + (ty2 * 16 + tx2) * SD + 32 * wr + 16 * a + li;
+        const float y00 = dp[0], y01 = dp[SD], y10 = dp[16 * SD], y11 = dp[17 * SD];
+        bsum[a] += (y00 + y01) + (y10 + y11);
+        // R = A dY (4x2), W = R A^T (4x4)
+        const float r00 = y00, r01 = y01, r10 = y00 + y10, r11 = y01 + y11, r20 = y00 - y10, r21 = y01 - y11,
+                    r30 = -y10, r31 = -y11;
+        float w[16];
+        w[0] = r00; w[1] = r00 + r01; w[2] = r00 - r01; w[3] = -r01;
+        w[4] = r10; w[5] = r10 + r11; w[6] = r10 - r11; w[7] = -r11;
+        w[8] = r20; w[9] = r20 + r21; w[10] = r20 - r21; w[11] = -r21;
+        w[12] = r30; w[13] = r30 + r31; w[14] = r30 - r31; w[15] = -r31;
+        if (WGW_ABLATE & 2) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) w[q] = (q & 1) ? y01 : y00;
+        }
+        if (WGW_ABLATE & 1) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc[q][a][0] += w[q] * v[q];
+        } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q][a] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q], v[q], acc[q][a], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- slab write: D[row n = 4*kq + r][col c = li] per position ------------------------------------
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 32 * wr + 16 * a + 4 * kq + r;
+        const int c = c0 + 16 * wc + li;
+        if (n < p.Nr && c < p.Cc) p.partial[(((size_t)split * 16 + q) * p.Nr + n) * p.Cc + c] = acc[q][a][r];
+      }
+    float bs = bsum[a];
+    bs += __shfl_xor(bs, 16);
+    bs += __shfl_xor(bs, 32);
+    if (blockIdx.z == 0 && wc == 0 && kq == 0) {
+      const int n = n0 + 32 * wr + 16 * a + li;
+      if (n < p.Nr) p.bpartial[(size_t)split * p.Nr + n] = bs;
+    }
+  }
+}
+
+// Reduce the Winograd slabs in a fixed order, apply dg = G^T dU G and accumulate into the OIHW gradient.
+// Block = 16 (n, c4) items x 16 positions: thread (item, pos) sums S slabs of its position (4 loads in flight), the
+// 16 sums of an item meet in LDS and one thread per item does the 4x4 -> 3x3 transform.
+__global__ __launch_bounds__(256) void wgrad_wino_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial,
+                                                              int S, int Nr, int Cc, int N, int Cin,
+                                                              float* __restrict__ gw, float* __restrict__ gb) {
+  __shared__ f32x4 du[16][16];
+  const int c4n = Cc >> 2;
+  const int items = Nr * c4n;
+  const int wblocks = (items + 15) / 16;
+  if ((int)blockIdx.x >= wblocks) {                    // bias entries: 256 per block, serial over S (short: S <= 128)
+    if (gb == nullptr) return;
+    const int i = ((int)blockIdx.x - wblocks) * 256 + threadIdx.x;
+    if (i < N) {
+      float b0 = 0.f, b1 = 0.f;
+      int k = 0;
+      for (; k + 1 < S; k += 2) { b0 += bpartial[(size_t)k * Nr + i]; b1 += bpartial[(size_t)(k + 1) * Nr + i]; }
+      if (k < S) b0 += bpartial[(size_t)k * Nr + i];
+      gb[i] += b0 + b1;
+    }
+    return;
+  }
+  const int item_l = threadIdx.x & 15, pos = threadIdx.x >> 4;
+  const int item = blockIdx.x * 16 + item_l;
+  const f32x4* p4 = reinterpret_cast<const f32x4*>(partial);
+  const size_t slab4 = (size_t)16 * items, off = (size_t)pos * items + item;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  if (item < items) {
+    int k = 0;
+    for (; k + 3 < S; k += 4) {
+      s0 += p4[off + (size_t)k * slab4];
+      s1 += p4[off + (size_t)(k + 1) * slab4];
+      s2 += p4[off + (size_t)(k + 2) * slab4];
+      s3 += p4[off + (size_t)(k + 3) * slab4];
+    }
+    for (; k < S; ++k) s0 += p4[off + (size_t)k * slab4];
+  }
+  du[pos][item_l] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (pos == 0 && item < items) {
+    const int c0 = (item % c4n) * 4, n = item / c4n;
+    if (n < N) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (c0 + j >= Cin) continue;
+        float u[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) u[q] = du[q][item_l][j];
+        float x[3][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          x[0][q] = u[q] + 0.5f * (u[4 + q] + u[8 + q]);
+          x[1][q] = 0.5f * (u[4 + q] - u[8 + q]);
+          x[2][q] = 0.5f * (u[4 + q] + u[8 + q]) + u[12 + q];
+        }
+        float* g = gw + ((size_t)n * Cin + c0 + j) * 9;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          g[a * 3 + 0] += x[a][0] + 0.5f * (x[a][1] + x[a][2]);
+          g[a * 3 + 1] += 0.5f * (x[a][1] - x[a][2]);
+          g[a * 3 + 2] += 0.5f * (x[a][1] + x[a][2]) + x[a][3];
+        }
+      }
+    }
+  }
+}
+
 // Reduce S slabs in a fixed order and accumulate into the OIHW gradient:  gw[n][c][tap] += sum_s partial[s][tap][n][c]
 // A thread owns 4 consecutive c of one (tap, n) row (16-byte loads); the S slabs are split over the block's 4 waves,
 // 4 loads in flight each; the 4 partial sums are combined through LDS in a fixed order -> bitwise reproducible.
@@ -369,18 +603,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-struct WgradPlan { int RT, CT, Nr, Cc, nblk, cblk, S, tiles_per_split, ntiles, tiles_x, tiles_y; size_t bytes; bool use32; };
+struct WgradPlan { int RT, CT, Nr, Cc, nblk, cblk, S, tiles_per_split, ntiles, tiles_x, tiles_y; size_t bytes; bool use32; bool wino; };
 
 static bool g_wgrad_force16 = false;   // test hook
-void wgrad_set_force16(int on) { g_wgrad_force16 = on != 0; }
+static bool g_wgrad_wino = true;       // Winograd weight gradient for 3x3 (test hook bit 1 disables)
+void wgrad_set_force16(int on) { g_wgrad_force16 = (on & 1) != 0; g_wgrad_wino = (on & 2) == 0; }
 
 static WgradPlan make_plan(int N, int Cin, int ksize, int B, int H, int W) {
   WgradPlan pl;
-  pl.use32 = (N % 32 == 0) && !g_wgrad_force16;
+  pl.wino = (ksize == 3) && g_wgrad_wino;
+  pl.use32 = (N % 32 == 0) && !g_wgrad_force16 && !pl.wino;
   // row tiles: 3 when N is a multiple of 48 but not of 64 (N=48), else 4; col tiles 4 with RT=3, else 2 or 4
   if (N % 64 != 0 && N % 48 == 0) { pl.RT = 3; pl.CT = 4; }
   else { pl.RT = 4; pl.CT = (Cin >= 64 && ksize == 1) ? 4 : 2; }
   if (pl.use32) { pl.RT = 2; pl.CT = 2; }              // 32 x 32 output tile per block
+  if (pl.wino) { pl.RT = 4; pl.CT = 2; }               // 64 x 32 output tile, 16 transform positions
   const int bnw = pl.RT * 16, bcw = pl.CT * 16;
   pl.nblk = (N + bnw - 1) / bnw;
   pl.cblk = (Cin + bcw - 1) / bcw;
@@ -391,12 +628,12 @@ static WgradPlan make_plan(int N, int Cin, int ksize, int B, int H, int W) {
   pl.ntiles = B * pl.tiles_x * pl.tiles_y;
   // the RT=3 tile (N=48) needs ~90 KB of LDS and >256 registers: one block per CU -> aim for one round of 256
   // blocks (half the slab traffic of 512); the other tiles run two blocks per CU
-  int S = (pl.RT == 3 ? 256 : 512) / (pl.nblk * pl.cblk);
+  int S = ((pl.RT == 3 && !pl.wino) ? 256 : 512) / (pl.nblk * pl.cblk);
   if (S < 1) S = 1;
   if (S > pl.ntiles) S = pl.ntiles;
   pl.tiles_per_split = (pl.ntiles + S - 1) / S;
   pl.S = (pl.ntiles + pl.tiles_per_split - 1) / pl.tiles_per_split;
-  const int taps = ksize * ksize;
+  const int taps = pl.wino ? 16 : ksize * ksize;
   pl.bytes = ((size_t)pl.S * taps * pl.Nr * pl.Cc + (size_t)pl.S * pl.Nr) * sizeof(float);
   return pl;
 }
@@ -428,9 +665,19 @@ int wgrad_launch(const float* in, int in_stride, int Cin, const float* dout, int
   d.in = in; d.in_stride = in_stride; d.Cin = Cin; d.dout = dout; d.dout_stride = dout_stride; d.N = N;
   d.B = B; d.H = H; d.W = W; d.tiles_x = pl.tiles_x; d.tiles_y = pl.tiles_y; d.ntiles = pl.ntiles;
   d.tiles_per_split = pl.tiles_per_split; d.Nr = pl.Nr; d.Cc = pl.Cc;
-  const int taps = ksize * ksize;
+  const int taps = pl.wino ? 16 : ksize * ksize;
   d.partial = static_cast<float*>(ws);
   d.bpartial = d.partial + (size_t)pl.S * taps * pl.Nr * pl.Cc;
+  if (pl.wino) {
+    hipLaunchKernelGGL(wgrad_wino_kernel, dim3(pl.S, pl.nblk, pl.cblk), dim3(256), 0, st, d);
+    SININN_LAUNCH_CHECK("wgrad_wino");
+    const int items = pl.Nr * (pl.Cc / 4);
+    const int bias_blocks = gb ? (N + 255) / 256 : 0;
+    hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3((items + 15) / 16 + bias_blocks), dim3(256), 0, st,
+                       d.partial, d.bpartial, pl.S, pl.Nr, pl.Cc, N, Cin, gw, gb);
+    SININN_LAUNCH_CHECK("wgrad_wino_reduce");
+    return 0;
+  }
   if (ksize == 3) launch_wgrad<3>(pl, d, st); else launch_wgrad<1>(pl, d, st);
   SININN_LAUNCH_CHECK("wgrad_mfma");
   const int total4 = taps * pl.Nr * (pl.Cc / 4);

@@ -108,13 +108,13 @@ def test_conv_strided_input_and_mask_add(env, ksize):
 
 @pytest.mark.parametrize('ksize', [3, 1])
 @pytest.mark.parametrize('cin,n', [(256, 48), (24, 256), (96, 256), (256, 192)])
-@pytest.mark.parametrize('force16', [0, 1])
+@pytest.mark.parametrize('force16', [0, 1, 2, 3])    # bit0: 16-wide MFMA tiles, bit1: no Winograd wgrad for 3x3
 def test_wgrad(env, ksize, cin, n, force16):
     S, O, dev = env
     from sin_inn_amd import ops, _lib
     _lib.lib().sininn_wgrad_test_hooks(force16)
     torch.manual_seed(cin * 3 + n)
-    b, h, w = 3, 12, 20
+    b, h, w = 3, 13, 21                               # odd sizes: partial pixel tiles and partial Winograd tiles
     conv = torch.nn.Conv2d(cin, n, ksize, padding=ksize // 2)
     x = torch.randn(b, cin + 8, h, w)
     g = torch.randn(b, n, h, w)

@@ -33,7 +33,7 @@ def main():
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--ck', type=int, default=0)
     ap.add_argument('--cfg', type=int, default=0)
-    ap.add_argument('--wgrad16', type=int, default=0)
+    ap.add_argument('--wgrad16', type=int, default=0, help='bit0: 16-wide tiles, bit1: disable the Winograd wgrad')
     ap.add_argument('--wino', type=int, default=0, help='1: run 3x3 convs with 32-multiple columns through the Winograd kernel')
     a = ap.parse_args()
     dev = torch.device('cuda', 0)
