@@ -44,7 +44,7 @@ struct ConvDev {
 // addend, y, s) is a coalesced float4 instead of a per-lane 4-byte scatter.
 //   HT = half-tile of the coupling interleave: tile of 2*HT columns = [ s HT ch | t HT ch ].
 // ------------------------------------------------------------------------------------------------
-template <int TH, int BN, int HT>
+template <int TH, int BN, int HT, int NTHR = 256>
 __device__ __forceinline__ void conv_epilogue_tile(const ConvDev& p, const float* T, int b, int y0, int x0, int n0,
                                                    int tid, float* red) {
   constexpr int TS = BN + 4;
@@ -56,7 +56,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvDev& p, const float
     constexpr int Q = CB / 4;                        // channel quads per pixel
     const int c_block0 = n0 / 2;
     float ld_acc = 0.f;
-    for (int idx = tid; idx < NPIX * Q; idx += 256) {
+    for (int idx = tid; idx < NPIX * Q; idx += NTHR) {
       const int pl = idx / Q, q4 = idx - pl * Q;
       const int cl = q4 * 4;                         // block-local channel
       const int c = c_block0 + cl;
@@ -93,11 +93,16 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvDev& p, const float
       const float w = wave_sum(ld_acc);
       if ((tid & 63) == 0) red[tid >> 6] = w;
       __syncthreads();
-      if (tid == 0) atomicAdd(p.logdet + b, red[0] + red[1] + red[2] + red[3]);
+      if (tid == 0) {
+        float tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < NTHR / 64; ++i) tot += red[i];
+        atomicAdd(p.logdet + b, tot);
+      }
     }
   } else {
     constexpr int Q = BN / 4;
-    for (int idx = tid; idx < NPIX * Q; idx += 256) {
+    for (int idx = tid; idx < NPIX * Q; idx += NTHR) {
       const int pl = idx / Q, q4 = idx - pl * Q;
       const int col = n0 + q4 * 4;
       const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);

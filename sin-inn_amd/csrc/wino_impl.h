@@ -3,7 +3,9 @@
 //
 //   Y = A^T [ (G g G^T) .* (B^T d B) ] A      d: 4x4 input patch, g: 3x3 filter, Y: 2x2 outputs
 //
-//   * block  = 16x16 output pixels (8x8 Winograd tiles) x 32 packed columns; 4 waves = 4 groups of 16 tiles.
+//   * block  = 16x16 output pixels (8x8 Winograd tiles) x (CG * 32) packed columns; 4 * CG waves: wave = (column
+//     group, 16 tiles).  With CG = 2 the two column groups share ONE staged halo tile: a 256-channel input is then
+//     read once per 64 columns instead of once per 32 (PMC: the Np=64 coupling conv fetched 198 MB for a 67 MB input).
 //   * the filter transform U = G g G^T is done once per weight update by the pack kernel:
 //     U[pos 16][column][cin] (k-contiguous rows), so per position the kernel runs a plain
 //     [16 tiles x K] x [K x 16 columns] MFMA product, accumulating all 16 positions in registers
@@ -21,15 +23,20 @@
 
 namespace sininn {
 
-template <int NT, int HT>
-__global__ __launch_bounds__(256, 2) void wino_kernel(ConvDev p) {
+template <int NT, int HT, int CG>
+__global__ __launch_bounds__(256 * CG, 2 / CG) void wino_kernel(ConvDev p) {
   constexpr int CK = 8;
+  constexpr int NTHR = 256 * CG;
   constexpr int IW = 18, NPIX_IN = 18 * 18;
-  constexpr int BN = NT * 16;
-  constexpr int SI = 12, SU = 12;                       // LDS row strides (floats): 8 channels + 4 pad
-  constexpr int IN_F4 = (NPIX_IN * 2 + 255) / 256;      // 2 float4 per pixel
-  constexpr int U_F4 = (16 * BN * 2 + 255) / 256;
-  constexpr int IN_BUF = NPIX_IN * SI, U_BUF = 16 * BN * SU;
+  constexpr int BG = NT * 16;                           // columns of one wave group
+  constexpr int BN = CG * BG;                           // columns of the block
+  constexpr int SI = 12, SU = 12;                       // LDS pixel / column strides (floats): 8 channels + 4 pad
+  // halo-tile row pitch + a 4-float skew on every second row pair: the two tile rows a wave reads with one
+  // ds_read_b64 then fall on disjoint banks (tile step 24 floats = multiples of 8 banks; row-pair step 440 +- 4)
+  constexpr int PITCH = IW * SI + 4;
+  constexpr int IN_F4 = (NPIX_IN * 2 + NTHR - 1) / NTHR;   // 2 float4 per pixel
+  constexpr int U_F4 = (16 * BN * 2 + NTHR - 1) / NTHR;
+  constexpr int IN_BUF = IW * PITCH + 4, U_BUF = 16 * BN * SU;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const in_lds0 = smem;
@@ -38,7 +45,7 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(ConvDev p) {
   float* const u_lds1 = u_lds0 + U_BUF;
 
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
+  const int wave = (tid >> 6) & 3, grp = tid >> 8, lane = tid & 63;   // wave: tile group, grp: column group
   const int li = lane & 15, kq = lane >> 4;
 
   int bid = blockIdx.x;
@@ -52,19 +59,19 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(ConvDev p) {
   int in_goff[IN_F4], in_loff[IN_F4];
 #pragma unroll
   for (int r = 0; r < IN_F4; ++r) {
-    const int f = tid + 256 * r;
+    const int f = tid + NTHR * r;
     const int pix = f >> 1, c4 = f & 1;
     const int py = pix / IW, px = pix - py * IW;
     const int gy = y0 + py - 1, gx = x0 + px - 1;
     const bool inside = pix < NPIX_IN;
     const bool inimg = inside && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-    in_loff[r] = inside ? (pix * SI + c4 * 4) : -1;
+    in_loff[r] = inside ? (py * PITCH + ((py >> 1) & 1) * 4 + px * SI + c4 * 4) : -1;
     in_goff[r] = inimg ? (((b * p.H + gy) * p.W + gx) * p.in_stride + c4 * 4) : -1;
   }
   int u_goff[U_F4], u_loff[U_F4];
 #pragma unroll
   for (int r = 0; r < U_F4; ++r) {
-    const int f = tid + 256 * r;
+    const int f = tid + NTHR * r;
     const int c4 = f & 1, col = (f >> 1) % BN, pos = (f >> 1) / BN;
     const bool inside = pos < 16;
     u_loff[r] = inside ? ((pos * BN + col) * SU + c4 * 4) : -1;
@@ -96,8 +103,10 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(ConvDev p) {
 
   // this lane's Winograd tile for the A operand (tile = 16*wave + li) and its patch origin in the halo tile
   const int a_ty = 2 * wave + (li >> 3), a_tx = li & 7;
-  const int a_base = ((2 * a_ty) * IW + 2 * a_tx) * SI + 2 * kq;
-  const int b_base = li * SU + 2 * kq;
+  // patch rows a = 0,1 carry the skew of row pair a_ty, rows a = 2,3 that of row pair a_ty + 1
+  const int a_base01 = (2 * a_ty) * PITCH + (a_ty & 1) * 4 + (2 * a_tx) * SI + 2 * kq;
+  const int a_base23 = (2 * a_ty) * PITCH + ((a_ty + 1) & 1) * 4 + (2 * a_tx) * SI + 2 * kq;
+  const int b_base = (grp * BG + li) * SU + 2 * kq;
 
   f32x4 acc[16][NT];
 #pragma unroll
@@ -115,51 +124,64 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(ConvDev p) {
       if (it + 1 < nchunks) store_chunk(((it + 1) & 1) ? in_lds1 : in_lds0, ((it + 1) & 1) ? u_lds1 : u_lds0);
       if (it + 2 < nchunks) load_chunk(it + 2);
     }
-    const float* A = ((it & 1) ? in_lds1 : in_lds0) + a_base;
-    const float* Uc = ((it & 1) ? u_lds1 : u_lds0) + b_base;
+    const unsigned A01 = lds_addr(((it & 1) ? in_lds1 : in_lds0) + a_base01);
+    const unsigned A23 = lds_addr(((it & 1) ? in_lds1 : in_lds0) + a_base23);
+    const unsigned Uc = lds_addr(((it & 1) ? u_lds1 : u_lds0) + b_base);
 
     // ---- input transform V = B^T d B for (this lane's tile, channels 2kq / 2kq+1) -----------------
-    float2 v[4][4];
-    if (p.ablate & 4) {
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[a][c] = make_float2(1.f + a, 2.f + c);
-    } else {
-      float2 d[4][4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) d[a][c] = *reinterpret_cast<const float2*>(A + (a * IW + c) * SI);
-      float2 t[4][4];
+    f32x2 v[4][4];
+    {
+      f32x2 d[4][4];
+      static_for<0, 16>([&](auto i) {
+        constexpr int a = decltype(i)::value >> 2, c = decltype(i)::value & 3;
+        d[a][c] = lds_read_b64<(a * PITCH + c * SI) * 4>(a < 2 ? A01 : A23);
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[0][2]), "+v"(d[0][3]), "+v"(d[1][0]), "+v"(d[1][1]), "+v"(d[1][2]),
+                     "+v"(d[1][3]), "+v"(d[2][0]), "+v"(d[2][1]), "+v"(d[2][2]), "+v"(d[2][3]), "+v"(d[3][0]), "+v"(d[3][1]),
+                     "+v"(d[3][2]), "+v"(d[3][3]));
+      f32x2 t[4][4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        t[0][c] = make_float2(d[0][c].x - d[2][c].x, d[0][c].y - d[2][c].y);
-        t[1][c] = make_float2(d[1][c].x + d[2][c].x, d[1][c].y + d[2][c].y);
-        t[2][c] = make_float2(d[2][c].x - d[1][c].x, d[2][c].y - d[1][c].y);
-        t[3][c] = make_float2(d[1][c].x - d[3][c].x, d[1][c].y - d[3][c].y);
+        t[0][c] = d[0][c] - d[2][c];
+        t[1][c] = d[1][c] + d[2][c];
+        t[2][c] = d[2][c] - d[1][c];
+        t[3][c] = d[1][c] - d[3][c];
       }
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        v[a][0] = make_float2(t[a][0].x - t[a][2].x, t[a][0].y - t[a][2].y);
-        v[a][1] = make_float2(t[a][1].x + t[a][2].x, t[a][1].y + t[a][2].y);
-        v[a][2] = make_float2(t[a][2].x - t[a][1].x, t[a][2].y - t[a][1].y);
-        v[a][3] = make_float2(t[a][1].x - t[a][3].x, t[a][1].y - t[a][3].y);
+        v[a][0] = t[a][0] - t[a][2];
+        v[a][1] = t[a][1] + t[a][2];
+        v[a][2] = t[a][2] - t[a][1];
+        v[a][3] = t[a][1] - t[a][3];
       }
     }
     // ---- 16 positions x NT column tiles x 2 k-steps -----------------------------------------------
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      float2 bf[NT];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const float2*>(Uc + ((q * BN + n * 16) * SU));
+    // the U fragments of position q + PF are requested before the MFMAs of position q issue, so the matrix pipe
+    // does not idle for the LDS latency at every position
+    constexpr int PF = 2;
+    static_assert(NT == 2, "the wait counts below assume two column tiles per wave");
+    f32x2 bf[PF + 1][NT];
+    static_for<0, PF>([&](auto qq) {
+      constexpr int q = decltype(qq)::value;
+      bf[q][0] = lds_read_b64<((q * BN) * SU) * 4>(Uc);
+      bf[q][1] = lds_read_b64<((q * BN + 16) * SU) * 4>(Uc);
+    });
+    static_for<0, 16>([&](auto qq) {
+      constexpr int q = decltype(qq)::value;
+      if constexpr (q + PF < 16) {
+        bf[(q + PF) % (PF + 1)][0] = lds_read_b64<(((q + PF) * BN) * SU) * 4>(Uc);
+        bf[(q + PF) % (PF + 1)][1] = lds_read_b64<(((q + PF) * BN + 16) * SU) * 4>(Uc);
+      }
+      constexpr int newer = (q + PF < 16 ? PF : 15 - q) * NT;     // reads issued after this position's
+      lds_wait<newer>(bf[q % (PF + 1)][0], bf[q % (PF + 1)][1]);
 #pragma unroll
       for (int n = 0; n < NT; ++n)
-        acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q >> 2][q & 3].x, bf[n].x, acc[q][n], 0, 0, 0);
+        acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q >> 2][q & 3].x, bf[q % (PF + 1)][n].x, acc[q][n], 0, 0, 0);
 #pragma unroll
       for (int n = 0; n < NT; ++n)
-        acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q >> 2][q & 3].y, bf[n].y, acc[q][n], 0, 0, 0);
-    }
+        acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q >> 2][q & 3].y, bf[q % (PF + 1)][n].y, acc[q][n], 0, 0, 0);
+    });
     if (!(p.ablate & 2)) __syncthreads();
   }
 
@@ -183,33 +205,47 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(ConvDev p) {
         }
         const int tl = 4 * kq + r;
         const int oy = 2 * (2 * wave + (tl >> 3)), ox = 2 * (tl & 7);
-        float* t00 = T + (oy * 16 + ox) * TS + n * 16 + li;
+        float* t00 = T + (oy * 16 + ox) * TS + grp * BG + n * 16 + li;
         t00[0] = r0[0] + r0[1] + r0[2];
         t00[TS] = r0[1] - r0[2] - r0[3];
         t00[16 * TS] = r1[0] + r1[1] + r1[2];
         t00[17 * TS] = r1[1] - r1[2] - r1[3];
       }
     __syncthreads();
-    __shared__ float red[4];
-    conv_epilogue_tile<16, BN, HT>(p, T, b, y0, x0, n0, tid, red);
+    __shared__ float red[4 * CG];
+    conv_epilogue_tile<16, BN, HT, NTHR>(p, T, b, y0, x0, n0, tid, red);
   }
 }
 
-static int wino_dispatch(ConvDev& d, hipStream_t st) {
-  constexpr int NT = 2, BN = NT * 16;
-  constexpr size_t lds_main = (size_t)(2 * 18 * 18 * 12 + 2 * 16 * BN * 12) * sizeof(float);
+template <int CG>
+static int wino_launch(ConvDev& d, hipStream_t st) {
+  constexpr int NT = 2, BN = CG * NT * 16;
+  constexpr size_t lds_main = (size_t)(2 * (18 * (18 * 12 + 4) + 4) + 2 * 16 * BN * 12) * sizeof(float);
   constexpr size_t lds_epi = (size_t)256 * (BN + 4) * sizeof(float);
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  static_assert(lds <= 160 * 1024, "LDS tile too large");
   d.tiles_x = (d.W + 15) / 16;
   d.tiles_y = (d.H + 15) / 16;
   dim3 grid(d.tiles_x * d.tiles_y * d.B, (d.Np + BN - 1) / BN);
   // HT = half-width of the coupling (s|t) column interleave the weights were packed with (16 or 8)
-  auto k = (d.col_tile == 16) ? wino_kernel<NT, 8> : wino_kernel<NT, 16>;
+  auto k = (d.col_tile == 16) ? wino_kernel<NT, 8, CG> : wino_kernel<NT, 16, CG>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { set_error("wino: cannot raise LDS limit to %zu", lds); return 1; }
-  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, d);
+  hipLaunchKernelGGL(k, grid, dim3(256 * CG), lds, st, d);
   SININN_LAUNCH_CHECK("wino");
   return 0;
+}
+
+// cg2: 0 auto, 1 force 32-column blocks, 2 force 64-column blocks (test hook)
+static int wino_dispatch(ConvDev& d, hipStream_t st, int cg2 = 0) {
+  // 64-column blocks (8 waves sharing one halo tile) when the columns split evenly and the input is wide enough
+  // for its re-reads to matter
+  // (an even number of 32-column groups; the last group may be partial, as with 32-column blocks)
+  const bool even_groups = ((d.Np + 31) / 32) % 2 == 0;
+  bool wide = even_groups && d.Cin >= 64;
+  if (cg2 == 1) wide = false;
+  if (cg2 == 2) wide = even_groups;
+  return wide ? wino_launch<2>(d, st) : wino_launch<1>(d, st);
 }
 
 }  // namespace sininn

@@ -290,11 +290,20 @@ def test_bayer_bin_bit_exact(env, scale, reduction):
 
 
 @pytest.mark.parametrize('cin,n,hw', [(24, 256, (16, 32)), (256, 96, (12, 20)), (48, 256, (9, 17)), (8, 24, (5, 7)),
-                                      (256, 48, (16, 16)), (192, 256, (40, 24))])
-def test_winograd_conv(env, cin, n, hw):
+                                      (256, 48, (16, 16)), (192, 256, (40, 24)), (64, 128, (19, 33))])
+@pytest.mark.parametrize('cg', [1, 2])          # 32-column blocks / 64-column blocks (8 waves share the halo tile)
+def test_winograd_conv(env, cin, n, hw, cg):
     """Winograd F(2x2,3x3) kernel against torch conv2d: forward pack + LINEAR/RELU, data-gradient pack + ADD."""
     S, O, dev = env
     from sin_inn_amd import ops, _lib
+    try:
+        _lib.lib().sininn_conv_test_hooks(cg, 0)
+        _winograd_conv_case(dev, ops, _lib, cin, n, hw)
+    finally:
+        _lib.lib().sininn_conv_test_hooks(0, 0)
+
+
+def _winograd_conv_case(dev, ops, _lib, cin, n, hw):
     torch.manual_seed(cin + n)
     h, w = hw
     conv = torch.nn.Conv2d(cin, n, 3, padding=1)

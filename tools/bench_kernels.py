@@ -52,8 +52,8 @@ def main():
                 if a.only and a.only != 'conv':
                     continue
                 npk = ops.pad16(n)
-                wino = a.wino and k == 3 and ops.pad32(n) % 32 == 0 and (mode != _lib.CONV_COUPLE_FWD or co % 16 == 0)
-                if wino:
+                wino = a.wino and k == 3
+                if wino and mode != _lib.CONV_COUPLE_FWD:
                     npk = ops.pad32(n)
                 x = torch.randn(m, cin, device=dev)
                 w = torch.randn((16 if wino else taps) * npk * cin, device=dev) * 0.05
