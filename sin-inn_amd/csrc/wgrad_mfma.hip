@@ -313,13 +313,14 @@ __global__ __launch_bounds__(256, 2) void wgrad32_kernel(WgradDev p) {
 // ------------------------------------------------------------------------------------------------
 // Winograd weight gradient for 3x3 convs:   dU[pos][n][c] = sum_tiles W_pos[tile][n] * V_pos[tile][c]
 //   W = A dY A^T (4x4 from the 2x2 output-gradient patch of a Winograd tile),  V = B^T d B (4x4 input patch),
-//   dg = G^T dU G is applied by the reduce kernel.  16 positions x (tiles x N x C) instead of 9 taps x (pixels x N x C):
+//   dg = G^T dU G is applied per lane before the slab write.  16 positions x (tiles x N x C) instead of 9 taps x (pixels x N x C):
 //   2.25x fewer MFMA FLOPs.  Both transforms are done per lane in registers (lane = (n or c, tile)); MFMA rows = n,
 //   cols = c, k = 4 Winograd tiles.  Block = 64 n x 32 c, waves 2 x 2, wave tile 32 n x 16 c x 16 positions
 //   (128 accumulator VGPRs); pixel tiles of 8x16 (32 Winograd tiles = 8 k-steps) are walked split-K style.
 // ------------------------------------------------------------------------------------------------
+template <int TH, int UNR>
 __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgradDev p) {
-  constexpr int IW = 18, IH = WG_TH + 2, NPIX_IN = IH * IW, NPIX = WG_TH * 16;
+  constexpr int IW = 18, IH = TH + 2, NPIX_IN = IH * IW, NPIX = TH * 16;
   constexpr int BNW = 64, BCW = 32;
   constexpr int SD = BNW + 8, SI = BCW + 8;            // 2*SD == 2*SI == 16 (mod 32): the 4 k-lanes hit disjoint banks
   constexpr int D_F4 = (NPIX * BNW / 4 + 255) / 256;
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgradDev p) {
     const int tx = tt % p.tiles_x; tt /= p.tiles_x;
     const int ty = tt % p.tiles_y;
     const int b = tt / p.tiles_y;
-    const int y0 = ty * WG_TH, x0 = tx * 16;
+    const int y0 = ty * TH, x0 = tx * 16;
 #pragma unroll
     for (int r = 0; r < D_F4; ++r) {
       const int f = tid + 256 * r;
@@ -396,8 +397,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgradDev p) {
     __syncthreads();
     if (tile + 1 < t_end && !(WGW_ABLATE & 4)) load_tile(tile + 1);
     }
-#pragma unroll 1                                     // unroll 2 needs > 256 VGPRs (acc 128 + 56 tile prefetch)
-    for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll UNR
+    for (int ks = 0; ks < TH; ++ks) {
       const int t = 4 * ks + kq;                       // this lane's Winograd tile (k index)
       const int ty2 = 2 * (t >> 3), tx2 = 2 * (t & 7);
       // ---- V = B^T d B for (input channel c = 16*wc + li, tile t) ---------------------------------
@@ -452,90 +453,40 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgradDev p) {
     }
   }
 
-  // ---- slab write: D[row n = 4*kq + r][col c = li] per position ------------------------------------
+  // ---- dg = G^T dU G per lane (all 16 positions of an (n, c) pair live in one lane), then the 9-tap slab write:
+  // D[row n = 4*kq + r][col c = li]; 9 instead of 16 values per pair cuts the slab traffic by 44 % and the ordered
+  // reduction is the plain tap-major one
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q)
+    for (int r = 0; r < 4; ++r) {
+      float x[3][4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = n0 + 32 * wr + 16 * a + 4 * kq + r;
-        const int c = c0 + 16 * wc + li;
-        if (n < p.Nr && c < p.Cc) p.partial[(((size_t)split * 16 + q) * p.Nr + n) * p.Cc + c] = acc[q][a][r];
+      for (int q = 0; q < 4; ++q) {
+        const float u0 = acc[q][a][r], u1 = acc[4 + q][a][r], u2 = acc[8 + q][a][r], u3 = acc[12 + q][a][r];
+        x[0][q] = u0 + 0.5f * (u1 + u2);
+        x[1][q] = 0.5f * (u1 - u2);
+        x[2][q] = 0.5f * (u1 + u2) + u3;
       }
+      const int n = n0 + 32 * wr + 16 * a + 4 * kq + r;
+      const int c = c0 + 16 * wc + li;
+      if (n < p.Nr && c < p.Cc) {
+        float* dst = p.partial + ((size_t)split * 9 * p.Nr + n) * p.Cc + c;
+        const size_t tap_stride = (size_t)p.Nr * p.Cc;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          dst[(i * 3 + 0) * tap_stride] = x[i][0] + 0.5f * (x[i][1] + x[i][2]);
+          dst[(i * 3 + 1) * tap_stride] = 0.5f * (x[i][1] - x[i][2]);
+          dst[(i * 3 + 2) * tap_stride] = 0.5f * (x[i][1] + x[i][2]) + x[i][3];
+        }
+      }
+    }
     float bs = bsum[a];
     bs += __shfl_xor(bs, 16);
     bs += __shfl_xor(bs, 32);
     if (blockIdx.z == 0 && wc == 0 && kq == 0) {
       const int n = n0 + 32 * wr + 16 * a + li;
       if (n < p.Nr) p.bpartial[(size_t)split * p.Nr + n] = bs;
-    }
-  }
-}
-
-// Reduce the Winograd slabs in a fixed order, apply dg = G^T dU G and accumulate into the OIHW gradient.
-// Block = 16 (n, c4) items x 16 positions: thread (item, pos) sums S slabs of its position (4 loads in flight), the
-// 16 sums of an item meet in LDS and one thread per item does the 4x4 -> 3x3 transform.
-__global__ __launch_bounds__(256) void wgrad_wino_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial,
-                                                              int S, int Nr, int Cc, int N, int Cin,
-                                                              float* __restrict__ gw, float* __restrict__ gb) {
-  __shared__ f32x4 du[16][16];
-  const int c4n = Cc >> 2;
-  const int items = Nr * c4n;
-  const int wblocks = (items + 15) / 16;
-  if ((int)blockIdx.x >= wblocks) {                    // bias entries: 256 per block, serial over S (short: S <= 128)
-    if (gb == nullptr) return;
-    const int i = ((int)blockIdx.x - wblocks) * 256 + threadIdx.x;
-    if (i < N) {
-      float b0 = 0.f, b1 = 0.f;
-      int k = 0;
-      for (; k + 1 < S; k += 2) { b0 += bpartial[(size_t)k * Nr + i]; b1 += bpartial[(size_t)(k + 1) * Nr + i]; }
-      if (k < S) b0 += bpartial[(size_t)k * Nr + i];
-      gb[i] += b0 + b1;
-    }
-    return;
-  }
-  const int item_l = threadIdx.x & 15, pos = threadIdx.x >> 4;
-  const int item = blockIdx.x * 16 + item_l;
-  const f32x4* p4 = reinterpret_cast<const f32x4*>(partial);
-  const size_t slab4 = (size_t)16 * items, off = (size_t)pos * items + item;
-  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-  if (item < items) {
-    int k = 0;
-    for (; k + 3 < S; k += 4) {
-      s0 += p4[off + (size_t)k * slab4];
-      s1 += p4[off + (size_t)(k + 1) * slab4];
-      s2 += p4[off + (size_t)(k + 2) * slab4];
-      s3 += p4[off + (size_t)(k + 3) * slab4];
-    }
-    for (; k < S; ++k) s0 += p4[off + (size_t)k * slab4];
-  }
-  du[pos][item_l] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (pos == 0 && item < items) {
-    const int c0 = (item % c4n) * 4, n = item / c4n;
-    if (n < N) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (c0 + j >= Cin) continue;
-        float u[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) u[q] = du[q][item_l][j];
-        float x[3][4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          x[0][q] = u[q] + 0.5f * (u[4 + q] + u[8 + q]);
-          x[1][q] = 0.5f * (u[4 + q] - u[8 + q]);
-          x[2][q] = 0.5f * (u[4 + q] + u[8 + q]) + u[12 + q];
-        }
-        float* g = gw + ((size_t)n * Cin + c0 + j) * 9;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          g[a * 3 + 0] += x[a][0] + 0.5f * (x[a][1] + x[a][2]);
-          g[a * 3 + 1] += 0.5f * (x[a][1] - x[a][2]);
-          g[a * 3 + 2] += 0.5f * (x[a][1] + x[a][2]) + x[a][3];
-        }
-      }
     }
   }
 }
@@ -603,11 +554,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-struct WgradPlan { int RT, CT, Nr, Cc, nblk, cblk, S, tiles_per_split, ntiles, tiles_x, tiles_y; size_t bytes; bool use32; bool wino; };
+struct WgradPlan { int RT, CT, Nr, Cc, nblk, cblk, S, tiles_per_split, ntiles, tiles_x, tiles_y; size_t bytes; bool use32; bool wino; int th; };
 
 static bool g_wgrad_force16 = false;   // test hook
 static bool g_wgrad_wino = true;       // Winograd weight gradient for 3x3 (test hook bit 1 disables)
-void wgrad_set_force16(int on) { g_wgrad_force16 = (on & 1) != 0; g_wgrad_wino = (on & 2) == 0; }
+static bool g_wgrad_wino_th8 = false;  // test hook bit 2: 8-row pixel tiles in the Winograd weight gradient
+void wgrad_set_force16(int on) { g_wgrad_force16 = (on & 1) != 0; g_wgrad_wino = (on & 2) == 0; g_wgrad_wino_th8 = (on & 4) != 0; }
 
 static WgradPlan make_plan(int N, int Cin, int ksize, int B, int H, int W) {
   WgradPlan pl;
@@ -624,7 +576,8 @@ static WgradPlan make_plan(int N, int Cin, int ksize, int B, int H, int W) {
   pl.Nr = pl.nblk * bnw;
   pl.Cc = pl.cblk * bcw;
   pl.tiles_x = (W + 15) / 16;
-  pl.tiles_y = (H + WG_TH - 1) / WG_TH;
+  pl.th = (pl.wino && !(g_wgrad_wino_th8)) ? 4 : WG_TH;
+  pl.tiles_y = (H + pl.th - 1) / pl.th;
   pl.ntiles = B * pl.tiles_x * pl.tiles_y;
   // the RT=3 tile (N=48) needs ~90 KB of LDS and >256 registers: one block per CU -> aim for one round of 256
   // blocks (half the slab traffic of 512); the other tiles run two blocks per CU
@@ -633,7 +586,7 @@ static WgradPlan make_plan(int N, int Cin, int ksize, int B, int H, int W) {
   if (S > pl.ntiles) S = pl.ntiles;
   pl.tiles_per_split = (pl.ntiles + S - 1) / S;
   pl.S = (pl.ntiles + pl.tiles_per_split - 1) / pl.tiles_per_split;
-  const int taps = pl.wino ? 16 : ksize * ksize;
+  const int taps = ksize * ksize;
   pl.bytes = ((size_t)pl.S * taps * pl.Nr * pl.Cc + (size_t)pl.S * pl.Nr) * sizeof(float);
   return pl;
 }
@@ -665,21 +618,17 @@ int wgrad_launch(const float* in, int in_stride, int Cin, const float* dout, int
   d.in = in; d.in_stride = in_stride; d.Cin = Cin; d.dout = dout; d.dout_stride = dout_stride; d.N = N;
   d.B = B; d.H = H; d.W = W; d.tiles_x = pl.tiles_x; d.tiles_y = pl.tiles_y; d.ntiles = pl.ntiles;
   d.tiles_per_split = pl.tiles_per_split; d.Nr = pl.Nr; d.Cc = pl.Cc;
-  const int taps = pl.wino ? 16 : ksize * ksize;
+  const int taps = ksize * ksize;
   d.partial = static_cast<float*>(ws);
   d.bpartial = d.partial + (size_t)pl.S * taps * pl.Nr * pl.Cc;
   if (pl.wino) {
-    hipLaunchKernelGGL(wgrad_wino_kernel, dim3(pl.S, pl.nblk, pl.cblk), dim3(256), 0, st, d);
+    if (pl.th == 4) hipLaunchKernelGGL((wgrad_wino_kernel<4, 2>), dim3(pl.S, pl.nblk, pl.cblk), dim3(256), 0, st, d);
+    else hipLaunchKernelGGL((wgrad_wino_kernel<8, 1>), dim3(pl.S, pl.nblk, pl.cblk), dim3(256), 0, st, d);
     SININN_LAUNCH_CHECK("wgrad_wino");
-    const int items = pl.Nr * (pl.Cc / 4);
-    const int bias_blocks = gb ? (N + 255) / 256 : 0;
-    hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3((items + 15) / 16 + bias_blocks), dim3(256), 0, st,
-                       d.partial, d.bpartial, pl.S, pl.Nr, pl.Cc, N, Cin, gw, gb);
-    SININN_LAUNCH_CHECK("wgrad_wino_reduce");
-    return 0;
+  } else {
+    if (ksize == 3) launch_wgrad<3>(pl, d, st); else launch_wgrad<1>(pl, d, st);
+    SININN_LAUNCH_CHECK("wgrad_mfma");
   }
-  if (ksize == 3) launch_wgrad<3>(pl, d, st); else launch_wgrad<1>(pl, d, st);
-  SININN_LAUNCH_CHECK("wgrad_mfma");
   const int total4 = taps * pl.Nr * (pl.Cc / 4);
   const int bias_blocks = gb ? (N + 63) / 64 : 0;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total4 + 63) / 64 + bias_blocks), dim3(256), 0, st,
