@@ -55,6 +55,19 @@ int sininn_pack_conv_weights(const float* w_oihw, const float* bias, int N, int 
 int sininn_pack_winograd(const float* w_oihw, int N, int Cin, const int* colmap, int Np, float* u_fwd,
                          int Cdp, float* u_dgrad, void* stream);
 
+/* All weight packs of a model in ONE launch (the optimiser step invalidates every pack at once; 48 small pack
+ * launches per training step cost ~0.2 ms).  `descs` is a DEVICE array of n descriptors; destinations and
+ * conventions are those of sininn_pack_conv_weights (wino_* == 0) / sininn_pack_winograd (wino_* != 0, ksize 3);
+ * b_fwd (packed bias) is written whenever it is non-NULL.  work_begin = exclusive prefix sum of
+ * sininn_pack_work_items over the array (host-computed), total_work = its grand total. */
+typedef struct sininn_pack_desc {
+  const float* w; const float* bias; int N, Cin, ksize; const int* colmap; int Np;
+  float* w_fwd; float* b_fwd; int Cdp; float* w_dgrad; int wino_fwd, wino_dgrad;
+  int work_begin;
+} sininn_pack_desc;
+int sininn_pack_work_items(const sininn_pack_desc* host_desc);
+int sininn_pack_batch(const sininn_pack_desc* descs, int n, int total_work, void* stream);
+
 /* Packed column order used by the coupling epilogue for a subnet with 2*Co outputs (s | t):
  * `tile`-column MFMA tile q = [ s[h*q .. h*q+h-1] | t[h*q .. h*q+h-1] ], h = tile/2, tile in {16, 32}
  * (tile 32 needs Co % 16 == 0).  Writes 2*Co ints (host memory).  The same `tile` must be passed as

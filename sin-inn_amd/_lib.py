@@ -51,6 +51,13 @@ class GlowArgs(C.Structure):
                 ('dout', c_f), ('gld', c_f), ('dx', c_f)]
 
 
+class PackDesc(C.Structure):
+    """Mirror of sininn_pack_desc."""
+    _fields_ = [('w', c_f), ('bias', c_f), ('N', C.c_int), ('Cin', C.c_int), ('ksize', C.c_int), ('colmap', c_i),
+                ('Np', C.c_int), ('w_fwd', c_f), ('b_fwd', c_f), ('Cdp', C.c_int), ('w_dgrad', c_f),
+                ('wino_fwd', C.c_int), ('wino_dgrad', C.c_int), ('work_begin', C.c_int)]
+
+
 CONV_RELU, CONV_COUPLE_FWD, CONV_COUPLE_INV, CONV_MASK, CONV_ADD, CONV_LINEAR = range(6)
 
 _SIGS = {
@@ -58,6 +65,8 @@ _SIGS = {
     'sininn_last_error': (C.c_char_p, []),
     'sininn_pack_conv_weights': (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, c_i, C.c_int, c_f, c_f, C.c_int, c_f, C.c_void_p]),
     'sininn_pack_winograd': (C.c_int, [c_f, C.c_int, C.c_int, c_i, C.c_int, c_f, C.c_int, c_f, C.c_void_p]),
+    'sininn_pack_work_items': (C.c_int, [C.POINTER(PackDesc)]),
+    'sininn_pack_batch': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'sininn_coupling_colmap': (None, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
     'sininn_conv': (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     'sininn_conv_test_hooks': (None, [C.c_int, C.c_int]),

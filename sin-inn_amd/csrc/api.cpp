@@ -62,6 +62,8 @@ int irn_coupling_bwd_launch(const float* dy, int dy_stride, const float* vy, int
                             hipStream_t st);
 void profile_begin(int h);
 int profile_end(int* count, float* total_ms);
+int pack_work_items(const sininn_pack_desc* d);
+int pack_batch_launch(const sininn_pack_desc* descs, int n, int total, hipStream_t st);
 int pack_winograd_launch(const float* w, int N, int Cin, const int* colmap, int Np, float* u_fwd, int Cdp,
                          float* u_dgrad, hipStream_t st);
 int bayer_bin_launch(const uint8_t* hr, uint8_t* lr, int T, int H, int W, int scale, int reduce_sum, hipStream_t st);
@@ -84,6 +86,10 @@ int sininn_pack_conv_weights(const float* w_oihw, const float* bias, int N, int 
   return pack_launch(w_oihw, bias, N, Cin, ksize, colmap, Np, w_fwd, b_fwd, Cdp, w_dgrad, ST(stream));
 }
 
+int sininn_pack_work_items(const sininn_pack_desc* host_desc) { return host_desc ? pack_work_items(host_desc) : 0; }
+int sininn_pack_batch(const sininn_pack_desc* descs, int n, int total_work, void* stream) {
+  return pack_batch_launch(descs, n, total_work, ST(stream));
+}
 int sininn_pack_winograd(const float* w_oihw, int N, int Cin, const int* colmap, int Np, float* u_fwd, int Cdp,
                          float* u_dgrad, void* stream) {
   return pack_winograd_launch(w_oihw, N, Cin, colmap, Np, u_fwd, Cdp, u_dgrad, ST(stream));

@@ -892,6 +892,81 @@ __global__ void pack_winograd_kernel(const float* __restrict__ w, int N, int Cin
   }
 }
 
+// ---- batched packs: one launch refreshes every pack of a model ------------------------------------------------------
+__host__ __device__ static inline void pack_regions(const sininn_pack_desc& d, int& nf, int& nd, int& nb) {
+  const int taps = d.ksize * d.ksize;
+  nf = d.w_fwd ? (d.wino_fwd ? d.Np * d.Cin : taps * d.Np * d.Cin) : 0;
+  nd = d.w_dgrad ? (d.wino_dgrad ? d.Cdp * d.N : taps * d.Cdp * d.N) : 0;
+  nb = d.b_fwd ? d.Np : 0;
+}
+
+int pack_work_items(const sininn_pack_desc* d) {
+  int nf, nd, nb;
+  pack_regions(*d, nf, nd, nb);
+  return nf + nd + nb;
+}
+
+__global__ void pack_batch_kernel(const sininn_pack_desc* __restrict__ descs, int n, int total) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int lo = 0, hi = n - 1;                              // last descriptor with work_begin <= idx
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].work_begin <= idx) lo = mid; else hi = mid - 1;
+  }
+  const sininn_pack_desc d = descs[lo];
+  int k = idx - d.work_begin;
+  int nf, nd, nb;
+  pack_regions(d, nf, nd, nb);
+  const int taps = d.ksize * d.ksize;
+  float g[9], u[16];
+  if (k < nf) {
+    if (d.wino_fwd) {
+      const int c = k % d.Cin, q = k / d.Cin;
+      const int nn = d.colmap ? d.colmap[q] : q;
+      const bool ok = nn >= 0 && nn < d.N;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) g[t] = ok ? d.w[((size_t)nn * d.Cin + c) * 9 + t] : 0.f;
+      wino_filter(g, u);
+#pragma unroll
+      for (int pz = 0; pz < 16; ++pz) d.w_fwd[((size_t)pz * d.Np + q) * d.Cin + c] = u[pz];
+    } else {
+      const int c = k % d.Cin, q = (k / d.Cin) % d.Np, t = k / (d.Cin * d.Np);
+      const int nn = d.colmap ? d.colmap[q] : q;
+      d.w_fwd[k] = (nn >= 0 && nn < d.N) ? d.w[((size_t)nn * d.Cin + c) * taps + t] : 0.f;
+    }
+    return;
+  }
+  k -= nf;
+  if (k < nd) {
+    if (d.wino_dgrad) {
+      const int nn = k % d.N, c = k / d.N;
+      const bool ok = c < d.Cin;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) g[t] = ok ? d.w[((size_t)nn * d.Cin + c) * 9 + (8 - t)] : 0.f;
+      wino_filter(g, u);
+#pragma unroll
+      for (int pz = 0; pz < 16; ++pz) d.w_dgrad[((size_t)pz * d.Cdp + c) * d.N + nn] = u[pz];
+    } else {
+      const int nn = k % d.N, c = (k / d.N) % d.Cdp, t = k / (d.N * d.Cdp);
+      d.w_dgrad[k] = (c < d.Cin) ? d.w[((size_t)nn * d.Cin + c) * taps + (taps - 1 - t)] : 0.f;
+    }
+    return;
+  }
+  k -= nd;
+  if (k < nb) {
+    const int nn = d.colmap ? d.colmap[k] : k;
+    d.b_fwd[k] = (d.bias && nn >= 0 && nn < d.N) ? d.bias[nn] : 0.f;
+  }
+}
+
+int pack_batch_launch(const sininn_pack_desc* descs, int n, int total, hipStream_t st) {
+  SININN_CHECK(descs != nullptr && n > 0 && total > 0, "pack_batch: bad arguments");
+  hipLaunchKernelGGL(pack_batch_kernel, dim3((total + 255) / 256), dim3(256), 0, st, descs, n, total);
+  SININN_LAUNCH_CHECK("pack_batch");
+  return 0;
+}
+
 int pack_winograd_launch(const float* w, int N, int Cin, const int* colmap, int Np, float* u_fwd, int Cdp,
                          float* u_dgrad, hipStream_t st) {
   SININN_CHECK(w != nullptr && N > 0 && Cin > 0 && (u_fwd || u_dgrad), "pack_winograd: bad arguments");

@@ -9,6 +9,8 @@ pixel-major (NHWC) inside the network, NCHW-shaped channels_last views at the bo
 import ctypes as C
 
 import numpy as np
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -23,7 +25,10 @@ WEIGHTS_EPOCH = [0]
 
 
 def bump_weights_epoch():
+    """Called by the fused optimiser after it has written new weights: invalidates every cached pack and refreshes the
+    registered ones with one batched launch on the current stream."""
     WEIGHTS_EPOCH[0] += 1
+    _PACK_REGISTRY.refresh()
 
 
 def _vp(t, off=0, dtype=torch.float32):
@@ -84,18 +89,73 @@ USE_WINOGRAD = [_os.environ.get('SININN_WINOGRAD', '1') != '0']
 
 
 class _PackCache:
+    """Packed weights of the convs of one block.  Buffers are persistent: a stale entry is refreshed in place, and every
+    live entry is registered so that the optimiser step can refresh ALL packs of the model with one launch."""
+
     def __init__(self):
         self.store = {}
 
+    @staticmethod
+    def _key(conv, want_dgrad, wino_fwd, wino_dgrad):
+        return (conv.weight.data_ptr(), conv.weight._version, conv.bias._version, WEIGHTS_EPOCH[0], want_dgrad,
+                wino_fwd, wino_dgrad)
+
     def get(self, conv, colmap, want_dgrad, wino_fwd=False, wino_dgrad=False):
-        key = (conv.weight.data_ptr(), conv.weight._version, conv.bias._version, WEIGHTS_EPOCH[0], want_dgrad,
-               wino_fwd, wino_dgrad)
+        key = self._key(conv, want_dgrad, wino_fwd, wino_dgrad)
         hit = self.store.get(id(conv))
-        if hit is None or hit[0] != key:
-            packs = ops.pack_conv(conv.weight.detach(), conv.bias.detach(), colmap, want_dgrad, wino_fwd, wino_dgrad)
-            hit = (key, packs)
-            self.store[id(conv)] = hit
-        return hit[1]
+        if hit is None or hit.key != key:
+            same_shape = hit is not None and hit.key[0] == key[0] and hit.key[4:] == key[4:]
+            packs = ops.pack_conv(conv.weight.detach(), conv.bias.detach(), colmap, want_dgrad, wino_fwd, wino_dgrad,
+                                  out=hit.packs if same_shape else None)
+            if same_shape:
+                hit.key = key
+            else:
+                if hit is not None:
+                    _PACK_REGISTRY.discard(hit)
+                hit = _PackEntry(conv, colmap, key, packs)
+                self.store[id(conv)] = hit
+                _PACK_REGISTRY.add(hit)
+        return hit.packs
+
+
+class _PackEntry:
+    def __init__(self, conv, colmap, key, packs):
+        self.conv = weakref.ref(conv)
+        self.colmap, self.key, self.packs = colmap, key, packs
+
+
+class _PackRegistry:
+    """All live pack entries; refresh() re-packs every one of them from the current weights in a single launch."""
+
+    def __init__(self):
+        self.entries = []
+        self.table = None
+
+    def add(self, entry):
+        self.entries.append(entry)
+        self.table = None
+
+    def discard(self, entry):
+        self.entries = [e for e in self.entries if e is not entry]
+        self.table = None
+
+    def refresh(self):
+        live = [e for e in self.entries if e.conv() is not None and e.conv().weight.is_cuda]
+        if len(live) != len(self.entries):
+            self.entries, self.table = live, None
+        if not live:
+            return
+        ptrs = tuple(e.conv().weight.data_ptr() for e in live)
+        if self.table is None or self.table[0] != ptrs:
+            descs = [ops.pack_desc(e.conv().weight.detach(), e.conv().bias.detach(), e.colmap, e.packs, e.key[5], e.key[6])
+                     for e in live]
+            self.table = (ptrs, ops.pack_batch(descs, live[0].conv().weight.device))
+        ops.pack_batch_run(self.table[1])
+        for e in live:
+            e.key = _PackCache._key(e.conv(), *e.key[4:])
+
+
+_PACK_REGISTRY = _PackRegistry()
 
 
 # ------------------------------------------------------------------------------------------------

@@ -64,10 +64,11 @@ def pad32(n):
     return (n + 31) // 32 * 32
 
 
-def pack_conv(weight, bias, colmap=None, want_dgrad=True, wino_fwd=False, wino_dgrad=False):
+def pack_conv(weight, bias, colmap=None, want_dgrad=True, wino_fwd=False, wino_dgrad=False, out=None):
     """OIHW conv weight -> (w_fwd, b_fwd, w_dgrad).
     tap-major packs: w_fwd [taps][Np][Cin], w_dgrad [taps][pad16(Cin)][N];
-    Winograd packs (3x3 only): w_fwd [16][Np][Cin], w_dgrad [16][pad32(Cin)][N]  (U = G g G^T)."""
+    Winograd packs (3x3 only): w_fwd [16][Np][Cin], w_dgrad [16][pad32(Cin)][N]  (U = G g G^T).
+    `out` = a previous result of the same call to refresh in place."""
     _chk(weight)
     n, cin, k, _ = weight.shape
     assert weight.is_contiguous() and (bias is None or bias.is_contiguous())
@@ -77,12 +78,15 @@ def pack_conv(weight, bias, colmap=None, want_dgrad=True, wino_fwd=False, wino_d
     npk = colmap.numel() if colmap is not None else pad16(n)
     taps = k * k
     cmap = ptr(colmap, dtype=torch.int32)
-    b_fwd = torch.empty(npk, device=dev, dtype=torch.float32)
-    w_fwd = torch.empty((16 if wino_fwd else taps) * npk * cin, device=dev, dtype=torch.float32)
-    w_dg = None
-    if want_dgrad:
-        cdp = pad32(cin) if wino_dgrad else pad16(cin)
-        w_dg = torch.empty((16 if wino_dgrad else taps) * cdp * n, device=dev, dtype=torch.float32)
+    if out is not None:
+        w_fwd, b_fwd, w_dg = out
+    else:
+        b_fwd = torch.empty(npk, device=dev, dtype=torch.float32)
+        w_fwd = torch.empty((16 if wino_fwd else taps) * npk * cin, device=dev, dtype=torch.float32)
+        w_dg = None
+        if want_dgrad:
+            cdp = pad32(cin) if wino_dgrad else pad16(cin)
+            w_dg = torch.empty((16 if wino_dgrad else taps) * cdp * n, device=dev, dtype=torch.float32)
     # tap-major parts (+ the packed bias) in one launch, Winograd parts in another
     check(lib.sininn_pack_conv_weights(ptr(weight), ptr(bias), n, cin, k, cmap, npk,
                                        None if wino_fwd else ptr(w_fwd), ptr(b_fwd),
@@ -91,6 +95,38 @@ def pack_conv(weight, bias, colmap=None, want_dgrad=True, wino_fwd=False, wino_d
         check(lib.sininn_pack_winograd(ptr(weight), n, cin, cmap, npk, ptr(w_fwd) if wino_fwd else None,
                                        pad32(cin), ptr(w_dg) if (want_dgrad and wino_dgrad) else None, _stream()))
     return w_fwd, b_fwd, w_dg
+
+
+def pack_desc(weight, bias, colmap, packs, wino_fwd, wino_dgrad):
+    """sininn_pack_desc refreshing `packs` (a pack_conv result) from (weight, bias)."""
+    n, cin, k, _ = weight.shape
+    w_fwd, b_fwd, w_dg = packs
+    d = _lib.PackDesc()
+    d.w, d.bias, d.N, d.Cin, d.ksize = ptr(weight), ptr(bias), n, cin, k
+    d.colmap = ptr(colmap, dtype=torch.int32)
+    d.Np = colmap.numel() if colmap is not None else pad16(n)
+    d.w_fwd, d.b_fwd = ptr(w_fwd), ptr(b_fwd)
+    d.Cdp = (pad32(cin) if wino_dgrad else pad16(cin))
+    d.w_dgrad = ptr(w_dg)
+    d.wino_fwd, d.wino_dgrad = int(bool(wino_fwd)), int(bool(wino_dgrad and w_dg is not None))
+    return d
+
+
+def pack_batch(descs, device):
+    """Upload a list of PackDesc and return (device table tensor, n, total_work) for pack_batch_run."""
+    lib = _lib.lib()
+    arr = (_lib.PackDesc * len(descs))(*descs)
+    total = 0
+    for d in arr:
+        d.work_begin = total
+        total += lib.sininn_pack_work_items(C.byref(d))
+    raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+    return raw, len(descs), total
+
+
+def pack_batch_run(table):
+    raw, n, total = table
+    check(_lib.lib().sininn_pack_batch(C.c_void_p(raw.data_ptr()), n, total, _stream()))
 
 
 # ---- conv engine ---------------------------------------------------------------------------------

@@ -327,3 +327,24 @@ def _winograd_conv_case(dev, ops, _lib, cin, n, hw):
     ops.conv(in_=ops.ptr(nhwc(g)), in_stride=n, Cin=n, w=ops.ptr(wd), Np=ops.pad32(cin), winograd=1, B=2, H=h, W=w, ksize=3,
              mode=_lib.CONV_ADD, out=ops.ptr(dx), out_stride=cin, N=cin, addend=ops.ptr(add), addend_stride=cin)
     assert relerr(nchw(dx), xin.grad + nchw(add)) < RTOL
+
+
+def test_pack_batch_matches_single_packs(env):
+    """sininn_pack_batch (one launch for all convs) writes exactly what the per-conv pack entry points write."""
+    S, O, dev = env
+    from sin_inn_amd import ops
+    torch.manual_seed(3)
+    cases = [(256, 24, 3, None, True, True), (48, 256, 3, ops.coupling_colmap(24, dev), True, True),
+             (256, 96, 1, None, False, False), (192, 256, 1, ops.coupling_colmap(96, dev), False, False),
+             (256, 40, 3, None, True, False)]
+    singles, descs, batched = [], [], []
+    for n, cin, k, cmap, wf, wd in cases:
+        w = torch.randn(n, cin, k, k, device=dev); b = torch.randn(n, device=dev)
+        singles.append(ops.pack_conv(w, b, cmap, True, wf, wd))
+        out = tuple(torch.full_like(t, float('nan')) for t in singles[-1])
+        batched.append(out)
+        descs.append(ops.pack_desc(w, b, cmap, out, wf, wd))
+    ops.pack_batch_run(ops.pack_batch(descs, dev))
+    for a, b in zip(singles, batched):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
