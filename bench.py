@@ -101,7 +101,7 @@ def main():
     ap.add_argument('--frames', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=2)
-    ap.add_argument('--wgrad16', type=int, default=0, help='diagnostic: force the 16x16x4 weight-gradient kernel')
+    ap.add_argument('--wgrad16', type=int, default=0, help='diagnostic (sininn_wgrad_test_hooks): bit0 16x16x4 tiles, bit1 no Winograd wgrad, bit2 8-row tiles')
     ap.add_argument('--no-overlap', action='store_true', help='diagnostic: single stream (no pass / wgrad overlap)')
     args = ap.parse_args()
 
@@ -181,7 +181,7 @@ def main():
         ach = flops / (kms * 1e-3) / 1e12
         roof = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
-                'kernel': 'wino_kernel<2,8> (fused 3x3 coupling conv 256->48 + affine + log-det, level 0; Winograd '
+                'kernel': 'wino_kernel<2,8,2> (fused 3x3 coupling conv 256->48 + affine + log-det, level 0; Winograd '
                           'F(2x2,3x3): executes 2.25x fewer MFMA FLOPs than the algorithmic direct-conv count used here)',
                 'launches_timed': timer.count, 'avg_ms': kms, 'alg_flops_per_launch': flops,
                 'alg_bytes_per_launch': 4.0 * (m0 * 256 + m0 * 3 * co0 + 9 * 256 * 2 * co0)}
