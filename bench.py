@@ -101,7 +101,7 @@ def main():
     ap.add_argument('--frames', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=2)
-    ap.add_argument('--wgrad16', type=int, default=0, help='diagnostic (sininn_wgrad_test_hooks): bit0 16x16x4 tiles, bit1 no Winograd wgrad, bit2 8-row tiles')
+    ap.add_argument('--wgrad16', type=int, default=0, help='diagnostic (sininn_wgrad_test_hooks): bit0 16x16x4 tiles, bit1 no Winograd wgrad, bit2 8-row tiles, bit3 8-wave k-split blocks')
     ap.add_argument('--no-overlap', action='store_true', help='diagnostic: single stream (no pass / wgrad overlap)')
     args = ap.parse_args()
 

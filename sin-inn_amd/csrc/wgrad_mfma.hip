@@ -23,9 +23,6 @@ struct WgradDev {
   int Nr, Cc;
 };
 
-#ifndef WGW_ABLATE
-#define WGW_ABLATE 0   // timing experiments only: 1 no MFMA, 2 no transforms, 4 no tile reloads
-#endif
 constexpr int WG_TH = 8;   // pixel tile 8 x 16
 
 template <int KS, int RT, int CT, int WR, int WC>
@@ -318,18 +315,27 @@ __global__ __launch_bounds__(256, 2) void wgrad32_kernel(WgradDev p) {
 //   cols = c, k = 4 Winograd tiles.  Block = 64 n x 32 c, waves 2 x 2, wave tile 32 n x 16 c x 16 positions
 //   (128 accumulator VGPRs); pixel tiles of 8x16 (32 Winograd tiles = 8 k-steps) are walked split-K style.
 // ------------------------------------------------------------------------------------------------
-template <int TH, int UNR>
-__global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgradDev p) {
+template <int TH, int UNR, int KH>
+__global__ __launch_bounds__(256 * KH, 2 / KH) void wgrad_wino_kernel(WgradDev p) {
+  // KH = 2: eight waves; the two wave quads take alternate halves of every pixel tile's k-steps and are summed through
+  // LDS at the end -> one slab per CU instead of two (half the split-K slab traffic), one staged tile per 8 waves.
+  constexpr int NTHR = 256 * KH;
   constexpr int IW = 18, IH = TH + 2, NPIX_IN = IH * IW, NPIX = TH * 16;
   constexpr int BNW = 64, BCW = 32;
   constexpr int SD = BNW + 8, SI = BCW + 8;            // 2*SD == 2*SI == 16 (mod 32): the 4 k-lanes hit disjoint banks
-  constexpr int D_F4 = (NPIX * BNW / 4 + 255) / 256;
-  constexpr int I_F4 = (NPIX_IN * BCW / 4 + 255) / 256;
-  __shared__ __attribute__((aligned(16))) float d_lds[NPIX * SD];
-  __shared__ __attribute__((aligned(16))) float i_lds[NPIX_IN * SI];
+  constexpr int D_F4 = (NPIX * BNW / 4 + NTHR - 1) / NTHR;
+  constexpr int I_F4 = (NPIX_IN * BCW / 4 + NTHR - 1) / NTHR;
+  constexpr int KSTEPS = TH / KH;                      // k-steps of a tile per wave
+  constexpr int LDS_TILE = NPIX * SD + NPIX_IN * SI;
+  constexpr int LDS_RED = (KH == 2) ? 16 * 256 * 4 : 0;   // 8 positions x 2 row tiles x 256 lanes x float4
+  constexpr int LDS_FLOATS = LDS_TILE > LDS_RED ? LDS_TILE : LDS_RED;
+  static_assert(TH % KH == 0, "k-steps must split evenly");
+  __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
+  float* const d_lds = smem;
+  float* const i_lds = smem + NPIX * SD;
 
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
+  const int wave = (tid >> 6) & 3, kh = tid >> 8, lane = tid & 63;
   const int li = lane & 15, kq = lane >> 4;
   const int wr = wave & 1, wc = wave >> 1;
   const int split = blockIdx.x;
@@ -352,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgradDev p) {
     const int y0 = ty * TH, x0 = tx * 16;
 #pragma unroll
     for (int r = 0; r < D_F4; ++r) {
-      const int f = tid + 256 * r;
+      const int f = tid + NTHR * r;
       const int pix = f / (BNW / 4), n4 = f % (BNW / 4);
       const int gy = y0 + pix / 16, gx = x0 + (pix & 15);
       const int n = n0 + n4 * 4;
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgradDev p) {
     }
 #pragma unroll
     for (int r = 0; r < I_F4; ++r) {
-      const int f = tid + 256 * r;
+      const int f = tid + NTHR * r;
       const int pix = f / (BCW / 4), c4 = f % (BCW / 4);
       const int py = pix / IW, px = pix - py * IW;
       const int gy = y0 + py - 1, gx = x0 + px - 1;
@@ -377,13 +383,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgradDev p) {
   auto store_tile = [&]() {
 #pragma unroll
     for (int r = 0; r < D_F4; ++r) {
-      const int f = tid + 256 * r;
+      const int f = tid + NTHR * r;
       const int pix = f / (BNW / 4), n4 = f % (BNW / 4);
       if (pix < NPIX) *reinterpret_cast<f32x4*>(d_lds + pix * SD + n4 * 4) = d_reg[r];
     }
 #pragma unroll
     for (int r = 0; r < I_F4; ++r) {
-      const int f = tid + 256 * r;
+      const int f = tid + NTHR * r;
       const int pix = f / (BCW / 4), c4 = f % (BCW / 4);
       if (pix < NPIX_IN) *reinterpret_cast<f32x4*>(i_lds + pix * SI + c4 * 4) = i_reg[r];
     }
@@ -391,14 +397,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgradDev p) {
 
   if (t_begin < t_end) load_tile(t_begin);
   for (int tile = t_begin; tile < t_end; ++tile) {
-    if (!(WGW_ABLATE & 4) || tile == t_begin) {
     __syncthreads();
     store_tile();
     __syncthreads();
-    if (tile + 1 < t_end && !(WGW_ABLATE & 4)) load_tile(tile + 1);
-    }
+    if (tile + 1 < t_end) load_tile(tile + 1);
 #pragma unroll UNR
-    for (int ks = 0; ks < TH; ++ks) {
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+      const int ks = kh * KSTEPS + kk;
       const int t = 4 * ks + kq;                       // this lane's Winograd tile (k index)
       const int ty2 = 2 * (t >> 3), tx2 = 2 * (t & 7);
       // ---- V = B^T d B for (input channel c = 16*wc + li, tile t) ---------------------------------
@@ -406,10 +411,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgradDev p) {
       {
         const float* ip = i_lds + (ty2 * IW + tx2) * SI + 16 * wc + li;
         float tt[4][4];
-        if (WGW_ABLATE & 2) {
-#pragma unroll
-          for (int q = 0; q < 16; ++q) v[q] = ip[q];
-        } else {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const float d0 = ip[(0 * IW + c) * SI], d1 = ip[(1 * IW + c) * SI], d2 = ip[(2 * IW + c) * SI], d3 = ip[(3 * IW + c) * SI];
@@ -421,7 +422,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgradDev p) {
           v[a * 4 + 1] = tt[a][1] + tt[a][2];
           v[a * 4 + 2] = tt[a][2] - tt[a][1];
           v[a * 4 + 3] = tt[a][1] - tt[a][3];
-        }
         }
       }
       // ---- W = A dY A^T for (output channel n = 32*wr + 16*a + li, tile t), a = 0, 1 ---------------
@@ -438,19 +438,40 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(WgradDev p) {
         w[4] = r10; w[5] = r10 + r11; w[6] = r10 - r11; w[7] = -r11;
         w[8] = r20; w[9] = r20 + r21; w[10] = r20 - r21; w[11] = -r21;
         w[12] = r30; w[13] = r30 + r31; w[14] = r30 - r31; w[15] = -r31;
-        if (WGW_ABLATE & 2) {
-#pragma unroll
-          for (int q = 0; q < 16; ++q) w[q] = (q & 1) ? y01 : y00;
-        }
-        if (WGW_ABLATE & 1) {
-#pragma unroll
-          for (int q = 0; q < 16; ++q) acc[q][a][0] += w[q] * v[q];
-        } else {
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[q][a] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q], v[q], acc[q][a], 0, 0, 0);
-        }
       }
     }
+  }
+
+  // ---- KH = 2: add the second wave quad's accumulators (and bias sums) to the first through LDS, 8 positions at a time
+  if constexpr (KH == 2) {
+    f32x4* const red = reinterpret_cast<f32x4*>(smem);
+    const int slot = wave * 64 + lane;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();                                 // tile buffers (first round) / previous round consumed
+      if (kh == 1) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+          for (int a = 0; a < 2; ++a) red[(q * 2 + a) * 256 + slot] = acc[half * 8 + q][a];
+      }
+      __syncthreads();
+      if (kh == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+          for (int a = 0; a < 2; ++a) acc[half * 8 + q][a] += red[(q * 2 + a) * 256 + slot];
+      }
+    }
+    __syncthreads();
+    float* const bred = smem;
+    if (kh == 1) { bred[slot * 2 + 0] = bsum[0]; bred[slot * 2 + 1] = bsum[1]; }
+    __syncthreads();
+    if (kh == 1) return;
+    bsum[0] += bred[slot * 2 + 0];
+    bsum[1] += bred[slot * 2 + 1];
   }
 
   // ---- dg = G^T dU G per lane (all 16 positions of an (n, c) pair live in one lane), then the 9-tap slab write:
@@ -554,12 +575,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-struct WgradPlan { int RT, CT, Nr, Cc, nblk, cblk, S, tiles_per_split, ntiles, tiles_x, tiles_y; size_t bytes; bool use32; bool wino; int th; };
+struct WgradPlan { int RT, CT, Nr, Cc, nblk, cblk, S, tiles_per_split, ntiles, tiles_x, tiles_y; size_t bytes; bool use32; bool wino; int th; int kh; };
 
 static bool g_wgrad_force16 = false;   // test hook
 static bool g_wgrad_wino = true;       // Winograd weight gradient for 3x3 (test hook bit 1 disables)
 static bool g_wgrad_wino_th8 = false;  // test hook bit 2: 8-row pixel tiles in the Winograd weight gradient
-void wgrad_set_force16(int on) { g_wgrad_force16 = (on & 1) != 0; g_wgrad_wino = (on & 2) == 0; g_wgrad_wino_th8 = (on & 4) != 0; }
+static bool g_wgrad_wino_kh2 = false;  // test hook bit 3: 8-wave blocks with an in-block k split (half the slabs; same kernel
+                                       // time, but 3 % slower end to end when other streams' kernels co-run) -- off
+void wgrad_set_force16(int on) { g_wgrad_force16 = (on & 1) != 0; g_wgrad_wino = (on & 2) == 0; g_wgrad_wino_th8 = (on & 4) != 0; g_wgrad_wino_kh2 = (on & 8) != 0; }
 
 static WgradPlan make_plan(int N, int Cin, int ksize, int B, int H, int W) {
   WgradPlan pl;
@@ -576,12 +599,13 @@ static WgradPlan make_plan(int N, int Cin, int ksize, int B, int H, int W) {
   pl.Nr = pl.nblk * bnw;
   pl.Cc = pl.cblk * bcw;
   pl.tiles_x = (W + 15) / 16;
-  pl.th = (pl.wino && !(g_wgrad_wino_th8)) ? 4 : WG_TH;
+  pl.kh = (pl.wino && g_wgrad_wino_kh2) ? 2 : 1;      // 8-wave blocks, in-block k split
+  pl.th = (pl.wino && !g_wgrad_wino_th8 && pl.kh == 1) ? 4 : WG_TH;
   pl.tiles_y = (H + pl.th - 1) / pl.th;
   pl.ntiles = B * pl.tiles_x * pl.tiles_y;
   // the RT=3 tile (N=48) needs ~90 KB of LDS and >256 registers: one block per CU -> aim for one round of 256
   // blocks (half the slab traffic of 512); the other tiles run two blocks per CU
-  int S = ((pl.RT == 3 && !pl.wino) ? 256 : 512) / (pl.nblk * pl.cblk);
+  int S = (((pl.RT == 3 && !pl.wino) || pl.kh == 2) ? 256 : 512) / (pl.nblk * pl.cblk);
   if (S < 1) S = 1;
   if (S > pl.ntiles) S = pl.ntiles;
   pl.tiles_per_split = (pl.ntiles + S - 1) / S;
@@ -622,8 +646,9 @@ int wgrad_launch(const float* in, int in_stride, int Cin, const float* dout, int
   d.partial = static_cast<float*>(ws);
   d.bpartial = d.partial + (size_t)pl.S * taps * pl.Nr * pl.Cc;
   if (pl.wino) {
-    if (pl.th == 4) hipLaunchKernelGGL((wgrad_wino_kernel<4, 2>), dim3(pl.S, pl.nblk, pl.cblk), dim3(256), 0, st, d);
-    else hipLaunchKernelGGL((wgrad_wino_kernel<8, 1>), dim3(pl.S, pl.nblk, pl.cblk), dim3(256), 0, st, d);
+    if (pl.kh == 2) hipLaunchKernelGGL((wgrad_wino_kernel<8, 2, 2>), dim3(pl.S, pl.nblk, pl.cblk), dim3(512), 0, st, d);
+    else if (pl.th == 4) hipLaunchKernelGGL((wgrad_wino_kernel<4, 2, 1>), dim3(pl.S, pl.nblk, pl.cblk), dim3(256), 0, st, d);
+    else hipLaunchKernelGGL((wgrad_wino_kernel<8, 1, 1>), dim3(pl.S, pl.nblk, pl.cblk), dim3(256), 0, st, d);
     SININN_LAUNCH_CHECK("wgrad_wino");
   } else {
     if (ksize == 3) launch_wgrad<3>(pl, d, st); else launch_wgrad<1>(pl, d, st);

@@ -108,7 +108,8 @@ def test_conv_strided_input_and_mask_add(env, ksize):
 
 @pytest.mark.parametrize('ksize', [3, 1])
 @pytest.mark.parametrize('cin,n', [(256, 48), (24, 256), (96, 256), (256, 192)])
-@pytest.mark.parametrize('force16', [0, 1, 2, 3])    # bit0: 16-wide MFMA tiles, bit1: no Winograd wgrad for 3x3
+@pytest.mark.parametrize('force16', [0, 1, 2, 3, 8, 12])   # bit0: 16-wide MFMA tiles, bit1: no Winograd wgrad for 3x3,
+                                                            # bit2: 8-row tiles, bit3: 8-wave blocks with in-block k split
 def test_wgrad(env, ksize, cin, n, force16):
     S, O, dev = env
     from sin_inn_amd import ops, _lib
