@@ -101,6 +101,7 @@ def main():
     ap.add_argument('--frames', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=2)
+    ap.add_argument('--conv-cfg', type=int, default=0, help='diagnostic (sininn_conv_test_hooks force_cfg): 1 / 2 pin 32- / 64-column Winograd blocks')
     ap.add_argument('--wgrad16', type=int, default=0, help='diagnostic (sininn_wgrad_test_hooks): bit0 16x16x4 tiles, bit1 no Winograd wgrad, bit2 8-row tiles, bit3 8-wave k-split blocks')
     ap.add_argument('--no-overlap', action='store_true', help='diagnostic: single stream (no pass / wgrad overlap)')
     args = ap.parse_args()
@@ -119,6 +120,7 @@ def main():
 
     from sin_inn_amd import _lib as _l, modules as _m
     _l.lib().sininn_wgrad_test_hooks(args.wgrad16)
+    _l.lib().sininn_conv_test_hooks(args.conv_cfg, 0)
     if args.no_overlap:
         _m.USE_SIDE_STREAM[0] = False
     opt = make_opt(args.num_coupling, args.lr_window)

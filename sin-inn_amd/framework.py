@@ -151,6 +151,8 @@ class ReversibleGraphNet(nn.Module):
         dev = x.device
         cur = x                                   # (B,C,H,W)-shaped, any strides
         pixel_major = False                       # True once `cur` is a contiguous (B,H,W,C) tensor
+        n_glow = sum(1 for kind, _ in steps if kind == 'glow')
+        ld_rows = iter(torch.zeros(n_glow, x.shape[0], device=dev, dtype=torch.float32)) if n_glow else None
         for kind, p in steps:
             cmap = None
             if p.get('perm') is not None:
@@ -166,6 +168,7 @@ class ReversibleGraphNet(nn.Module):
                 if not pixel_major:
                     cur = import_nchw(cur)
                     pixel_major = True
+                p['block']._ld_row = next(ld_rows)
                 cur = p['block'].apply_pixel_major(cur, rev=rev, dst=cmap)
             else:
                 src = cur.permute(0, 3, 1, 2) if pixel_major else cur

@@ -228,7 +228,11 @@ class _GlowFn(torch.autograd.Function):
         lib = _lib.lib()
         need_grad = any(ctx.needs_input_grad)      # False under torch.no_grad(): nothing is kept then
         out = torch.empty_like(x)
-        logdet = torch.zeros(b, device=dev, dtype=torch.float32)
+        # zero-initialised log-det accumulator: a row of the buffer the graph executor zeroed once for the whole pass
+        # (one fill instead of one per block), else a fresh tensor
+        logdet, block._ld_row = block._ld_row, None
+        if logdet is None or logdet.shape != (b,) or logdet.device != dev:
+            logdet = torch.zeros(b, device=dev, dtype=torch.float32)
         saved = torch.empty(lib.sininn_glow_saved_floats(b, h, w, c), device=dev, dtype=torch.float32)
         s1, keep1 = _subnet_args(block, block.s1, block.split_len2, dev, need_grad, False)
         s2, keep2 = _subnet_args(block, block.s2, block.split_len1, dev, need_grad, False)
@@ -293,6 +297,8 @@ class GLOWCouplingBlock(nn.Module):
 
     def _params(self):
         return [p for s in (self.s1, self.s2) for p in s.parameters()]
+
+    _ld_row = None          # set by ReversibleGraphNet.forward for the next call only
 
     def apply_pixel_major(self, x, rev=False, dst=None):
         out, logdet = _GlowFn.apply(x, self, bool(rev), dst, *self._params())
