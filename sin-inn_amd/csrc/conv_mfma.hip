@@ -77,7 +77,7 @@ int conv_launch(const sininn_conv_args* a, hipStream_t st) {
     SININN_CHECK(a->ksize == 3, "conv: the Winograd pack needs ksize 3");
     d.col_tile = (couple && a->col_tile == 32) ? 32 : 16;
     if (couple && d.col_tile == 32) SININN_CHECK(a->Co % 16 == 0, "conv: col_tile 32 needs Co %% 16 == 0");
-    return wino_dispatch_k3(d, st, g_force_cfg % 10);   // test hook: 1 pins 32-column blocks, 2 pins 64-column blocks
+    return wino_dispatch_k3(d, st, g_force_cfg % 16);   // test hook: see wino_dispatch
   }
   // column-tile width: coupling weights are packed for one specific width (col_tile); other modes take the
   // 32-wide MFMA shape whenever the column count allows (g_force_cfg >= 10 pins the 16-wide kernel for tests)

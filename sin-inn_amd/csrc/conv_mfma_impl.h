@@ -44,9 +44,10 @@ struct ConvDev {
 // addend, y, s) is a coalesced float4 instead of a per-lane 4-byte scatter.
 //   HT = half-tile of the coupling interleave: tile of 2*HT columns = [ s HT ch | t HT ch ].
 // ------------------------------------------------------------------------------------------------
+// T2 (optional): a second tile of partial sums added to T on the fly (position-split Winograd kernel).
 template <int TH, int BN, int HT, int NTHR = 256>
 __device__ __forceinline__ void conv_epilogue_tile(const ConvDev& p, const float* T, int b, int y0, int x0, int n0,
-                                                   int tid, float* red) {
+                                                   int tid, float* red, const float* T2 = nullptr) {
   constexpr int TS = BN + 4;
   constexpr int NPIX = TH * 16;
   const int MODE = p.mode;
@@ -65,6 +66,10 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvDev& p, const float
         const int tcol = (cl / HT) * (2 * HT) + (cl % HT);
         f32x4 s4 = *reinterpret_cast<const f32x4*>(T + pl * TS + tcol);
         f32x4 t4 = *reinterpret_cast<const f32x4*>(T + pl * TS + tcol + HT);
+        if (T2) {
+          s4 += *reinterpret_cast<const f32x4*>(T2 + pl * TS + tcol);
+          t4 += *reinterpret_cast<const f32x4*>(T2 + pl * TS + tcol + HT);
+        }
         if (p.bias) {
           s4 += *reinterpret_cast<const f32x4*>(p.bias + n0 + tcol);
           t4 += *reinterpret_cast<const f32x4*>(p.bias + n0 + tcol + HT);
@@ -109,6 +114,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvDev& p, const float
       if (col < p.N && gy < p.H && gx < p.W) {
         const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
         f32x4 val = *reinterpret_cast<const f32x4*>(T + pl * TS + q4 * 4);
+        if (T2) val += *reinterpret_cast<const f32x4*>(T2 + pl * TS + q4 * 4);
         const bool full = (col + 3 < p.N);
         if (MODE == SININN_CONV_RELU || MODE == SININN_CONV_LINEAR || MODE == SININN_CONV_LRELU) {
           if (p.bias) val += *reinterpret_cast<const f32x4*>(p.bias + col);   // packed bias has Np >= col+4 entries

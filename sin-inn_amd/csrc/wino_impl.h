@@ -20,6 +20,7 @@
 //     double-buffered through VGPRs -> LDS, one barrier per chunk.
 #pragma once
 #include "conv_mfma_impl.h"
+#include "wino32_impl.h"
 
 namespace sininn {
 
@@ -236,8 +237,11 @@ static int wino_launch(ConvDev& d, hipStream_t st) {
   return 0;
 }
 
-// cg2: 0 auto, 1 force 32-column blocks, 2 force 64-column blocks (test hook)
+// cg2 (test hook): 0 auto, 1 force 32-column blocks, 2 force 64-column blocks; +4: never the 32x32x2 kernel
+// (wino32_impl.h); +8: the 32x32x2 kernel wherever it applies (32-column blocks, 16-column coupling interleave)
 static int wino_dispatch(ConvDev& d, hipStream_t st, int cg2 = 0) {
+  const bool never32 = (cg2 & 4) != 0, always32 = (cg2 & 8) != 0;
+  cg2 &= 3;
   // 64-column blocks (8 waves sharing one halo tile) when the columns split evenly and the input is wide enough
   // for its re-reads to matter
   // (an even number of 32-column groups; the last group may be partial, as with 32-column blocks)
@@ -245,7 +249,11 @@ static int wino_dispatch(ConvDev& d, hipStream_t st, int cg2 = 0) {
   bool wide = even_groups && d.Cin >= 64;
   if (cg2 == 1) wide = false;
   if (cg2 == 2) wide = even_groups;
-  return wide ? wino_launch<2>(d, st) : wino_launch<1>(d, st);
+  if (wide) return wino_launch<2>(d, st);
+  // long K and few blocks (at most one 4-wave block per CU -> one wave per SIMD): the 32x32x2 kernel
+  const long blocks = (long)d.B * ((d.H + 15) / 16) * ((d.W + 15) / 16) * ((d.Np + 31) / 32);
+  const bool use32 = d.col_tile == 16 && !never32 && (always32 || (d.Cin >= 128 && blocks <= 256));
+  return use32 ? wino32_launch(d, st) : wino_launch<1>(d, st);
 }
 
 }  // namespace sininn

@@ -292,7 +292,7 @@ def test_bayer_bin_bit_exact(env, scale, reduction):
 
 @pytest.mark.parametrize('cin,n,hw', [(24, 256, (16, 32)), (256, 96, (12, 20)), (48, 256, (9, 17)), (8, 24, (5, 7)),
                                       (256, 48, (16, 16)), (192, 256, (40, 24)), (64, 128, (19, 33))])
-@pytest.mark.parametrize('cg', [1, 2])          # 32-column blocks / 64-column blocks (8 waves share the halo tile)
+@pytest.mark.parametrize('cg', [1, 2, 5, 9])    # 32- / 64-column blocks; +4 never / +8 always the 32x32x2 kernel
 def test_winograd_conv(env, cin, n, hw, cg):
     """Winograd F(2x2,3x3) kernel against torch conv2d: forward pack + LINEAR/RELU, data-gradient pack + ADD."""
     S, O, dev = env
