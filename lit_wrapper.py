@@ -66,6 +66,27 @@ class SingleVideoINN(pl.LightningModule):
         z = _latent(b, o.z_dims, h, w, hr.device)
         lr_z = _cat_channels(lr, z)
 
+        # The two passes are independent until the optimizer step (the reverse pass starts from the ground-truth LR and a
+        # fresh z, not from the forward output), so the reverse pass -- forward AND backward -- is queued on a second
+        # HIP stream that only waits for the inputs: kernels of the two chains interleave on the GPU and fill each
+        # other's prologue / epilogue / tail bubbles.  Weight gradients of both chains accumulate on ONE side stream
+        # (sin_inn_amd.modules), so the += into the shared gradient buffers stays ordered.
+        main = torch.cuda.current_stream()
+        # only networks whose parameter gradients are all accumulated on the dedicated side stream may run two
+        # backward chains at once (the SRF graph does; the Python-orchestrated IRN path accumulates on the calling stream)
+        concurrent = self.overlap_passes and getattr(self.inn, 'concurrent_passes_safe', False)
+        second = _second_stream(hr.device) if concurrent else main
+        if second is not main:
+            ready = torch.cuda.Event()
+            ready.record(main)                       # inputs produced, gradients zeroed
+            second.wait_event(ready)
+        with torch.cuda.stream(second):
+            # reverse pass: (LR | z) -> HR
+            hr_hat = self.inn(lr_z, rev=True)
+            bwd_loss = o.lambda_bwd_rec * loss.reconstruction(hr_hat, hr)
+            bwd_loss = bwd_loss + o.lambda_bwd_mmd * loss.mmd(hr_hat, hr, rev=True)
+            self.manual_backward(bwd_loss)
+
         # forward pass: HR -> (LR | z)
         lr_z_hat = self.inn(hr)
         fwd_loss = o.lambda_fwd_rec * loss.reconstruction(lr_z_hat[:, :o.lr_dims], lr)
@@ -73,19 +94,8 @@ class SingleVideoINN(pl.LightningModule):
         fwd_loss = fwd_loss + o.lambda_latent_nll * loss.latent_nll(lr_z_hat[:, o.lr_dims:])
         self.manual_backward(fwd_loss)
 
-        # reverse pass: (LR | z) -> HR.  It is independent of the forward pass until the optimizer step, so it is
-        # queued on a second HIP stream: kernels of the two passes interleave on the GPU and fill each other's
-        # prologue / epilogue / tail bubbles (weight-gradient accumulation stays ordered on its own stream).
-        main = torch.cuda.current_stream()
-        second = _second_stream(hr.device) if self.overlap_passes else main
-        second.wait_stream(main)
-        with torch.cuda.stream(second):
-            hr_hat = self.inn(lr_z, rev=True)
-            bwd_loss = o.lambda_bwd_rec * loss.reconstruction(hr_hat, hr)
-            bwd_loss = bwd_loss + o.lambda_bwd_mmd * loss.mmd(hr_hat, hr, rev=True)
-            self.manual_backward(bwd_loss)
         if second is not main:
-            for t in (hr, lr_z):
+            for t in (hr, lr, lr_z):
                 t.record_stream(second)
             main.wait_stream(second)
 

@@ -178,6 +178,13 @@ class ReversibleGraphNet(nn.Module):
                 pixel_major = True
         return cur.permute(0, 3, 1, 2) if pixel_major else cur
 
+    @property
+    def concurrent_passes_safe(self):
+        """True when two passes (forward + backward each) may run on two streams at once: every parameter gradient of
+        this graph is accumulated by the GLOW block executor on the dedicated weight-gradient stream."""
+        from .modules import USE_SIDE_STREAM
+        return bool(USE_SIDE_STREAM[0])
+
     def log_jacobian(self, x=None, c=None, rev=False, run_forward=True):
         if run_forward and x is not None:
             self.forward(x, rev=rev)
