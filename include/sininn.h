@@ -116,6 +116,9 @@ typedef struct sininn_conv_args {
   int col_tile;                                    /* coupling: 16 or 32, the (s|t) interleave of the weights */
   const float* mask; int mask_stride;              /* MASK mode                                            */
   const float* addend; int addend_stride; const int* addend_map; /* ADD mode                               */
+  unsigned long long* stamp;                       /* optional device words {start, end}: every block folds its entry /
+                                                      exit time (wall-clock ticks, sininn_wall_clock_khz) in with atomic
+                                                      min / max; initialise to {~0ull >> 1, 0}                       */
 } sininn_conv_args;
 
 int sininn_conv(const sininn_conv_args* args, void* stream);
@@ -189,10 +192,15 @@ typedef struct sininn_glow_args {
 } sininn_glow_args;
 
 /* Live timing for bench.py: between begin and end, every forward 3x3 coupling conv (conv2 + affine epilogue) of the
- * level whose image height is `level_height` is bracketed by HIP events on its launch stream; end() synchronises on
- * them and returns the number of launches timed and their summed duration. */
-void sininn_profile_begin(int level_height);
+ * level whose image height is `level_height` is (a) bracketed by HIP events on its launch stream and (b), when `stamps`
+ * (device, 2 words per launch, initialised to {~0ull >> 1, 0}) is given, stamped from inside the kernel (see
+ * sininn_conv_args.stamp; launch i uses words 2i, 2i+1, launches beyond max_launches are not stamped).  With several
+ * streams in flight the event bracket also contains the time the launch waits for the GPU behind other streams'
+ * kernels; the stamps are the kernel's own execution window (what a kernel trace reports).  end() synchronises on the
+ * events and returns the number of launches timed and their summed event duration. */
+void sininn_profile_begin(int level_height, unsigned long long* stamps, int max_launches);
 int sininn_profile_end(int* count, float* total_ms);
+int sininn_wall_clock_khz(void);   /* tick rate of the stamps */
 
 size_t sininn_glow_saved_floats(int B, int H, int W, int C);
 size_t sininn_glow_scratch_bytes(int B, int H, int W, int C, int ksize);

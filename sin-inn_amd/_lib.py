@@ -32,6 +32,7 @@ class ConvArgs(C.Structure):
         ('Co', C.c_int), ('clamp', C.c_float), ('col_tile', C.c_int),
         ('mask', c_f), ('mask_stride', C.c_int),
         ('addend', c_f), ('addend_stride', C.c_int), ('addend_map', c_i),
+        ('stamp', C.c_void_p),
     ]
 
 
@@ -76,7 +77,8 @@ _SIGS = {
                                c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]),
     'sininn_coupling_bwd': (C.c_int, [c_f, C.c_int, c_i, c_f, C.c_int, c_i, c_f, c_f, C.c_int, C.c_int, C.c_int,
                                       C.c_float, C.c_int, c_f, c_f, C.c_int, C.c_void_p]),
-    'sininn_profile_begin': (None, [C.c_int]),
+    'sininn_profile_begin': (None, [C.c_int, C.c_void_p, C.c_int]),
+    'sininn_wall_clock_khz': (C.c_int, []),
     'sininn_profile_end': (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     'sininn_glow_saved_floats': (C.c_size_t, [C.c_int] * 4),
     'sininn_glow_scratch_bytes': (C.c_size_t, [C.c_int] * 5),

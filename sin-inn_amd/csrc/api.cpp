@@ -60,7 +60,7 @@ int lrelu_bwd_launch(float* g, int g_stride, const float* f, int f_stride, int64
 int irn_coupling_bwd_launch(const float* dy, int dy_stride, const float* vy, int vy_stride, const float* hval, int64_t M,
                             int Co, float clamp, int inverse, float* dG, float* dh, float* dv, int dv_stride,
                             hipStream_t st);
-void profile_begin(int h);
+void profile_begin(int h, unsigned long long* stamps, int max_launches);
 int profile_end(int* count, float* total_ms);
 int pack_work_items(const sininn_pack_desc* d);
 int pack_batch_launch(const sininn_pack_desc* descs, int n, int total, hipStream_t st);
@@ -125,7 +125,14 @@ int sininn_coupling_bwd(const float* dy, int dy_stride, const int* dy_map, const
                              dv_stride, ST(stream));
 }
 
-void sininn_profile_begin(int level_height) { profile_begin(level_height); }
+void sininn_profile_begin(int level_height, unsigned long long* stamps, int max_launches) {
+  profile_begin(level_height, stamps, max_launches);
+}
+int sininn_wall_clock_khz(void) {
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return 0;
+  return khz;
+}
 int sininn_profile_end(int* count, float* total_ms) { return profile_end(count, total_ms); }
 size_t sininn_glow_saved_floats(int B, int H, int W, int C) { return glow_saved_floats(B, H, W, C); }
 size_t sininn_glow_scratch_bytes(int B, int H, int W, int C, int ksize) { return glow_scratch_bytes(B, H, W, C, ksize); }

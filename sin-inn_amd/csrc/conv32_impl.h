@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256, 2) void conv32_kernel(ConvDev p) {
   float* const w_lds1 = w_lds0 + BN * S;
 
   const int tid = threadIdx.x;
+  stamp_begin(p);
   const int wave = tid >> 6, lane = tid & 63;
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, kh = lane >> 5;
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(256, 2) void conv32_kernel(ConvDev p) {
     __syncthreads();
     __shared__ float red[4];
     conv_epilogue_tile<TH, BN, 16>(p, T, b, y0, x0, n0, tid, red);
+    stamp_end(p);
   }
 }
 
@@ -220,6 +222,7 @@ __global__ __launch_bounds__(256, 2) void conv32_dma_kernel(ConvDev p) {
   float* const w_lds1 = w_lds0 + BN * 32;          // unpadded, swizzled
 
   const int tid = threadIdx.x;
+  stamp_begin(p);
   const int wave = tid >> 6, lane = tid & 63;
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, kh = lane >> 5;
@@ -365,6 +368,7 @@ __global__ __launch_bounds__(256, 2) void conv32_dma_kernel(ConvDev p) {
     __syncthreads();
     __shared__ float red[4];
     conv_epilogue_tile<TH, BN, 16>(p, T, b, y0, x0, n0, tid, red);
+    stamp_end(p);
   }
 }
 

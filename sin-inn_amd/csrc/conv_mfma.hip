@@ -66,6 +66,7 @@ int conv_launch(const sininn_conv_args* a, hipStream_t st) {
   d.addend = a->addend; d.addend_stride = a->addend_stride; d.addend_map = a->addend_map;
   d.mode = a->mode;
   d.col_tile = a->col_tile;
+  d.stamp = a->stamp;
   d.ablate = g_ablate;
   SININN_CHECK(a->mode >= 0 && a->mode <= SININN_CONV_ADD_CBWD_INV, "conv: unknown mode %d", a->mode);
   // channel chunk: the largest of 32/24/16/8 that divides Cin

@@ -33,9 +33,18 @@ struct ConvDev {
   int tiles_x, tiles_y;
   int mode;
   int col_tile;   // coupling (s|t) interleave width of the packed weights (16 or 32)
+  unsigned long long* stamp;   // optional {start, end} wall-clock words (sininn_conv_args.stamp)
   int ablate;   // diagnostic only (tools/bench_kernels.py --ablate): 1 skip staging, 2 skip loop barrier, 4 skip LDS reads
 };
 
+
+// kernel-side execution window for the live roofline measurement (block-uniform branch, one atomic per block)
+__device__ __forceinline__ void stamp_begin(const ConvDev& p) {
+  if (p.stamp && threadIdx.x == 0) atomicMin(p.stamp, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+__device__ __forceinline__ void stamp_end(const ConvDev& p) {
+  if (p.stamp && threadIdx.x == 0) atomicMax(p.stamp + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
 
 // ------------------------------------------------------------------------------------------------
 // Epilogue, phase 2 (shared by the 16- and 32-wide kernels): the block's accumulator tile has been
@@ -211,6 +220,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvDev p) {
   float* const w_lds1 = w_lds0 + BN * S;
 
   const int tid = threadIdx.x;
+  stamp_begin(p);
   const int wave = tid >> 6, lane = tid & 63;
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 15, kq = lane >> 4;
@@ -365,6 +375,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvDev p) {
     __syncthreads();
     __shared__ float red[4];
     conv_epilogue_tile<TH, BN, 8>(p, T, b, y0, x0, n0, tid, red);
+    stamp_end(p);
   }
 }
 

@@ -50,11 +50,14 @@ static int order_after(hipStream_t waiter, hipStream_t producer) {
 // ---- live timing of the dominant kernel (bench.py): HIP events on the launch stream around every forward 3x3
 // coupling conv (conv2 + affine epilogue) of the level whose image height is g_prof_h ----------------------------
 static int g_prof_h = 0;
+static unsigned long long* g_prof_stamps = nullptr;   // device words, 2 per timed launch (optional)
+static int g_prof_max = 0;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
 
-void profile_begin(int h) {
+void profile_begin(int h, unsigned long long* stamps, int max_launches) {
   std::lock_guard<std::mutex> lock(g_ev_mutex);
+  g_prof_stamps = stamps; g_prof_max = stamps ? max_launches : 0;
   for (auto& p : g_prof_events) g_prof_pool.push_back(p);
   g_prof_events.clear();
   g_prof_h = h;
@@ -62,7 +65,7 @@ void profile_begin(int h) {
 
 int profile_end(int* count, float* total_ms) {
   std::lock_guard<std::mutex> lock(g_ev_mutex);
-  g_prof_h = 0;
+  g_prof_h = 0; g_prof_stamps = nullptr; g_prof_max = 0;
   float tot = 0.f;
   int n = 0;
   for (auto& p : g_prof_events) {
@@ -80,12 +83,14 @@ int profile_end(int* count, float* total_ms) {
   return 0;
 }
 
-static bool prof_pair(hipEvent_t* a, hipEvent_t* b) {
+static bool prof_pair(hipEvent_t* a, hipEvent_t* b, unsigned long long** stamp) {
   std::lock_guard<std::mutex> lock(g_ev_mutex);
   if (g_prof_events.size() >= 8192) return false;
   std::pair<hipEvent_t, hipEvent_t> p;
   if (!g_prof_pool.empty()) { p = g_prof_pool.back(); g_prof_pool.pop_back(); }
   else if (hipEventCreate(&p.first) != hipSuccess || hipEventCreate(&p.second) != hipSuccess) return false;
+  const int slot = (int)g_prof_events.size();
+  *stamp = (slot < g_prof_max) ? g_prof_stamps + 2 * (size_t)slot : nullptr;
   g_prof_events.push_back(p);
   *a = p.first; *b = p.second;
   return true;
@@ -196,7 +201,9 @@ int glow_forward(const sininn_glow_args* a, hipStream_t st) {
     c2.out2 = (i == 0) ? sv.ybuf : nullptr; c2.out2_stride = h.co;
     c2.sbuf = sbuf; c2.logdet = a->logdet; c2.Co = h.co; c2.clamp = a->clamp; c2.col_tile = col_tile_of(h.co);
     hipEvent_t e0, e1;
-    const bool timed = g_prof_h != 0 && a->ksize == 3 && a->H == g_prof_h && prof_pair(&e0, &e1);
+    unsigned long long* stamp = nullptr;
+    const bool timed = g_prof_h != 0 && a->ksize == 3 && a->H == g_prof_h && prof_pair(&e0, &e1, &stamp);
+    c2.stamp = timed ? stamp : nullptr;
     if (timed) (void)hipEventRecord(e0, st);
     if (int rc = conv_launch(&c2, st)) return rc;
     if (timed) (void)hipEventRecord(e1, st);

@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256 * CG, 2 / CG) void wino32_kernel(ConvDev p) {
   float* const u_lds1 = u_lds0 + U_BUF;
 
   const int tid = threadIdx.x;
+  stamp_begin(p);
   const int wv = (tid >> 6) & 3, grp = tid >> 8, lane = tid & 63;
   const int tg = wv >> 1, ph = wv & 1;                  // tile group (32 tiles), position half
   const int li = lane & 31, kq = lane >> 5;
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(256 * CG, 2 / CG) void wino32_kernel(ConvDev p) {
     __syncthreads();
     __shared__ float red[4 * CG];
     conv_epilogue_tile<16, BN, HT, NTHR>(p, T0, b, y0, x0, n0, tid, red, T1);
+    stamp_end(p);
   }
 }
 

@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256 * CG, 2 / CG) void wino_kernel(ConvDev p) {
   float* const u_lds1 = u_lds0 + U_BUF;
 
   const int tid = threadIdx.x;
+  stamp_begin(p);
   const int wave = (tid >> 6) & 3, grp = tid >> 8, lane = tid & 63;   // wave: tile group, grp: column group
   const int li = lane & 15, kq = lane >> 4;
 
@@ -215,6 +216,7 @@ __global__ __launch_bounds__(256 * CG, 2 / CG) void wino_kernel(ConvDev p) {
     __syncthreads();
     __shared__ float red[4 * CG];
     conv_epilogue_tile<16, BN, HT, NTHR>(p, T, b, y0, x0, n0, tid, red);
+    stamp_end(p);
   }
 }
 
