@@ -189,6 +189,8 @@ typedef struct sininn_glow_args {
   float* saved;
   void* scratch; size_t scratch_bytes;
   const float* dout; const float* gld; float* dx;
+  int skip_dx;                           /* backward: the caller does not need dx (first block of a pass): the last data-
+                                            gradient conv is skipped; dx must still be a valid buffer (partly written) */
 } sininn_glow_args;
 
 /* Live timing for bench.py: between begin and end, every forward 3x3 coupling conv (conv2 + affine epilogue) of the

@@ -49,7 +49,7 @@ class GlowArgs(C.Structure):
                 ('x', c_f), ('out', c_f), ('dst_map', c_i), ('logdet', c_f),
                 ('s1', SubnetArgs), ('s2', SubnetArgs),
                 ('saved', c_f), ('scratch', C.c_void_p), ('scratch_bytes', C.c_size_t),
-                ('dout', c_f), ('gld', c_f), ('dx', c_f)]
+                ('dout', c_f), ('gld', c_f), ('dx', c_f), ('skip_dx', C.c_int)]
 
 
 class PackDesc(C.Structure):

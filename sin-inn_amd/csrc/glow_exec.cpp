@@ -234,7 +234,7 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
                       const float* dy, int dy_stride, const int* dy_map, const float* vy, int vy_stride, const int* vy_map,
                       const float* cond, int cond_stride, int cond_cin,
                       const float* addend, int add_stride, const int* add_map, float* dcond, int dcond_stride,
-                      bool do_coupling, const Fuse* fuse) -> int {
+                      bool do_coupling, const Fuse* fuse, bool skip_d1) -> int {
     const sininn_subnet* net = h.net;
     if (do_coupling)
       if (int rc = coupling_bwd_launch(dy, dy_stride, dy_map, vy, vy_stride, vy_map, sbuf, a->gld, B, HW, h.co, a->clamp, inv,
@@ -255,6 +255,7 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
       if (int rc = wgrad_launch(cond, cond_stride, cond_cin, dh, SININN_HIDDEN, SININN_HIDDEN, B, H, W, k, net->gw1, net->gb1,
                                 sc.ws, sc.ws_bytes, wst)) return rc;
     }
+    if (skip_d1) return 0;                           // the gradient w.r.t. this half's condition is not needed
     sininn_conv_args d1 = {};
     d1.in = dh; d1.in_stride = SININN_HIDDEN; d1.Cin = SININN_HIDDEN; d1.w = net->w1_dgrad;
     d1.winograd = (net->winograd & 4) && k == 3;
@@ -286,7 +287,7 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
     fz.s = sv.s_a;
     fz.dr = sc.dr_a;
     if (int rc = half_bwd(hv[1], sv.h_b, sv.s_b, sc.dr_b, sc.dh_b, dy, C, map_b, vy, vy_stride, vy_map,
-                          sv.ybuf, co_a, co_a, addend, C, map_a, sc.dy_first, co_a, true, &fz)) return rc;
+                          sv.ybuf, co_a, co_a, addend, C, map_a, sc.dy_first, co_a, true, &fz, false)) return rc;
   }
   // ---- first half: condition = x[:, cond range]; its data gradient accumulates in place into dx ----
   {
@@ -295,7 +296,7 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
     const int vy_stride = a->rev ? co_a : C;
     if (int rc = half_bwd(hv[0], sv.h_a, sv.s_a, sc.dr_a, sc.dh_a, sc.dy_first, co_a, nullptr, vy, vy_stride, nullptr,
                           a->x + cond_off, C, cond_cin, a->dx + cond_off, C, nullptr, a->dx + cond_off, C, false,
-                          nullptr)) return rc;
+                          nullptr, a->skip_dx != 0)) return rc;
   }
   return 0;
 }

@@ -264,7 +264,8 @@ class _GlowFn(torch.autograd.Function):
         s2, keep2 = _subnet_args(block, block.s2, block.split_len1, dev, True, True)
         a = GlowArgs(B=b, H=h, W=w, C=c, ksize=block.ksize, rev=1 if rev else 0, clamp=block.clamp, x=_pv(x),
                      out=_pv(out), dst_map=_pv(dst), s1=s1, s2=s2, saved=_pv(saved), scratch=_pv(scratch),
-                     scratch_bytes=nbytes, dout=_pv(dout), gld=_pv(gld), dx=_pv(dx))
+                     scratch_bytes=nbytes, dout=_pv(dout), gld=_pv(gld), dx=_pv(dx),
+                     skip_dx=0 if ctx.needs_input_grad[0] else 1)     # first block of a pass: nobody consumes dx
         main = torch.cuda.current_stream()
         side = _side_stream(dev) if USE_SIDE_STREAM[0] else main
         _lib.check(lib.sininn_glow_backward(C.byref(a), C.c_void_p(main.cuda_stream), C.c_void_p(side.cuda_stream)))
@@ -272,7 +273,7 @@ class _GlowFn(torch.autograd.Function):
             for t in (scratch, saved, x) + keep1 + keep2:
                 if t is not None:
                     t.record_stream(side)
-        return (dx, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+        return (dx if ctx.needs_input_grad[0] else None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
 
 
 class GLOWCouplingBlock(nn.Module):
