@@ -1,3 +1,8 @@
+"""Compare two variants in the output of several `tools/bench_kernels.py` runs captured in one log:
+    for L in a.so b.so a.so b.so; do echo "$L"; SININN_LIB=$PWD/sin-inn_amd/$L python tools/bench_kernels.py ...; done > ab.log
+    python tools/ab_compare.py ab.log
+Lines that are not kernel timings are taken as the label of the following block; the best (minimum) time of every
+kernel per label is compared.  Always A/B on ONE box: boxes differ by up to 10 %."""
 import re, sys
 blocks={}; cur=None
 for l in open(sys.argv[1]):
