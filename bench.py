@@ -232,6 +232,11 @@ def main():
                                  'note': 'three streams in flight: the window contains other kernels\' blocks'},
                 'alg_flops_per_launch': flops,
                 'alg_bytes_per_launch': 4.0 * (m0 * 256 + m0 * 3 * co0 + 9 * 256 * 2 * co0)}
+        # the same launch against the HBM roof (north_star quotes an HBM fraction): algorithmic bytes / time / 8 TB/s
+        abytes = roof['alg_bytes_per_launch']
+        roof['hbm'] = {'achieved': abytes / (kms * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                       'frac': abytes / (kms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                       'note': '168 FLOP/B >> the fp32 ridge (20 FLOP/B): the kernel is MFMA-bound, this fraction is low by nature'}
     out = {'metric': 'training frames/sec at 256x256 bs=16', 'value': value, 'unit': 'frames/s', 'n_gpus': ws,
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',

@@ -132,6 +132,7 @@ def test_training_step_matches_oracle(lam):
     zs = [torch.randn(4, opt.z_dims, 8, 8, generator=g) for _ in range(1 + 2)]
     rands = [torch.rand(4, 3, generator=g) for _ in range(2)]
     zq, rq = list(zs), list(rands)
+    real_latent = lit_wrapper._latent
     lit_wrapper._latent = lambda b, zd, h, w, device, temp=1.0: zq.pop(0).to(device)
     real_rand = torch.rand
     torch.rand = lambda *a, **k: rq.pop(0) if a == (4, 3) else real_rand(*a, **k)
@@ -139,6 +140,7 @@ def test_training_step_matches_oracle(lam):
         model.training_step([{'hr': hr_g, 'lr': lr_g}, {'hr': hr_g, 'lr': lr_g}], 0)
     finally:
         torch.rand = real_rand
+        lit_wrapper._latent = real_latent
     lamd = dict(fwd_rec=opt.lambda_fwd_rec, fwd_mmd=opt.lambda_fwd_mmd, latent_nll=opt.lambda_latent_nll,
                 bwd_rec=opt.lambda_bwd_rec, bwd_mmd=opt.lambda_bwd_mmd)
     tcr = None
@@ -224,3 +226,35 @@ def test_bigger_configs_properties():
         assert relerr(back, x) < RTOL and relerr(ld2, -ld) < 1e-3
         del net, x, y, back
         torch.cuda.empty_cache()
+
+
+def test_training_is_bitwise_reproducible():
+    """Two identical runs (same seed, frames, latents) give bitwise identical weights after 3 steps: the forward / reverse
+    chains run on two streams and all weight gradients on a third, but every `+=` into a gradient buffer is issued on
+    that ONE stream in host order and the split-K slabs are reduced in a fixed order -- a race between the chains would
+    show up here as run-to-run differences."""
+    import lit_wrapper
+    from data import FrameStore
+    from sin_inn_amd.functional import sample_windows
+
+    def run():
+        torch.manual_seed(5)
+        opt = make_opt(num_coupling=2, lr_window=2)
+        model = lit_wrapper.SingleVideoINN(3, 128, 128, opt).cuda()
+        optim = model.attach_optimizer()
+        assert model.overlap_passes and model.inn.concurrent_passes_safe
+        store = FrameStore.synthetic(12, 128, 128).to('cuda')
+        g = torch.Generator().manual_seed(7)
+        torch.cuda.manual_seed(9)
+        for _ in range(3):
+            idx = torch.randint(2, 10, (8,), generator=g).cuda()
+            hr, lr = sample_windows(store.hr, store.lr, idx, 2)
+            model.training_step([{'hr': hr, 'lr': lr}, {'hr': hr, 'lr': lr}], 0)
+        torch.cuda.synchronize()
+        return optim.flat_params()[0].clone(), float(model._logged['train'])
+
+    p1, l1 = run()
+    p2, l2 = run()
+    assert torch.isfinite(p1).all()
+    assert torch.equal(p1, p2)
+    assert l1 == l2
