@@ -294,6 +294,28 @@ int sininn_bayer_bin(const uint8_t* hr, uint8_t* lr, int T, int H, int W, int sc
 int sininn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                      float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Photometric-loss operators of the flow trainer.  NCHW contiguous fp32.
+ *   softsplat      video-interpolation/my_utils/softsplat.py:8-177: out (ZEROED by the caller) += forward splat of `in`
+ *                  along `flow`; _bwd returns d/d in and / or d/d flow (either may be NULL) for an upstream gout.
+ *   occlusion_wang video-interpolation/my_utils/occlusions.py:29-104: corr (ZEROED, [B][H][W]) = range map of flow21,
+ *                  mask (optional, [B][1][H][W]) = 1 - (corr <= thresh).
+ *   census         video-interpolation/my_utils/loss.py:30-72 (CensusLoss.forward(im1, im2, mask)), 3-channel images,
+ *                  mask [B][1][H][W], max_distance 1..4.  acc (ZEROED, SININN_CENSUS_ACC_FLOATS floats: two sums + 64
+ *                  partial slots) receives {sum of distances, sum(mask)} in its first two words
+ *                  and is the saved state for _bwd; out[0] = the loss.  _bwd: g1 / g2 = gscale[0] * d loss / d im1 / im2
+ *                  (no gradient w.r.t. the mask, which the trainer builds from comparisons).
+ * ---------------------------------------------------------------------------------------------- */
+int sininn_softsplat(const float* in, const float* flow, int B, int C, int H, int W, float* out, void* stream);
+int sininn_softsplat_bwd(const float* in, const float* flow, const float* gout, int B, int C, int H, int W,
+                         float* gin, float* gflow, void* stream);
+int sininn_occlusion_wang(const float* flow21, int B, int H, int W, float thresh, float* corr, float* mask, void* stream);
+#define SININN_CENSUS_ACC_FLOATS 130
+int sininn_census(const float* im1, const float* im2, const float* mask, int B, int H, int W, int max_distance,
+                  float weight, float* acc, float* out, void* stream);
+int sininn_census_bwd(const float* im1, const float* im2, const float* mask, int B, int H, int W, int max_distance,
+                      float weight, const float* acc, const float* gscale, float* g1, float* g2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

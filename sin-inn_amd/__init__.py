@@ -9,6 +9,7 @@ from .framework import InputNode, Node, OutputNode, ReversibleGraphNet      # no
 from .optim import FusedAdam                                                 # noqa: F401
 from . import irn                                                             # noqa: F401
 from . import functional                                                     # noqa: F401
+from . import flowloss                                                       # noqa: F401
 
 __all__ = ['GLOWCouplingBlock', 'IRevNetDownsampling', 'PermuteRandom', 'InputNode', 'Node', 'OutputNode',
            'ReversibleGraphNet', 'FusedAdam', 'functional', 'ops']

@@ -68,6 +68,11 @@ _SIGS = {
     'sininn_pack_winograd': (C.c_int, [c_f, C.c_int, C.c_int, c_i, C.c_int, c_f, C.c_int, c_f, C.c_void_p]),
     'sininn_pack_work_items': (C.c_int, [C.POINTER(PackDesc)]),
     'sininn_pack_batch': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'sininn_softsplat': (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f, C.c_void_p]),
+    'sininn_softsplat_bwd': (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f, c_f, C.c_void_p]),
+    'sininn_occlusion_wang': (C.c_int, [c_f, C.c_int, C.c_int, C.c_int, C.c_float, c_f, c_f, C.c_void_p]),
+    'sininn_census': (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_f, c_f, C.c_void_p]),
+    'sininn_census_bwd': (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_f, c_f, c_f, c_f, C.c_void_p]),
     'sininn_coupling_colmap': (None, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
     'sininn_conv': (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     'sininn_conv_test_hooks': (None, [C.c_int, C.c_int]),

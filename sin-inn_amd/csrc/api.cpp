@@ -62,6 +62,15 @@ int irn_coupling_bwd_launch(const float* dy, int dy_stride, const float* vy, int
                             hipStream_t st);
 void profile_begin(int h, unsigned long long* stamps, int max_launches);
 int profile_end(int* count, float* total_ms);
+int softsplat_fwd_launch(const float* in, const float* flow, int B, int C, int H, int W, float* out, hipStream_t st);
+int softsplat_bwd_launch(const float* in, const float* flow, const float* gout, int B, int C, int H, int W, float* gin,
+                         float* gflow, hipStream_t st);
+int occlusion_wang_launch(const float* flow21, int B, int H, int W, float thresh, float* corr_zeroed, float* mask,
+                          hipStream_t st);
+int census_fwd_launch(const float* im1, const float* im2, const float* mask, int B, int H, int W, int max_distance,
+                      float weight, float* acc_zeroed, float* out, hipStream_t st);
+int census_bwd_launch(const float* im1, const float* im2, const float* mask, int B, int H, int W, int max_distance,
+                      float weight, const float* acc, const float* gscale, float* g1, float* g2, hipStream_t st);
 int pack_work_items(const sininn_pack_desc* d);
 int pack_batch_launch(const sininn_pack_desc* descs, int n, int total, hipStream_t st);
 int pack_winograd_launch(const float* w, int N, int Cin, const int* colmap, int Np, float* u_fwd, int Cdp,
@@ -86,6 +95,24 @@ int sininn_pack_conv_weights(const float* w_oihw, const float* bias, int N, int 
   return pack_launch(w_oihw, bias, N, Cin, ksize, colmap, Np, w_fwd, b_fwd, Cdp, w_dgrad, ST(stream));
 }
 
+int sininn_softsplat(const float* in, const float* flow, int B, int C, int H, int W, float* out, void* stream) {
+  return softsplat_fwd_launch(in, flow, B, C, H, W, out, ST(stream));
+}
+int sininn_softsplat_bwd(const float* in, const float* flow, const float* gout, int B, int C, int H, int W, float* gin,
+                         float* gflow, void* stream) {
+  return softsplat_bwd_launch(in, flow, gout, B, C, H, W, gin, gflow, ST(stream));
+}
+int sininn_occlusion_wang(const float* flow21, int B, int H, int W, float thresh, float* corr, float* mask, void* stream) {
+  return occlusion_wang_launch(flow21, B, H, W, thresh, corr, mask, ST(stream));
+}
+int sininn_census(const float* im1, const float* im2, const float* mask, int B, int H, int W, int max_distance, float weight,
+                  float* acc, float* out, void* stream) {
+  return census_fwd_launch(im1, im2, mask, B, H, W, max_distance, weight, acc, out, ST(stream));
+}
+int sininn_census_bwd(const float* im1, const float* im2, const float* mask, int B, int H, int W, int max_distance,
+                      float weight, const float* acc, const float* gscale, float* g1, float* g2, void* stream) {
+  return census_bwd_launch(im1, im2, mask, B, H, W, max_distance, weight, acc, gscale, g1, g2, ST(stream));
+}
 int sininn_pack_work_items(const sininn_pack_desc* host_desc) { return host_desc ? pack_work_items(host_desc) : 0; }
 int sininn_pack_batch(const sininn_pack_desc* descs, int n, int total_work, void* stream) {
   return pack_batch_launch(descs, n, total_work, ST(stream));

@@ -1,0 +1,353 @@
+// Photometric-loss operators of the flow trainer, NCHW contiguous fp32 like the reference:
+//   * softmax / summation splatting   video-interpolation/my_utils/softsplat.py:8-177   (forward scatter, both gradients)
+//   * occlusion_wang correspondence   video-interpolation/my_utils/occlusions.py:29-104 (range map + threshold)
+//   * CensusLoss                      video-interpolation/my_utils/loss.py:30-72        (ternary census, forward + gradients)
+// All three are HBM / atomic bound: one thread per pixel computes the bilinear taps ONCE and walks the channels
+// (coalesced along x), scatters use the hardware fp32 atomic add (no CAS loop), the census kernel stages the two
+// grey-level tiles (+ halo) in LDS so every image byte is read once.
+#include "common.h"
+
+namespace sininn {
+
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+// ------------------------------------------------------------------------------------------------
+// forward splat: out[b, c, y + fy .., x + fx ..] += in[b, c, y, x] * bilinear weight      (softsplat.py:8-52)
+// ------------------------------------------------------------------------------------------------
+struct SplatTaps {
+  int nwx, nwy;
+  float nw, ne, sw, se;
+  bool vnw, vne, vsw, vse;
+};
+
+__device__ __forceinline__ SplatTaps splat_taps(float ox, float oy, int H, int W) {
+  SplatTaps t;
+  t.nwx = (int)floorf(ox); t.nwy = (int)floorf(oy);
+  const float sex = (float)(t.nwx + 1), sey = (float)(t.nwy + 1), nwx = (float)t.nwx, nwy = (float)t.nwy;
+  t.nw = (sex - ox) * (sey - oy);
+  t.ne = (ox - nwx) * (sey - oy);
+  t.sw = (sex - ox) * (oy - nwy);
+  t.se = (ox - nwx) * (oy - nwy);
+  const bool x0 = t.nwx >= 0 && t.nwx < W, x1 = t.nwx + 1 >= 0 && t.nwx + 1 < W;
+  const bool y0 = t.nwy >= 0 && t.nwy < H, y1 = t.nwy + 1 >= 0 && t.nwy + 1 < H;
+  t.vnw = x0 && y0; t.vne = x1 && y0; t.vsw = x0 && y1; t.vse = x1 && y1;
+  return t;
+}
+
+// Block = 32 x 8 source pixels of one image.  Taps that land inside the block's window (tile + SP_R pixels all round)
+// are accumulated with LDS atomics (ds_add_f32) and the window is flushed once with coalesced global atomics; only taps
+// thrown further than SP_R pixels go to global memory directly.  For the smooth, few-pixel flows of the trainer that cuts
+// the global atomic count ~3.5x and makes what remains row-contiguous.  ONES: splat a constant 1 (occlusion range map).
+constexpr int SP_TX = 32, SP_TY = 8, SP_R = 8, SP_CC = 4;
+constexpr int SP_WX = SP_TX + 2 * SP_R, SP_WY = SP_TY + 2 * SP_R;
+
+template <bool ONES>
+__global__ __launch_bounds__(SP_TX * SP_TY) void splat_fwd_kernel(const float* __restrict__ in, const float* __restrict__ flow,
+                                                                  int B, int C, int H, int W, float* __restrict__ out) {
+  __shared__ float win[SP_CC][SP_WY][SP_WX];
+  const int tiles_x = (W + SP_TX - 1) / SP_TX, tiles_y = (H + SP_TY - 1) / SP_TY;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int x0 = tx * SP_TX, y0 = ty * SP_TY;
+  const int lx = threadIdx.x % SP_TX, ly = threadIdx.x / SP_TX;
+  const int x = x0 + lx, y = y0 + ly;
+  const int64_t HW = (int64_t)H * W;
+  const bool live = x < W && y < H;
+  const int64_t r = live ? (int64_t)y * W + x : 0;
+  SplatTaps t = {};
+  bool any = false;
+  if (live) {
+    const float ox = (float)x + flow[((int64_t)b * 2 + 0) * HW + r], oy = (float)y + flow[((int64_t)b * 2 + 1) * HW + r];
+    if (ox == ox && oy == oy && fabsf(ox) < 1e9f && fabsf(oy) < 1e9f) { t = splat_taps(ox, oy, H, W); any = true; }
+  }
+  // window coordinates of the north-west tap
+  const int wx = t.nwx - (x0 - SP_R), wy = t.nwy - (y0 - SP_R);
+  const bool in_nw = wx >= 0 && wx < SP_WX && wy >= 0 && wy < SP_WY;
+  const bool in_ne = wx + 1 >= 0 && wx + 1 < SP_WX && wy >= 0 && wy < SP_WY;
+  const bool in_sw = wx >= 0 && wx < SP_WX && wy + 1 >= 0 && wy + 1 < SP_WY;
+  const bool in_se = wx + 1 >= 0 && wx + 1 < SP_WX && wy + 1 >= 0 && wy + 1 < SP_WY;
+  const int64_t o_nw = (int64_t)t.nwy * W + t.nwx;
+  for (int c0 = 0; c0 < C; c0 += SP_CC) {
+    const int cc = min(SP_CC, C - c0);
+    for (int e = threadIdx.x; e < cc * SP_WY * SP_WX; e += blockDim.x) (&win[0][0][0])[e] = 0.f;
+    __syncthreads();
+    if (any) {
+      for (int c = 0; c < cc; ++c) {
+        const float v = ONES ? 1.f : in[((int64_t)b * C + c0 + c) * HW + r];
+        float* o = out + ((int64_t)b * C + c0 + c) * HW;
+        if (t.vnw) { if (in_nw) atomic_add_f32(&win[c][wy][wx], v * t.nw); else atomic_add_f32(o + o_nw, v * t.nw); }
+        if (t.vne) { if (in_ne) atomic_add_f32(&win[c][wy][wx + 1], v * t.ne); else atomic_add_f32(o + o_nw + 1, v * t.ne); }
+        if (t.vsw) { if (in_sw) atomic_add_f32(&win[c][wy + 1][wx], v * t.sw); else atomic_add_f32(o + o_nw + W, v * t.sw); }
+        if (t.vse) { if (in_se) atomic_add_f32(&win[c][wy + 1][wx + 1], v * t.se); else atomic_add_f32(o + o_nw + W + 1, v * t.se); }
+      }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < cc * SP_WY * SP_WX; e += blockDim.x) {
+      const float v = (&win[0][0][0])[e];
+      if (v != 0.f) {
+        const int c = e / (SP_WY * SP_WX), q = e % (SP_WY * SP_WX);
+        const int gy = y0 - SP_R + q / SP_WX, gx = x0 - SP_R + q % SP_WX;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) atomic_add_f32(out + ((int64_t)b * C + c0 + c) * HW + (int64_t)gy * W + gx, v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// both gradients in one pass over gradOutput's four taps (softsplat.py:54-177):
+//   gin[b,c,y,x]  = sum_taps gout[b,c,tap] * w_tap
+//   gflow[b,0,y,x] = sum_c in[b,c,y,x] * sum_taps gout[b,c,tap] * dw_tap/dx     (likewise component 1 with d/dy)
+__global__ void softsplat_bwd_kernel(const float* __restrict__ in, const float* __restrict__ flow, const float* __restrict__ gout,
+                                     int B, int C, int H, int W, float* __restrict__ gin, float* __restrict__ gflow) {
+  const int64_t HW = (int64_t)H * W, total = (int64_t)B * HW;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int b = (int)(idx / HW);
+  const int64_t r = idx % HW;
+  const int y = (int)(r / W), x = (int)(r % W);
+  const float ox = (float)x + flow[(b * 2 + 0) * HW + r], oy = (float)y + flow[(b * 2 + 1) * HW + r];
+  const bool nan = !(ox == ox) || !(oy == oy);
+  SplatTaps t = splat_taps(nan ? 0.f : ox, nan ? 0.f : oy, H, W);
+  if (nan) t.vnw = t.vne = t.vsw = t.vse = false;
+  const float fx = ox - (float)t.nwx, fy = oy - (float)t.nwy;   // fractional parts
+  // d/dx of (nw, ne, sw, se) = (-(1-fy), (1-fy), -fy, fy);  d/dy = (-(1-fx), -fx, (1-fx), fx)
+  const int64_t o_nw = (int64_t)t.nwy * W + t.nwx;
+  float gfx = 0.f, gfy = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float* g = gout + ((int64_t)b * C + c) * HW;
+    const float gnw = t.vnw ? g[o_nw] : 0.f, gne = t.vne ? g[o_nw + 1] : 0.f;
+    const float gsw = t.vsw ? g[o_nw + W] : 0.f, gse = t.vse ? g[o_nw + W + 1] : 0.f;
+    if (gin) gin[((int64_t)b * C + c) * HW + r] = gnw * t.nw + gne * t.ne + gsw * t.sw + gse * t.se;
+    if (gflow) {
+      const float v = in[((int64_t)b * C + c) * HW + r];
+      gfx += v * ((gne - gnw) * (1.f - fy) + (gse - gsw) * fy);
+      gfy += v * ((gsw - gnw) * (1.f - fx) + (gse - gne) * fx);
+    }
+  }
+  if (gflow) { gflow[(b * 2 + 0) * HW + r] = gfx; gflow[(b * 2 + 1) * HW + r] = gfy; }
+}
+
+int softsplat_fwd_launch(const float* in, const float* flow, int B, int C, int H, int W, float* out, hipStream_t st) {
+  SININN_CHECK(in && flow && out, "softsplat: null pointer");
+  SININN_CHECK(B > 0 && C > 0 && H > 0 && W > 0, "softsplat: bad shape");
+  const int tiles = B * ((H + SP_TY - 1) / SP_TY) * ((W + SP_TX - 1) / SP_TX);
+  hipLaunchKernelGGL(splat_fwd_kernel<false>, dim3(tiles), dim3(SP_TX * SP_TY), 0, st, in, flow, B, C, H, W, out);
+  SININN_LAUNCH_CHECK("softsplat_fwd");
+  return 0;
+}
+
+int softsplat_bwd_launch(const float* in, const float* flow, const float* gout, int B, int C, int H, int W, float* gin,
+                         float* gflow, hipStream_t st) {
+  SININN_CHECK(in && flow && gout && (gin || gflow), "softsplat_bwd: null pointer");
+  SININN_CHECK(B > 0 && C > 0 && H > 0 && W > 0, "softsplat_bwd: bad shape");
+  const int64_t total = (int64_t)B * H * W;
+  hipLaunchKernelGGL(softsplat_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, flow, gout, B, C, H, W,
+                     gin, gflow);
+  SININN_LAUNCH_CHECK("softsplat_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// occlusion_wang (occlusions.py:29-104): range map of the backward flow, mask = NOT (map <= thresh)
+//   every pixel scatters its four CLAMPED corner weights and a corner that had to be clamped contributes 0 -- i.e. taps
+//   outside the image are dropped and the rest carry the bilinear weights: the summation splat of a constant 1
+// ------------------------------------------------------------------------------------------------
+__global__ void occlusion_mask_kernel(const float* __restrict__ corr, int64_t n, float thresh, float* __restrict__ mask) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) mask[i] = (corr[i] <= thresh) ? 0.f : 1.f;
+}
+
+int occlusion_wang_launch(const float* flow21, int B, int H, int W, float thresh, float* corr_zeroed, float* mask,
+                          hipStream_t st) {
+  SININN_CHECK(flow21 && corr_zeroed, "occlusion_wang: null pointer");
+  SININN_CHECK(B > 0 && H > 0 && W > 0, "occlusion_wang: bad shape");
+  const int64_t total = (int64_t)B * H * W;
+  const int tiles = B * ((H + SP_TY - 1) / SP_TY) * ((W + SP_TX - 1) / SP_TX);
+  hipLaunchKernelGGL(splat_fwd_kernel<true>, dim3(tiles), dim3(SP_TX * SP_TY), 0, st, nullptr, flow21, B, 1, H, W, corr_zeroed);
+  SININN_LAUNCH_CHECK("corr_map");
+  if (mask) {
+    hipLaunchKernelGGL(occlusion_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, corr_zeroed, total, thresh,
+                       mask);
+    SININN_LAUNCH_CHECK("occlusion_mask");
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CensusLoss (loss.py:30-72):  I = 255 * grey(img * mask);  t(p, o) = (I[p+o] - I[p]) / sqrt(0.81 + (.)^2)  (zero padding);
+//   d(p) = mean_o ((t1 - t2)^2 / (0.1 + (t1 - t2)^2));  loss = weight * mean(d * inner) * numel(mask) / sum(mask)
+// forward: acc[0] += sum_p d(p) * inner(p);  acc[1] += sum(mask)           (the host/device epilogue forms the scalar)
+// backward: g1 / g2 = d loss / d (img1, img2), 3 channels each, through the grey weights and the mask
+// ------------------------------------------------------------------------------------------------
+constexpr int CT = 16;                 // pixel tile
+constexpr int CMAXD = 4;               // max_distance <= 4  (reference default 2, trainer 3)
+constexpr int CENSUS_SLOTS = 64;       // acc = {sum d, sum mask, 64 x {partial d, partial mask}} = SININN_CENSUS_ACC_FLOATS
+
+__device__ __forceinline__ float grey255(const float* img, const float* mask, int b, int64_t HW, int64_t r) {
+  const float m = mask[(int64_t)b * HW + r];
+  return 255.f * (img[((int64_t)b * 3 + 0) * HW + r] * m * 0.2989f + img[((int64_t)b * 3 + 1) * HW + r] * m * 0.5870f +
+                  img[((int64_t)b * 3 + 2) * HW + r] * m * 0.1140f);
+}
+
+// LDS tiles of both grey images with a halo of `halo` pixels (zeros outside the image)
+__device__ __forceinline__ void census_stage(const float* im1, const float* im2, const float* mask, int b, int H, int W, int y0,
+                                             int x0, int halo, float* s1, float* s2) {
+  const int TW = CT + 2 * halo;
+  const int64_t HW = (int64_t)H * W;
+  for (int e = threadIdx.x; e < TW * TW; e += blockDim.x) {
+    const int ly = e / TW, lx = e % TW;
+    const int gy = y0 + ly - halo, gx = x0 + lx - halo;
+    float a = 0.f, c = 0.f;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      const int64_t r = (int64_t)gy * W + gx;
+      a = grey255(im1, mask, b, HW, r);
+      c = grey255(im2, mask, b, HW, r);
+    }
+    s1[e] = a; s2[e] = c;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(CT * CT) void census_fwd_kernel(const float* __restrict__ im1, const float* __restrict__ im2,
+                                                             const float* __restrict__ mask, int B, int H, int W, int md,
+                                                             float* __restrict__ acc) {
+  extern __shared__ float sm[];
+  const int TW = CT + 2 * md;
+  float* s1 = sm; float* s2 = sm + TW * TW;
+  const int tiles_x = (W + CT - 1) / CT, tiles_y = (H + CT - 1) / CT;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int y0 = ty * CT, x0 = tx * CT;
+  census_stage(im1, im2, mask, b, H, W, y0, x0, md, s1, s2);
+  const int ly = threadIdx.x / CT, lx = threadIdx.x % CT;
+  const int gy = y0 + ly, gx = x0 + lx;
+  float d = 0.f, msum = 0.f;
+  if (gy < H && gx < W) {
+    msum = mask[(int64_t)b * H * W + (int64_t)gy * W + gx];
+    const bool inner = gy >= md && gy < H - md && gx >= md && gx < W - md;
+    if (inner) {
+      const float c1 = s1[(ly + md) * TW + lx + md], c2 = s2[(ly + md) * TW + lx + md];
+      float sum = 0.f;
+      for (int oy = 0; oy <= 2 * md; ++oy)
+        for (int ox = 0; ox <= 2 * md; ++ox) {
+          const float a = s1[(ly + oy) * TW + lx + ox] - c1, c = s2[(ly + oy) * TW + lx + ox] - c2;
+          const float t1 = a * rsqrtf(0.81f + a * a), t2 = c * rsqrtf(0.81f + c * c);
+          const float q = (t1 - t2) * (t1 - t2);
+          sum += q * __frcp_rn(0.1f + q);
+        }
+      const int P = 2 * md + 1;
+      d = sum / (float)(P * P);
+    }
+  }
+  d = wave_sum(d); msum = wave_sum(msum);
+  __shared__ float red[2][CT * CT / 64];
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = d; red[1][threadIdx.x >> 6] = msum; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f, m = 0.f;
+    for (int i = 0; i < CT * CT / 64; ++i) { a += red[0][i]; m += red[1][i]; }
+    // 64 slots instead of one address: thousands of same-address atomics serialise in L2 (~80 us at 512x512, bs 4)
+    float* slot = acc + 2 + 2 * (blockIdx.x & (CENSUS_SLOTS - 1));
+    atomic_add_f32(slot + 0, a);
+    atomic_add_f32(slot + 1, m);
+  }
+}
+
+// gradient w.r.t. the grey levels, gathered per pixel q:  dI[q] = sum_o k(q - o, o) - sum_o k(q, o),
+//   k(p, o) = coef * inner(p) * dD/dq(t1 - t2) * dt/da   with a = I[p+o] - I[p]
+// then d img[c] = dI * 255 * grey_c * mask.   coef = gscale * weight / (P^2 * sum(mask))
+__global__ __launch_bounds__(CT * CT) void census_bwd_kernel(const float* __restrict__ im1, const float* __restrict__ im2,
+                                                             const float* __restrict__ mask, int B, int H, int W, int md,
+                                                             const float* __restrict__ acc, const float* __restrict__ gscale,
+                                                             float weight, float* __restrict__ g1, float* __restrict__ g2) {
+  extern __shared__ float sm[];
+  const int halo = md;                   // k(q - o, o) only touches I[q - o] and I[q]
+  const int TW = CT + 2 * halo;
+  float* s1 = sm; float* s2 = sm + TW * TW;
+  const int tiles_x = (W + CT - 1) / CT, tiles_y = (H + CT - 1) / CT;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int y0 = ty * CT, x0 = tx * CT;
+  census_stage(im1, im2, mask, b, H, W, y0, x0, halo, s1, s2);
+  const int ly = threadIdx.x / CT, lx = threadIdx.x % CT;
+  const int gy = y0 + ly, gx = x0 + lx;
+  if (gy >= H || gx >= W) return;
+  const int P = 2 * md + 1;
+  const float coef = (gscale ? gscale[0] : 1.f) * weight / ((float)(P * P) * acc[1]);
+  auto kterm = [&](int py, int px, int oy, int ox, float& k1, float& k2) {   // tile coords of centre p, offset o
+    const float a = s1[(py + oy) * TW + px + ox] - s1[py * TW + px], c = s2[(py + oy) * TW + px + ox] - s2[py * TW + px];
+    const float ra = rsqrtf(0.81f + a * a), rc = rsqrtf(0.81f + c * c);
+    const float t1 = a * ra, t2 = c * rc, df = t1 - t2, q = df * df;
+    const float rq = __frcp_rn(0.1f + q);
+    const float dq = 0.2f * rq * rq * df;                                    // d (q / (0.1 + q)) / d(t1 - t2)
+    k1 = dq * 0.81f * ra * ra * ra;                                          // dt1/da = 0.81 / (0.81 + a^2)^1.5
+    k2 = -dq * 0.81f * rc * rc * rc;
+  };
+  float d1 = 0.f, d2 = 0.f;
+  const int cy = ly + halo, cx = lx + halo;                                  // this pixel in tile coordinates
+  for (int oy = -md; oy <= md; ++oy)
+    for (int ox = -md; ox <= md; ++ox) {
+      float k1, k2;
+      // as the centre p = q: -k(q, o)
+      if (gy >= md && gy < H - md && gx >= md && gx < W - md) {
+        kterm(cy, cx, oy, ox, k1, k2);
+        d1 -= k1; d2 -= k2;
+      }
+      // as the neighbour of p = q - o: +k(q - o, o)
+      const int py = gy - oy, px = gx - ox;
+      if (py >= md && py < H - md && px >= md && px < W - md) {
+        kterm(cy - oy, cx - ox, oy, ox, k1, k2);
+        d1 += k1; d2 += k2;
+      }
+    }
+  const int64_t HW = (int64_t)H * W, r = (int64_t)gy * W + gx;
+  const float m = mask[(int64_t)b * HW + r] * 255.f * coef;
+  const float gw[3] = {0.2989f, 0.5870f, 0.1140f};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    if (g1) g1[((int64_t)b * 3 + c) * HW + r] = d1 * m * gw[c];
+    if (g2) g2[((int64_t)b * 3 + c) * HW + r] = d2 * m * gw[c];
+  }
+}
+
+__global__ void census_finish_kernel(float* __restrict__ acc, float weight, float* __restrict__ out) {
+  // mean(d * inner) / sum(mask) * numel(mask) * weight  ==  weight * sum(d * inner) / sum(mask)
+  float a = acc[2 + 2 * threadIdx.x], m = acc[3 + 2 * threadIdx.x];
+  a = wave_sum(a); m = wave_sum(m);
+  if (threadIdx.x == 0) { acc[0] = a; acc[1] = m; out[0] = weight * a / m; }
+}
+
+int census_fwd_launch(const float* im1, const float* im2, const float* mask, int B, int H, int W, int max_distance,
+                      float weight, float* acc_zeroed, float* out, hipStream_t st) {
+  SININN_CHECK(im1 && im2 && mask && acc_zeroed && out, "census: null pointer");
+  SININN_CHECK(B > 0 && H > 0 && W > 0 && max_distance >= 1 && max_distance <= CMAXD, "census: bad shape / max_distance in 1..%d", CMAXD);
+  const int tiles = B * ((H + CT - 1) / CT) * ((W + CT - 1) / CT);
+  const int TW = CT + 2 * max_distance;
+  hipLaunchKernelGGL(census_fwd_kernel, dim3(tiles), dim3(CT * CT), 2 * TW * TW * sizeof(float), st, im1, im2, mask, B, H, W,
+                     max_distance, acc_zeroed);
+  SININN_LAUNCH_CHECK("census_fwd");
+  static_assert(CENSUS_SLOTS == 64, "one wave sums the slots");
+  hipLaunchKernelGGL(census_finish_kernel, dim3(1), dim3(CENSUS_SLOTS), 0, st, acc_zeroed, weight, out);
+  SININN_LAUNCH_CHECK("census_finish");
+  return 0;
+}
+
+int census_bwd_launch(const float* im1, const float* im2, const float* mask, int B, int H, int W, int max_distance,
+                      float weight, const float* acc, const float* gscale, float* g1, float* g2, hipStream_t st) {
+  SININN_CHECK(im1 && im2 && mask && acc && (g1 || g2), "census_bwd: null pointer");
+  SININN_CHECK(B > 0 && H > 0 && W > 0 && max_distance >= 1 && max_distance <= CMAXD, "census_bwd: bad shape / max_distance in 1..%d", CMAXD);
+  const int tiles = B * ((H + CT - 1) / CT) * ((W + CT - 1) / CT);
+  const int TW = CT + 2 * max_distance;
+  hipLaunchKernelGGL(census_bwd_kernel, dim3(tiles), dim3(CT * CT), 2 * TW * TW * sizeof(float), st, im1, im2, mask, B, H, W,
+                     max_distance, acc, gscale, weight, g1, g2);
+  SININN_LAUNCH_CHECK("census_bwd");
+  return 0;
+}
+
+}  // namespace sininn

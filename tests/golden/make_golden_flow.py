@@ -1,0 +1,47 @@
+"""Generate golden_flow.npz FROM THE REFERENCE'S OWN CODE (flow trainer utilities).
+
+Run once in the build container (needs /root/reference; never runs on the GPU box):
+    python tests/golden/make_golden_flow.py
+Imports video-interpolation/my_utils/occlusions.py and my_utils/loss.py unmodified (pure torch; occlusions.py's
+`Resample2d` import resolves because resample2d.py only references its absent CUDA extension at call time, and it is
+not called here).  softsplat.py needs cupy and is NOT imported (its oracle is pinned by properties instead).
+Outputs are data only: inputs and expected outputs.
+"""
+import os, sys
+import numpy as np
+import torch
+
+REF = '/root/reference/video-interpolation'
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    sys.path.insert(0, REF)
+    import my_utils.occlusions as ref_occ          # noqa: E402
+    import my_utils.loss as ref_loss               # noqa: E402
+    sys.path.pop(0)
+    g = torch.Generator().manual_seed(21)
+    out = {}
+    # F1 occlusion_wang (occlusions.py:96-103) + its range map (occlusions.py:29-77); flows that leave the image too
+    flow12 = torch.randn(2, 2, 14, 19, generator=g) * 2.5
+    flow21 = torch.randn(2, 2, 14, 19, generator=g) * 2.5
+    flow21[0, :, :2] *= 4
+    base = ref_occ.mesh_grid(2, 14, 19).type_as(flow21)
+    out.update(f1_flow12=flow12, f1_flow21=flow21, f1_corr=ref_occ.get_corresponding_map(base + flow21),
+               f1_mask=ref_occ.occlusion_wang(flow12, flow21, 0.7))
+    # F2 CensusLoss (loss.py:30-72) for the reference default (2) and the trainer's (3) max_distance, values + gradients
+    for md in (2, 3):
+        im = torch.rand(2, 3, 20, 23, generator=g).requires_grad_(True)
+        im_w = (im.detach() + 0.08 * torch.randn(2, 3, 20, 23, generator=g)).clamp(0, 1).requires_grad_(True)
+        mask = (torch.rand(2, 1, 20, 23, generator=g) > 0.25).float()
+        loss = ref_loss.CensusLoss(0.1, max_distance=md)(im, im_w, mask)
+        loss.backward()
+        out.update({f'f2_{md}_im': im.detach(), f'f2_{md}_imw': im_w.detach(), f'f2_{md}_mask': mask,
+                    f'f2_{md}_loss': loss.detach(), f'f2_{md}_gim': im.grad, f'f2_{md}_gimw': im_w.grad})
+    np.savez_compressed(os.path.join(HERE, 'golden_flow.npz'),
+                        **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in out.items()})
+    print('wrote golden_flow.npz with', len(out), 'arrays')
+
+
+if __name__ == '__main__':
+    main()

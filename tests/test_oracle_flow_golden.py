@@ -1,0 +1,57 @@
+"""CPU: the flow-loss oracle (oracle/flow_oracle.py) against fixtures produced by the reference's own code
+(tests/golden/golden_flow.npz <- video-interpolation/my_utils/{occlusions,loss}.py), plus the properties that anchor the
+softsplat restatement (the reference's softsplat needs cupy and cannot run in the build container)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import flow_oracle as FO
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope='module')
+def gold():
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(HERE, 'golden', 'golden_flow.npz')).items()}
+
+
+def test_occlusion_wang_matches_reference(gold):
+    b, _, h, w = gold['f1_flow21'].shape
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
+    grid = torch.stack([xs, ys], 0)[None].expand(b, 2, h, w)
+    corr = FO.get_corresponding_map(grid + gold['f1_flow21'])
+    assert torch.allclose(corr, gold['f1_corr'], rtol=1e-6, atol=1e-6)
+    mask = FO.occlusion_wang(gold['f1_flow12'], gold['f1_flow21'], 0.7)
+    assert torch.equal(mask, gold['f1_mask'])
+    assert 0 < mask.mean() < 1                      # the fixture exercises both outcomes
+
+
+@pytest.mark.parametrize('md', [2, 3])
+def test_census_matches_reference(gold, md):
+    im = gold[f'f2_{md}_im'].clone().requires_grad_(True)
+    imw = gold[f'f2_{md}_imw'].clone().requires_grad_(True)
+    loss = FO.census_loss(im, imw, gold[f'f2_{md}_mask'], 0.1, md)
+    loss.backward()
+    assert abs(float(loss) / float(gold[f'f2_{md}_loss']) - 1) < 1e-5
+    for got, want in ((im.grad, gold[f'f2_{md}_gim']), (imw.grad, gold[f'f2_{md}_gimw'])):
+        assert float((got - want).abs().max() / want.abs().max()) < 1e-4
+
+
+def test_softsplat_properties():
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 3, 9, 11, generator=g)
+    # zero flow is the identity; an integer shift moves pixels and drops what leaves the image
+    assert torch.allclose(FO.softsplat_sum(x, torch.zeros(2, 2, 9, 11)), x)
+    shift = torch.zeros(2, 2, 9, 11); shift[:, 0] = 2; shift[:, 1] = -1
+    y = FO.softsplat_sum(x, shift)
+    assert torch.allclose(y[:, :, :-1, 2:], x[:, :, 1:, :-2]) and float(y[:, :, -1].abs().max()) == 0
+    # mass conservation away from the border: the four weights of a tap sum to one
+    flow = torch.randn(2, 2, 9, 11, generator=g) * 0.4
+    inner = torch.zeros(2, 3, 9, 11); inner[:, :, 2:-2, 2:-2] = x[:, :, 2:-2, 2:-2]
+    assert torch.allclose(FO.softsplat_sum(inner, flow).sum((2, 3)), inner.sum((2, 3)), rtol=1e-5, atol=1e-5)
+    # softmax mode: a constant image stays constant wherever anything lands
+    ones = torch.ones(2, 3, 9, 11)
+    sm = FO.function_softsplat(ones, flow, torch.randn(2, 1, 9, 11, generator=g), 'softmax')
+    assert torch.allclose(sm[sm != 0], torch.ones_like(sm[sm != 0]), rtol=1e-5)

@@ -1,0 +1,66 @@
+"""Microbenchmark of the flow-loss operators (csrc/flowloss.hip) at BASELINE config-3 size (512x512) on the GPU box:
+    python tools/bench_flowloss.py [--batch 4] [--size 512] [--reps 20]
+Prints time and achieved GB/s of ALGORITHMIC bytes (every operand read / written once) against the 8 TB/s HBM roof."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sin_inn_amd                                   # noqa: E402,F401
+from sin_inn_amd import flowloss as FL               # noqa: E402
+
+
+def timeit(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=4)
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--reps', type=int, default=20)
+    a = ap.parse_args()
+    b, h, w = a.batch, a.size, a.size
+    dev = torch.device('cuda', 0)
+    px = b * h * w
+    img = torch.rand(b, 3, h, w, device=dev)
+    img2 = (img + 0.05 * torch.randn_like(img)).clamp(0, 1)
+    flow = torch.randn(b, 2, h, w, device=dev) * 2
+    metric = torch.rand(b, 1, h, w, device=dev)
+    mask = (torch.rand(b, 1, h, w, device=dev) > 0.2).float()
+    rows = []
+    x4 = torch.cat([img * metric.exp(), metric.exp()], 1).contiguous()
+    out = torch.zeros_like(x4)
+    lib, ptr, st = FL._lib.lib(), FL.ptr, FL._stream
+    rows.append(('softsplat fwd (4 ch, softmax payload)', timeit(lambda: lib.sininn_softsplat(ptr(x4), ptr(flow), b, 4, h, w, ptr(out), st()), a.reps),
+                 px * 4 * (4 + 2 + 4)))
+    g = torch.randn_like(x4); gi = torch.empty_like(x4); gf = torch.empty_like(flow)
+    rows.append(('softsplat bwd (d in + d flow)', timeit(lambda: lib.sininn_softsplat_bwd(ptr(x4), ptr(flow), ptr(g), b, 4, h, w, ptr(gi), ptr(gf), st()), a.reps),
+                 px * 4 * (4 + 2 + 4 + 4 + 2)))
+    corr = torch.zeros(b, 1, h, w, device=dev); m = torch.empty_like(corr)
+    rows.append(('occlusion_wang (map + mask)', timeit(lambda: lib.sininn_occlusion_wang(ptr(flow), b, h, w, 0.7, ptr(corr), ptr(m), st()), a.reps),
+                 px * 4 * (2 + 1 + 1 + 1)))
+    acc = torch.zeros(130, device=dev); o = torch.empty(1, device=dev)
+    for md in (2, 3):
+        rows.append((f'census fwd (max_distance {md})', timeit(lambda: lib.sininn_census(ptr(img), ptr(img2), ptr(mask), b, h, w, md, 0.1, ptr(acc), ptr(o), st()), a.reps),
+                     px * 4 * (3 + 3 + 1)))
+        g1 = torch.empty_like(img); g2 = torch.empty_like(img)
+        rows.append((f'census bwd (max_distance {md})', timeit(lambda: lib.sininn_census_bwd(ptr(img), ptr(img2), ptr(mask), b, h, w, md, 0.1, ptr(acc), None, ptr(g1), ptr(g2), st()), a.reps),
+                     px * 4 * (3 + 3 + 1 + 3 + 3)))
+    for name, ms, nbytes in rows:
+        print(f'{name:42s} {ms * 1e3:9.1f} us  {nbytes / ms / 1e6:8.1f} GB/s algorithmic = {nbytes / ms / 1e6 / 8000 * 100:5.1f} % of the HBM roof')
+
+
+if __name__ == '__main__':
+    main()
