@@ -285,6 +285,10 @@ int sininn_sample_windows(const uint8_t* hr_clip, const uint8_t* lr_clip, const 
  * with the reference's float64 arithmetic and uint8 truncation.  hr (T,H,W,3) u8 -> lr (T,H/(2s),W/(2s),4) u8.
  * ---------------------------------------------------------------------------------------------- */
 int sininn_bayer_bin(const uint8_t* hr, uint8_t* lr, int T, int H, int W, int scale, int reduce_sum, void* stream);
+/* Demosaiced LR preview (datasets/prepare.py:103-119,158,163-165): the unquantised binned planes re-packed as an RGGB
+ * mosaic and bilinearly demosaiced (colour_demosaicing 0.1.6, scipy 'reflect' boundary), clipped, quantised:
+ * rgb [T][H/scale][W/scale][3] uint8. */
+int sininn_bayer_demosaic(const uint8_t* hr, uint8_t* rgb, int T, int H, int W, int scale, int reduce_sum, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Adam exactly as torch.optim.Adam (lit_wrapper.py:131-138: L2 weight decay, not AdamW):

@@ -75,6 +75,7 @@ int pack_work_items(const sininn_pack_desc* d);
 int pack_batch_launch(const sininn_pack_desc* descs, int n, int total, hipStream_t st);
 int pack_winograd_launch(const float* w, int N, int Cin, const int* colmap, int Np, float* u_fwd, int Cdp,
                          float* u_dgrad, hipStream_t st);
+int bayer_demosaic_launch(const uint8_t* hr, uint8_t* rgb, int T, int H, int W, int scale, int reduce_sum, hipStream_t st);
 int bayer_bin_launch(const uint8_t* hr, uint8_t* lr, int T, int H, int W, int scale, int reduce_sum, hipStream_t st);
 size_t glow_saved_floats(int B, int H, int W, int C);
 size_t glow_scratch_bytes(int B, int H, int W, int C, int ksize);
@@ -238,6 +239,9 @@ int sininn_sample_windows(const uint8_t* hr_clip, const uint8_t* lr_clip, const 
   return sample_windows_launch(hr_clip, lr_clip, idx, n, T, H, W, h, w, win, hr_out, hs, lr_out, ls, ST(stream));
 }
 
+int sininn_bayer_demosaic(const uint8_t* hr, uint8_t* rgb, int T, int H, int W, int scale, int reduce_sum, void* stream) {
+  return bayer_demosaic_launch(hr, rgb, T, H, W, scale, reduce_sum, ST(stream));
+}
 int sininn_bayer_bin(const uint8_t* hr, uint8_t* lr, int T, int H, int W, int scale, int reduce_sum, void* stream) {
   return bayer_bin_launch(hr, lr, T, H, W, scale, reduce_sum, ST(stream));
 }

@@ -842,6 +842,73 @@ int bayer_bin_launch(const uint8_t* hr, uint8_t* lr, int T, int H, int W, int sc
 }
 
 // ------------------------------------------------------------------------------------------------
+// Demosaiced LR preview (datasets/prepare.py:103-119,158,163-165): the UNQUANTISED binned RGGB planes are packed back into
+// a Bayer mosaic and bilinearly demosaiced (colour_demosaicing 0.1.6 `demosaicing_CFA_Bayer_bilinear`, pattern RGGB:
+// R / B = conv(CFA * mask, [[1,2,1],[2,4,2],[1,2,1]]/4), G = conv(CFA * mask, [[0,1,0],[1,4,1],[0,1,0]]/4), scipy's default
+// 'reflect' boundary), then clipped and quantised.  float64 and unfused multiply-adds in scipy's accumulation order, so the
+// bytes match the host pipeline.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double binned_value(const uint8_t* hr, int t, int H, int W, int scale, int reduce_sum, int my, int mx) {
+  const int py = my & 1, px = mx & 1, y = my >> 1, x = mx >> 1;
+  const int k = py * 2 + px;
+  const int ch = (k == 0) ? 0 : ((k == 3) ? 2 : 1);
+  double acc_cols = 0.0;
+  for (int j = 0; j < scale; ++j) {
+    double acc_rows = 0.0;
+    for (int i = 0; i < scale; ++i) {
+      const int yy = 2 * (y * scale + i) + py, xx = 2 * (x * scale + j) + px;
+      acc_rows += (double)hr[(((int64_t)t * H + yy) * W + xx) * 3 + ch] / 255.0;
+    }
+    acc_cols += reduce_sum ? acc_rows : acc_rows / (double)scale;
+  }
+  return reduce_sum ? acc_cols : acc_cols / (double)scale;
+}
+
+__global__ void bayer_demosaic_kernel(const uint8_t* __restrict__ hr, uint8_t* __restrict__ rgb, int T, int H, int W, int scale,
+                                      int reduce_sum) {
+  const int mh = H / scale, mw = W / scale;               // mosaic = 2 * (H / (2 scale))
+  const int64_t total = (int64_t)T * mh * mw;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = idx;
+    const int mx = (int)(r % mw); r /= mw;
+    const int my = (int)(r % mh);
+    const int t = (int)(r / mh);
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        int sy = my + dy, sx = mx + dx;                   // scipy 'reflect': (d c b a | a b c d | d c b a)
+        sy = sy < 0 ? -sy - 1 : (sy >= mh ? 2 * mh - 1 - sy : sy);
+        sx = sx < 0 ? -sx - 1 : (sx >= mw ? 2 * mw - 1 - sx : sx);
+        const double v = binned_value(hr, t, H, W, scale, reduce_sum, sy, sx);
+        const int cell = (sy & 1) * 2 + (sx & 1);         // colour of the SOURCE mosaic pixel: 0 R, 1/2 G, 3 B
+        const int ady = dy < 0 ? -dy : dy, adx = dx < 0 ? -dx : dx;
+        const double w_rb = (ady == 0 ? 2.0 : 1.0) * (adx == 0 ? 2.0 : 1.0) / 4.0;
+        const double w_g = (ady + adx == 0) ? 1.0 : ((ady + adx == 1) ? 0.25 : 0.0);
+        acc[0] = __dadd_rn(acc[0], __dmul_rn(cell == 0 ? v : 0.0, w_rb));
+        acc[1] = __dadd_rn(acc[1], __dmul_rn((cell == 1 || cell == 2) ? v : 0.0, w_g));
+        acc[2] = __dadd_rn(acc[2], __dmul_rn(cell == 3 ? v : 0.0, w_rb));
+      }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double v = acc[c];
+      v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+      rgb[idx * 3 + c] = (uint8_t)(v * 255.0);
+    }
+  }
+}
+
+int bayer_demosaic_launch(const uint8_t* hr, uint8_t* rgb, int T, int H, int W, int scale, int reduce_sum, hipStream_t st) {
+  SININN_CHECK(hr && rgb && T > 0 && H > 0 && W > 0 && scale > 0, "bayer_demosaic: bad arguments");
+  SININN_CHECK(H % (2 * scale) == 0 && W % (2 * scale) == 0, "bayer_demosaic: H and W must be multiples of 2*scale (prepare.py:152)");
+  const int64_t total = (int64_t)T * (H / scale) * (W / scale);
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(bayer_demosaic_kernel, dim3(blocks), dim3(256), 0, st, hr, rgb, T, H, W, scale, reduce_sum);
+  SININN_LAUNCH_CHECK("bayer_demosaic");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Winograd F(2x2,3x3) filter transform U = G g G^T (G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]), packed like the
 // direct weights with the tap axis replaced by the 16 transform positions:
 //   u_fwd  [16][Np ][Cin]  g[a][b] = w[colmap[q]][c][a][b]

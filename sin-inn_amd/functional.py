@@ -172,3 +172,17 @@ def bayer_bin(hr_clip, scale=4, reduction='mean'):
     _lib.check(_lib.lib().sininn_bayer_bin(hr_clip.data_ptr(), lr.data_ptr(), t, h, w, scale,
                                            1 if reduction == 'sum' else 0, ops._stream()))
     return lr
+
+
+def bayer_demosaic(hr_clip, scale=4, reduction='mean'):
+    """datasets/prepare.py's demosaiced LR preview (pack_demosaic of the unquantised binned planes, :103-119,158,163-165):
+    hr (T,H,W,3) u8 -> rgb (T, H/scale, W/scale, 3) u8."""
+    from . import _lib
+    assert hr_clip.dtype == torch.uint8 and hr_clip.dim() == 4 and hr_clip.shape[-1] == 3 and hr_clip.is_contiguous()
+    if not hr_clip.is_cuda:
+        raise NotImplementedError('sin-inn_amd ops run on the GPU only (got a CPU tensor)')
+    t, h, w, _ = hr_clip.shape
+    rgb = torch.empty((t, h // scale, w // scale, 3), device=hr_clip.device, dtype=torch.uint8)
+    _lib.check(_lib.lib().sininn_bayer_demosaic(hr_clip.data_ptr(), rgb.data_ptr(), t, h, w, scale,
+                                                1 if reduction == 'sum' else 0, ops._stream()))
+    return rgb

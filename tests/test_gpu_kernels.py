@@ -354,3 +354,18 @@ def test_pack_batch_matches_single_packs(env):
                 assert (x - y).abs().max() <= 1e-6 * x.abs().max(), (n, cin, k, i)
             else:
                 assert torch.equal(x, y), (n, cin, k, i)
+
+
+@pytest.mark.parametrize('scale,reduction', [(4, 'mean'), (2, 'mean'), (1, 'mean'), (2, 'sum')])
+def test_bayer_demosaic_preview_is_byte_exact(env, scale, reduction):
+    """datasets/prepare.py's lr_frames_demosaiced preview: binned RGGB planes -> mosaic -> bilinear demosaic -> uint8."""
+    S, O, dev = env
+    from sin_inn_amd.functional import bayer_demosaic
+    g = torch.Generator().manual_seed(13 + scale)
+    hr = torch.randint(0, 256, (2, 32, 48, 3), generator=g, dtype=torch.uint8)
+    if reduction == 'sum':
+        hr = hr // 3                              # some sums exceed 1 and are clipped, most are not
+    got = bayer_demosaic(hr.cuda(), scale, reduction)
+    want = O.bayer_demosaic(hr.numpy(), scale, reduction)
+    assert got.shape == (2, 32 // scale, 48 // scale, 3)
+    assert np.array_equal(got.cpu().numpy(), want)
