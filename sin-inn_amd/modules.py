@@ -140,19 +140,22 @@ class _PackRegistry:
         self.table = None
 
     def refresh(self):
-        live = [e for e in self.entries if e.conv() is not None and e.conv().weight.is_cuda]
+        # strong references for the duration of the call: a weakref can die between two derefs (the cyclic GC may run at
+        # any allocation, e.g. when a previous model goes away)
+        pairs = [(e, e.conv()) for e in self.entries]
+        live = [(e, c) for e, c in pairs if c is not None and c.weight.is_cuda]
         if len(live) != len(self.entries):
-            self.entries, self.table = live, None
+            self.entries, self.table = [e for e, _ in live], None
         if not live:
             return
-        ptrs = tuple(e.conv().weight.data_ptr() for e in live)
+        ptrs = tuple(c.weight.data_ptr() for _, c in live)
         if self.table is None or self.table[0] != ptrs:
-            descs = [ops.pack_desc(e.conv().weight.detach(), e.conv().bias.detach(), e.colmap, e.packs, e.key[5], e.key[6])
-                     for e in live]
-            self.table = (ptrs, ops.pack_batch(descs, live[0].conv().weight.device))
+            descs = [ops.pack_desc(c.weight.detach(), c.bias.detach(), e.colmap, e.packs, e.key[5], e.key[6])
+                     for e, c in live]
+            self.table = (ptrs, ops.pack_batch(descs, live[0][1].weight.device))
         ops.pack_batch_run(self.table[1])
-        for e in live:
-            e.key = _PackCache._key(e.conv(), *e.key[4:])
+        for e, c in live:
+            e.key = _PackCache._key(c, *e.key[4:])
 
 
 _PACK_REGISTRY = _PackRegistry()
