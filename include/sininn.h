@@ -305,7 +305,7 @@ int sininn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, fl
  *   occlusion_wang video-interpolation/my_utils/occlusions.py:29-104: corr (ZEROED, [B][H][W]) = range map of flow21,
  *                  mask (optional, [B][1][H][W]) = 1 - (corr <= thresh).
  *   census         video-interpolation/my_utils/loss.py:30-72 (CensusLoss.forward(im1, im2, mask)), 3-channel images,
- *                  mask [B][1][H][W], max_distance 1..4.  acc (ZEROED, SININN_CENSUS_ACC_FLOATS floats: two sums + 64
+ *                  mask [B][mask_channels][H][W] with 1 (pair_flow.py) or 3 (trainer.py:64) channels, max_distance 1..4.  acc (ZEROED, SININN_CENSUS_ACC_FLOATS floats: two sums + 64
  *                  partial slots) receives {sum of distances, sum(mask)} in its first two words
  *                  and is the saved state for _bwd; out[0] = the loss.  _bwd: g1 / g2 = gscale[0] * d loss / d im1 / im2
  *                  (no gradient w.r.t. the mask, which the trainer builds from comparisons).
@@ -315,10 +315,24 @@ int sininn_softsplat_bwd(const float* in, const float* flow, const float* gout, 
                          float* gin, float* gflow, void* stream);
 int sininn_occlusion_wang(const float* flow21, int B, int H, int W, float thresh, float* corr, float* mask, void* stream);
 #define SININN_CENSUS_ACC_FLOATS 130
-int sininn_census(const float* im1, const float* im2, const float* mask, int B, int H, int W, int max_distance,
-                  float weight, float* acc, float* out, void* stream);
-int sininn_census_bwd(const float* im1, const float* im2, const float* mask, int B, int H, int W, int max_distance,
-                      float weight, const float* acc, const float* gscale, float* g1, float* g2, void* stream);
+int sininn_census(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int H, int W,
+                  int max_distance, float weight, float* acc, float* out, void* stream);
+int sininn_census_bwd(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int H, int W,
+                      int max_distance, float weight, const float* acc, const float* gscale, float* g1, float* g2,
+                      void* stream);
+/* L1Loss (loss.py:17-27): l1_loss(im1*mask, im2*mask) / sum(mask) * numel(mask) * weight; mask channels 1 or C; acc as for
+ * the census loss (ZEROED, SININN_CENSUS_ACC_FLOATS).  _bwd: g1 = -g2 = gscale[0] * d loss / d im1. */
+int sininn_masked_l1(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int C, int H, int W,
+                     float weight, float* acc, float* out, void* stream);
+int sininn_masked_l1_bwd(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int C, int H,
+                         int W, float weight, const float* acc, const float* gscale, float* g1, float* g2, void* stream);
+/* BilateralSmooth (loss.py:106-132): edge-aware smoothness of flow [B][2][H][W] guided by img [B][C][H][W];
+ * order 1 | 2, gauss != 0: squared ('gauss') else absolute ('exp') image differences scaled by edge_constant.
+ * acc (ZEROED, SININN_CENSUS_ACC_FLOATS) is scratch.  _bwd: gflow = gscale[0] * d loss / d flow (img gets none). */
+int sininn_bilateral_smooth(const float* img, const float* flow, int B, int C, int H, int W, int order, int gauss,
+                            float edge_constant, float weight, float* acc, float* out, void* stream);
+int sininn_bilateral_smooth_bwd(const float* img, const float* flow, int B, int C, int H, int W, int order, int gauss,
+                                float edge_constant, float weight, const float* gscale, float* gflow, void* stream);
 
 #ifdef __cplusplus
 }

@@ -98,3 +98,30 @@ def census_loss(im, im_warp, mask, weight, max_distance=2):
     valid = torch.zeros(n, 1, h, w, dtype=im.dtype)
     valid[:, :, max_distance:h - max_distance, max_distance:w - max_distance] = 1
     return (dist * valid).mean() / mask.sum() * mask.numel() * weight
+
+
+def l1_loss(im1, im2, mask, weight):
+    """loss.py:17-27 (L1Loss.forward)."""
+    return torch.nn.functional.l1_loss(im1 * mask, im2 * mask) / mask.sum() * mask.numel() * weight
+
+
+def bilateral_smooth(img, flow, weight, abs_fun, edge_constant, order):
+    """loss.py:106-132 (BilateralSmooth.forward) with my_utils/utils.py:6-13 (image_grads, robust_l1)."""
+    def grads(t, stride=1):
+        return t[:, :, stride:] - t[:, :, :-stride], t[:, :, :, stride:] - t[:, :, :, :-stride]
+
+    def robust(x):
+        return (x ** 2 + 0.001 ** 2) ** 0.5
+
+    f = torch.abs if abs_fun == 'exp' else (lambda x: x ** 2)
+    igx, igy = grads(img, order)
+    fgx, fgy = grads(flow)
+    wx = torch.exp(-f(edge_constant * igx).mean(1)).unsqueeze(1)
+    wy = torch.exp(-f(edge_constant * igy).mean(1)).unsqueeze(1)
+    if order == 1:
+        loss = ((wx * robust(fgx)).mean() + (wy * robust(fgy)).mean()) / 2
+    else:
+        fgxx, _ = grads(fgx)
+        _, fgyy = grads(fgy)
+        loss = ((wx * robust(fgxx)).mean() + (wy * robust(fgyy)).mean()) / 2
+    return loss * weight

@@ -71,8 +71,12 @@ _SIGS = {
     'sininn_softsplat': (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f, C.c_void_p]),
     'sininn_softsplat_bwd': (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f, c_f, C.c_void_p]),
     'sininn_occlusion_wang': (C.c_int, [c_f, C.c_int, C.c_int, C.c_int, C.c_float, c_f, c_f, C.c_void_p]),
-    'sininn_census': (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_f, c_f, C.c_void_p]),
-    'sininn_census_bwd': (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_f, c_f, c_f, c_f, C.c_void_p]),
+    'sininn_census': (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_f, c_f, C.c_void_p]),
+    'sininn_census_bwd': (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_f, c_f, c_f, c_f, C.c_void_p]),
+    'sininn_masked_l1': (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_f, c_f, C.c_void_p]),
+    'sininn_masked_l1_bwd': (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_f, c_f, c_f, c_f, C.c_void_p]),
+    'sininn_bilateral_smooth': (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, c_f, c_f, C.c_void_p]),
+    'sininn_bilateral_smooth_bwd': (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, c_f, c_f, C.c_void_p]),
     'sininn_coupling_colmap': (None, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
     'sininn_conv': (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     'sininn_conv_test_hooks': (None, [C.c_int, C.c_int]),

@@ -67,10 +67,19 @@ int softsplat_bwd_launch(const float* in, const float* flow, const float* gout, 
                          float* gflow, hipStream_t st);
 int occlusion_wang_launch(const float* flow21, int B, int H, int W, float thresh, float* corr_zeroed, float* mask,
                           hipStream_t st);
-int census_fwd_launch(const float* im1, const float* im2, const float* mask, int B, int H, int W, int max_distance,
+int census_fwd_launch(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int H, int W,
+                      int max_distance, float weight, float* acc_zeroed, float* out, hipStream_t st);
+int census_bwd_launch(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int H, int W,
+                      int max_distance, float weight, const float* acc, const float* gscale, float* g1, float* g2,
+                      hipStream_t st);
+int masked_l1_fwd_launch(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int C, int H, int W,
+                         float weight, float* acc_zeroed, float* out, hipStream_t st);
+int masked_l1_bwd_launch(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int C, int H, int W,
+                         float weight, const float* acc, const float* gscale, float* g1, float* g2, hipStream_t st);
+int smooth_fwd_launch(const float* img, const float* flow, int B, int C, int H, int W, int order, int gauss, float k,
                       float weight, float* acc_zeroed, float* out, hipStream_t st);
-int census_bwd_launch(const float* im1, const float* im2, const float* mask, int B, int H, int W, int max_distance,
-                      float weight, const float* acc, const float* gscale, float* g1, float* g2, hipStream_t st);
+int smooth_bwd_launch(const float* img, const float* flow, int B, int C, int H, int W, int order, int gauss, float k,
+                      float weight, const float* gscale, float* gflow, hipStream_t st);
 int pack_work_items(const sininn_pack_desc* d);
 int pack_batch_launch(const sininn_pack_desc* descs, int n, int total, hipStream_t st);
 int pack_winograd_launch(const float* w, int N, int Cin, const int* colmap, int Np, float* u_fwd, int Cdp,
@@ -106,13 +115,30 @@ int sininn_softsplat_bwd(const float* in, const float* flow, const float* gout, 
 int sininn_occlusion_wang(const float* flow21, int B, int H, int W, float thresh, float* corr, float* mask, void* stream) {
   return occlusion_wang_launch(flow21, B, H, W, thresh, corr, mask, ST(stream));
 }
-int sininn_census(const float* im1, const float* im2, const float* mask, int B, int H, int W, int max_distance, float weight,
-                  float* acc, float* out, void* stream) {
-  return census_fwd_launch(im1, im2, mask, B, H, W, max_distance, weight, acc, out, ST(stream));
+int sininn_census(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int H, int W,
+                  int max_distance, float weight, float* acc, float* out, void* stream) {
+  return census_fwd_launch(im1, im2, mask, mask_channels, B, H, W, max_distance, weight, acc, out, ST(stream));
 }
-int sininn_census_bwd(const float* im1, const float* im2, const float* mask, int B, int H, int W, int max_distance,
-                      float weight, const float* acc, const float* gscale, float* g1, float* g2, void* stream) {
-  return census_bwd_launch(im1, im2, mask, B, H, W, max_distance, weight, acc, gscale, g1, g2, ST(stream));
+int sininn_census_bwd(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int H, int W,
+                      int max_distance, float weight, const float* acc, const float* gscale, float* g1, float* g2,
+                      void* stream) {
+  return census_bwd_launch(im1, im2, mask, mask_channels, B, H, W, max_distance, weight, acc, gscale, g1, g2, ST(stream));
+}
+int sininn_masked_l1(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int C, int H, int W,
+                     float weight, float* acc, float* out, void* stream) {
+  return masked_l1_fwd_launch(im1, im2, mask, mask_channels, B, C, H, W, weight, acc, out, ST(stream));
+}
+int sininn_masked_l1_bwd(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int C, int H,
+                         int W, float weight, const float* acc, const float* gscale, float* g1, float* g2, void* stream) {
+  return masked_l1_bwd_launch(im1, im2, mask, mask_channels, B, C, H, W, weight, acc, gscale, g1, g2, ST(stream));
+}
+int sininn_bilateral_smooth(const float* img, const float* flow, int B, int C, int H, int W, int order, int gauss,
+                            float edge_constant, float weight, float* acc, float* out, void* stream) {
+  return smooth_fwd_launch(img, flow, B, C, H, W, order, gauss, edge_constant, weight, acc, out, ST(stream));
+}
+int sininn_bilateral_smooth_bwd(const float* img, const float* flow, int B, int C, int H, int W, int order, int gauss,
+                                float edge_constant, float weight, const float* gscale, float* gflow, void* stream) {
+  return smooth_bwd_launch(img, flow, B, C, H, W, order, gauss, edge_constant, weight, gscale, gflow, ST(stream));
 }
 int sininn_pack_work_items(const sininn_pack_desc* host_desc) { return host_desc ? pack_work_items(host_desc) : 0; }
 int sininn_pack_batch(const sininn_pack_desc* descs, int n, int total_work, void* stream) {

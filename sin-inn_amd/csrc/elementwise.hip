@@ -205,7 +205,8 @@ int sqdiff_sum_launch(const float* x, const int64_t xs[4], const float* y, const
   SININN_CHECK(x && xs && out && B > 0 && C > 0 && H > 0 && W > 0, "sqdiff_sum: bad arguments");
   SININN_CHECK(!y || ys, "sqdiff_sum: y without strides");
   const int64_t total = (int64_t)B * C * H * W;
-  const int blocks = (int)((total + 1023) / 1024 < 2048 ? (total + 1023) / 1024 : 2048);
+  // one same-address atomic per block: keep the block count low (2048 of them serialise for ~25 us in L2)
+  const int blocks = (int)((total + 1023) / 1024 < 512 ? (total + 1023) / 1024 : 512);
   Str4 yss = y ? mk(ys) : Str4{0, 0, 0, 0};
   hipLaunchKernelGGL(sqdiff_sum_kernel, dim3(blocks), dim3(256), 0, st, x, mk(xs), y, yss, B, C, H, W,
                      xs[3] == 1 ? 1 : 0, out);

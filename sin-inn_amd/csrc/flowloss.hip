@@ -185,14 +185,18 @@ constexpr int CT = 16;                 // pixel tile
 constexpr int CMAXD = 4;               // max_distance <= 4  (reference default 2, trainer 3)
 constexpr int CENSUS_SLOTS = 64;       // acc = {sum d, sum mask, 64 x {partial d, partial mask}} = SININN_CENSUS_ACC_FLOATS
 
-__device__ __forceinline__ float grey255(const float* img, const float* mask, int b, int64_t HW, int64_t r) {
-  const float m = mask[(int64_t)b * HW + r];
-  return 255.f * (img[((int64_t)b * 3 + 0) * HW + r] * m * 0.2989f + img[((int64_t)b * 3 + 1) * HW + r] * m * 0.5870f +
-                  img[((int64_t)b * 3 + 2) * HW + r] * m * 0.1140f);
+// MC = mask channels: 1 (pair_flow.py: occlusion mask) or 3 (trainer.py:64: occlusion mask * (softmax != 0))
+__device__ __forceinline__ float mask_at(const float* mask, int MC, int b, int c, int64_t HW, int64_t r) {
+  return mask[((int64_t)b * MC + (MC == 1 ? 0 : c)) * HW + r];
+}
+__device__ __forceinline__ float grey255(const float* img, const float* mask, int MC, int b, int64_t HW, int64_t r) {
+  return 255.f * (img[((int64_t)b * 3 + 0) * HW + r] * mask_at(mask, MC, b, 0, HW, r) * 0.2989f +
+                  img[((int64_t)b * 3 + 1) * HW + r] * mask_at(mask, MC, b, 1, HW, r) * 0.5870f +
+                  img[((int64_t)b * 3 + 2) * HW + r] * mask_at(mask, MC, b, 2, HW, r) * 0.1140f);
 }
 
 // LDS tiles of both grey images with a halo of `halo` pixels (zeros outside the image)
-__device__ __forceinline__ void census_stage(const float* im1, const float* im2, const float* mask, int b, int H, int W, int y0,
+__device__ __forceinline__ void census_stage(const float* im1, const float* im2, const float* mask, int MC, int b, int H, int W, int y0,
                                              int x0, int halo, float* s1, float* s2) {
   const int TW = CT + 2 * halo;
   const int64_t HW = (int64_t)H * W;
@@ -202,8 +206,8 @@ __device__ __forceinline__ void census_stage(const float* im1, const float* im2,
     float a = 0.f, c = 0.f;
     if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
       const int64_t r = (int64_t)gy * W + gx;
-      a = grey255(im1, mask, b, HW, r);
-      c = grey255(im2, mask, b, HW, r);
+      a = grey255(im1, mask, MC, b, HW, r);
+      c = grey255(im2, mask, MC, b, HW, r);
     }
     s1[e] = a; s2[e] = c;
   }
@@ -211,8 +215,8 @@ __device__ __forceinline__ void census_stage(const float* im1, const float* im2,
 }
 
 __global__ __launch_bounds__(CT * CT) void census_fwd_kernel(const float* __restrict__ im1, const float* __restrict__ im2,
-                                                             const float* __restrict__ mask, int B, int H, int W, int md,
-                                                             float* __restrict__ acc) {
+                                                             const float* __restrict__ mask, int MC, int B, int H, int W,
+                                                             int md, float* __restrict__ acc) {
   extern __shared__ float sm[];
   const int TW = CT + 2 * md;
   float* s1 = sm; float* s2 = sm + TW * TW;
@@ -222,12 +226,12 @@ __global__ __launch_bounds__(CT * CT) void census_fwd_kernel(const float* __rest
   const int ty = bid % tiles_y;
   const int b = bid / tiles_y;
   const int y0 = ty * CT, x0 = tx * CT;
-  census_stage(im1, im2, mask, b, H, W, y0, x0, md, s1, s2);
+  census_stage(im1, im2, mask, MC, b, H, W, y0, x0, md, s1, s2);
   const int ly = threadIdx.x / CT, lx = threadIdx.x % CT;
   const int gy = y0 + ly, gx = x0 + lx;
   float d = 0.f, msum = 0.f;
   if (gy < H && gx < W) {
-    msum = mask[(int64_t)b * H * W + (int64_t)gy * W + gx];
+    for (int c = 0; c < MC; ++c) msum += mask[((int64_t)b * MC + c) * H * W + (int64_t)gy * W + gx];
     const bool inner = gy >= md && gy < H - md && gx >= md && gx < W - md;
     if (inner) {
       const float c1 = s1[(ly + md) * TW + lx + md], c2 = s2[(ly + md) * TW + lx + md];
@@ -261,8 +265,8 @@ __global__ __launch_bounds__(CT * CT) void census_fwd_kernel(const float* __rest
 //   k(p, o) = coef * inner(p) * dD/dq(t1 - t2) * dt/da   with a = I[p+o] - I[p]
 // then d img[c] = dI * 255 * grey_c * mask.   coef = gscale * weight / (P^2 * sum(mask))
 __global__ __launch_bounds__(CT * CT) void census_bwd_kernel(const float* __restrict__ im1, const float* __restrict__ im2,
-                                                             const float* __restrict__ mask, int B, int H, int W, int md,
-                                                             const float* __restrict__ acc, const float* __restrict__ gscale,
+                                                             const float* __restrict__ mask, int MC, int B, int H, int W,
+                                                             int md, const float* __restrict__ acc, const float* __restrict__ gscale,
                                                              float weight, float* __restrict__ g1, float* __restrict__ g2) {
   extern __shared__ float sm[];
   const int halo = md;                   // k(q - o, o) only touches I[q - o] and I[q]
@@ -274,12 +278,12 @@ __global__ __launch_bounds__(CT * CT) void census_bwd_kernel(const float* __rest
   const int ty = bid % tiles_y;
   const int b = bid / tiles_y;
   const int y0 = ty * CT, x0 = tx * CT;
-  census_stage(im1, im2, mask, b, H, W, y0, x0, halo, s1, s2);
+  census_stage(im1, im2, mask, MC, b, H, W, y0, x0, halo, s1, s2);
   const int ly = threadIdx.x / CT, lx = threadIdx.x % CT;
   const int gy = y0 + ly, gx = x0 + lx;
   if (gy >= H || gx >= W) return;
   const int P = 2 * md + 1;
-  const float coef = (gscale ? gscale[0] : 1.f) * weight / ((float)(P * P) * acc[1]);
+  const float coef = (gscale ? gscale[0] : 1.f) * weight * (float)MC / ((float)(P * P) * acc[1]);
   auto kterm = [&](int py, int px, int oy, int ox, float& k1, float& k2) {   // tile coords of centre p, offset o
     const float a = s1[(py + oy) * TW + px + ox] - s1[py * TW + px], c = s2[(py + oy) * TW + px + ox] - s2[py * TW + px];
     const float ra = rsqrtf(0.81f + a * a), rc = rsqrtf(0.81f + c * c);
@@ -307,46 +311,246 @@ __global__ __launch_bounds__(CT * CT) void census_bwd_kernel(const float* __rest
       }
     }
   const int64_t HW = (int64_t)H * W, r = (int64_t)gy * W + gx;
-  const float m = mask[(int64_t)b * HW + r] * 255.f * coef;
   const float gw[3] = {0.2989f, 0.5870f, 0.1140f};
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
+    const float m = mask_at(mask, MC, b, c, HW, r) * 255.f * coef;
     if (g1) g1[((int64_t)b * 3 + c) * HW + r] = d1 * m * gw[c];
     if (g2) g2[((int64_t)b * 3 + c) * HW + r] = d2 * m * gw[c];
   }
 }
 
+// shared by the census and masked-L1 losses: scale = weight * numel(mask) / numel(mean)
 __global__ void census_finish_kernel(float* __restrict__ acc, float weight, float* __restrict__ out) {
-  // mean(d * inner) / sum(mask) * numel(mask) * weight  ==  weight * sum(d * inner) / sum(mask)
+  // mean(d * inner) / sum(mask) * numel(mask) * weight  ==  (weight * MC) * sum(d * inner) / sum(mask)
   float a = acc[2 + 2 * threadIdx.x], m = acc[3 + 2 * threadIdx.x];
   a = wave_sum(a); m = wave_sum(m);
   if (threadIdx.x == 0) { acc[0] = a; acc[1] = m; out[0] = weight * a / m; }
 }
 
-int census_fwd_launch(const float* im1, const float* im2, const float* mask, int B, int H, int W, int max_distance,
-                      float weight, float* acc_zeroed, float* out, hipStream_t st) {
+int census_fwd_launch(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int H, int W,
+                      int max_distance, float weight, float* acc_zeroed, float* out, hipStream_t st) {
+  const int MC = mask_channels;
+  SININN_CHECK(MC == 1 || MC == 3, "census: mask must have 1 or 3 channels");
   SININN_CHECK(im1 && im2 && mask && acc_zeroed && out, "census: null pointer");
   SININN_CHECK(B > 0 && H > 0 && W > 0 && max_distance >= 1 && max_distance <= CMAXD, "census: bad shape / max_distance in 1..%d", CMAXD);
   const int tiles = B * ((H + CT - 1) / CT) * ((W + CT - 1) / CT);
   const int TW = CT + 2 * max_distance;
-  hipLaunchKernelGGL(census_fwd_kernel, dim3(tiles), dim3(CT * CT), 2 * TW * TW * sizeof(float), st, im1, im2, mask, B, H, W,
-                     max_distance, acc_zeroed);
+  hipLaunchKernelGGL(census_fwd_kernel, dim3(tiles), dim3(CT * CT), 2 * TW * TW * sizeof(float), st, im1, im2, mask, MC, B,
+                     H, W, max_distance, acc_zeroed);
   SININN_LAUNCH_CHECK("census_fwd");
   static_assert(CENSUS_SLOTS == 64, "one wave sums the slots");
-  hipLaunchKernelGGL(census_finish_kernel, dim3(1), dim3(CENSUS_SLOTS), 0, st, acc_zeroed, weight, out);
+  hipLaunchKernelGGL(census_finish_kernel, dim3(1), dim3(CENSUS_SLOTS), 0, st, acc_zeroed, weight * (float)MC, out);
   SININN_LAUNCH_CHECK("census_finish");
   return 0;
 }
 
-int census_bwd_launch(const float* im1, const float* im2, const float* mask, int B, int H, int W, int max_distance,
-                      float weight, const float* acc, const float* gscale, float* g1, float* g2, hipStream_t st) {
+int census_bwd_launch(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int H, int W,
+                      int max_distance, float weight, const float* acc, const float* gscale, float* g1, float* g2,
+                      hipStream_t st) {
+  const int MC = mask_channels;
+  SININN_CHECK(MC == 1 || MC == 3, "census_bwd: mask must have 1 or 3 channels");
   SININN_CHECK(im1 && im2 && mask && acc && (g1 || g2), "census_bwd: null pointer");
   SININN_CHECK(B > 0 && H > 0 && W > 0 && max_distance >= 1 && max_distance <= CMAXD, "census_bwd: bad shape / max_distance in 1..%d", CMAXD);
   const int tiles = B * ((H + CT - 1) / CT) * ((W + CT - 1) / CT);
   const int TW = CT + 2 * max_distance;
-  hipLaunchKernelGGL(census_bwd_kernel, dim3(tiles), dim3(CT * CT), 2 * TW * TW * sizeof(float), st, im1, im2, mask, B, H, W,
-                     max_distance, acc, gscale, weight, g1, g2);
+  hipLaunchKernelGGL(census_bwd_kernel, dim3(tiles), dim3(CT * CT), 2 * TW * TW * sizeof(float), st, im1, im2, mask, MC, B,
+                     H, W, max_distance, acc, gscale, weight, g1, g2);
   SININN_LAUNCH_CHECK("census_bwd");
+  return 0;
+}
+
+// one pair of slot atomics per BLOCK (same-address atomics serialise in L2: per-wave atomics cost ~100 us at 512x512)
+__device__ __forceinline__ void block_slot_add(float a, float b, float* acc) {
+  __shared__ float red[2][16];
+  a = wave_sum(a); b = wave_sum(b);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float x = 0.f, y = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { x += red[0][i]; y += red[1][i]; }
+    float* slot = acc + 2 + 2 * (blockIdx.x & (CENSUS_SLOTS - 1));
+    atomic_add_f32(slot + 0, x);
+    atomic_add_f32(slot + 1, y);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// L1Loss (loss.py:17-27): l1_loss(im1 * mask, im2 * mask) / sum(mask) * numel(mask) * weight; mask has 1 or C channels
+//   acc slots as in the census loss: {sum |im1*m - im2*m|, sum(mask)}
+// ------------------------------------------------------------------------------------------------
+__global__ void masked_l1_fwd_kernel(const float* __restrict__ a, const float* __restrict__ bb, const float* __restrict__ mask,
+                                     int MC, int B, int C, int H, int W, float* __restrict__ acc) {
+  const int64_t HW = (int64_t)H * W, total = (int64_t)B * HW;
+  float s = 0.f, ms = 0.f;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(idx / HW);
+    const int64_t r = idx % HW;
+    for (int c = 0; c < C; ++c) {
+      const float m = mask[((int64_t)b * MC + (MC == 1 ? 0 : c)) * HW + r];
+      s += fabsf(a[((int64_t)b * C + c) * HW + r] * m - bb[((int64_t)b * C + c) * HW + r] * m);
+      if (MC != 1 || c == 0) ms += m;
+    }
+  }
+  block_slot_add(s, ms, acc);
+}
+
+__global__ void masked_l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ bb, const float* __restrict__ mask,
+                                     int MC, int B, int C, int H, int W, const float* __restrict__ acc,
+                                     const float* __restrict__ gscale, float scale, float* __restrict__ g1,
+                                     float* __restrict__ g2) {
+  const int64_t HW = (int64_t)H * W, total = (int64_t)B * C * HW;
+  const float coef = (gscale ? gscale[0] : 1.f) * scale / acc[1];
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx % HW;
+    const int c = (int)((idx / HW) % C), b = (int)(idx / (HW * C));
+    const float m = mask[((int64_t)b * MC + (MC == 1 ? 0 : c)) * HW + r];
+    const float d = a[idx] * m - bb[idx] * m;
+    const float g = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * m * coef;
+    if (g1) g1[idx] = g;
+    if (g2) g2[idx] = -g;
+  }
+}
+
+int masked_l1_fwd_launch(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int C, int H, int W,
+                         float weight, float* acc_zeroed, float* out, hipStream_t st) {
+  SININN_CHECK(im1 && im2 && mask && acc_zeroed && out, "masked_l1: null pointer");
+  SININN_CHECK(B > 0 && C > 0 && H > 0 && W > 0 && (mask_channels == 1 || mask_channels == C), "masked_l1: bad shape");
+  const int64_t total = (int64_t)B * H * W;
+  const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+  hipLaunchKernelGGL(masked_l1_fwd_kernel, dim3(blocks), dim3(256), 0, st, im1, im2, mask, mask_channels, B, C, H, W, acc_zeroed);
+  SININN_LAUNCH_CHECK("masked_l1");
+  // mean over B*C*H*W, times numel(mask) = B*MC*H*W, over sum(mask):  weight * MC / C * sum / sum(mask)
+  hipLaunchKernelGGL(census_finish_kernel, dim3(1), dim3(CENSUS_SLOTS), 0, st, acc_zeroed,
+                     weight * (float)mask_channels / (float)C, out);
+  SININN_LAUNCH_CHECK("masked_l1_finish");
+  return 0;
+}
+
+int masked_l1_bwd_launch(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int C, int H, int W,
+                         float weight, const float* acc, const float* gscale, float* g1, float* g2, hipStream_t st) {
+  SININN_CHECK(im1 && im2 && mask && acc && (g1 || g2), "masked_l1_bwd: null pointer");
+  SININN_CHECK(B > 0 && C > 0 && H > 0 && W > 0 && (mask_channels == 1 || mask_channels == C), "masked_l1_bwd: bad shape");
+  const int64_t total = (int64_t)B * C * H * W;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(masked_l1_bwd_kernel, dim3(blocks), dim3(256), 0, st, im1, im2, mask, mask_channels, B, C, H, W, acc,
+                     gscale, weight * (float)mask_channels / (float)C, g1, g2);
+  SININN_LAUNCH_CHECK("masked_l1_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BilateralSmooth (loss.py:106-132): edge-aware 1st / 2nd order smoothness of a flow field
+//   order s: img differences with stride s weight the s-th finite difference of the flow (NOTE image_grads returns
+//   (d/dH, d/dW), which the reference names (gx, gy));  w = exp(-mean_c f(k * dimg)), f = |.| ('exp') or (.)^2 ('gauss');
+//   loss = weight * (mean(w_h * robust(dflow_h)) + mean(w_w * robust(dflow_w))) / 2,  robust(u) = sqrt(u^2 + 1e-6)
+// acc: {sum_h, sum_w} partial slots like the other losses (SININN_CENSUS_ACC_FLOATS floats)
+// ------------------------------------------------------------------------------------------------
+struct SmoothDev { const float* img; const float* flow; int B, C, H, W, order, gauss; float k; };
+
+// term along direction dir (0: H, 1: W) anchored at (y, x): weight w and the flow difference u of component kf
+__device__ __forceinline__ bool smooth_anchor_ok(const SmoothDev& p, int dir, int y, int x) {
+  return y >= 0 && x >= 0 && (dir == 0 ? (y < p.H - p.order && x < p.W) : (y < p.H && x < p.W - p.order));
+}
+__device__ __forceinline__ float smooth_w(const SmoothDev& p, int b, int dir, int y, int x) {
+  const int64_t HW = (int64_t)p.H * p.W;
+  const int64_t r0 = (int64_t)y * p.W + x, r1 = r0 + (dir == 0 ? (int64_t)p.order * p.W : p.order);
+  float m = 0.f;
+  for (int c = 0; c < p.C; ++c) {
+    const float g = p.k * (p.img[((int64_t)b * p.C + c) * HW + r1] - p.img[((int64_t)b * p.C + c) * HW + r0]);
+    m += p.gauss ? g * g : fabsf(g);
+  }
+  return expf(-m / (float)p.C);
+}
+__device__ __forceinline__ float smooth_u(const SmoothDev& p, int b, int kf, int dir, int y, int x) {
+  const int64_t HW = (int64_t)p.H * p.W;
+  const float* f = p.flow + ((int64_t)b * 2 + kf) * HW;
+  const int64_t r0 = (int64_t)y * p.W + x, st = dir == 0 ? p.W : 1;
+  return p.order == 1 ? f[r0 + st] - f[r0] : (f[r0 + 2 * st] - f[r0 + st]) - (f[r0 + st] - f[r0]);
+}
+
+__global__ void smooth_fwd_kernel(SmoothDev p, float* __restrict__ acc) {
+  const int64_t HW = (int64_t)p.H * p.W, total = (int64_t)p.B * HW;
+  float sh = 0.f, sw = 0.f;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(idx / HW);
+    const int y = (int)((idx % HW) / p.W), x = (int)(idx % p.W);
+    for (int dir = 0; dir < 2; ++dir)
+      if (smooth_anchor_ok(p, dir, y, x)) {
+        const float w = smooth_w(p, b, dir, y, x);
+        float t = 0.f;
+        for (int kf = 0; kf < 2; ++kf) { const float u = smooth_u(p, b, kf, dir, y, x); t += sqrtf(u * u + 1e-6f); }
+        (dir == 0 ? sh : sw) += w * t;
+      }
+  }
+  block_slot_add(sh, sw, acc);
+}
+
+__global__ void smooth_finish_kernel(float* __restrict__ acc, float ch, float cw, float* __restrict__ out) {
+  float a = acc[2 + 2 * threadIdx.x], m = acc[3 + 2 * threadIdx.x];
+  a = wave_sum(a); m = wave_sum(m);
+  if (threadIdx.x == 0) { acc[0] = a; acc[1] = m; out[0] = a * ch + m * cw; }
+}
+
+// d loss / d flow, gathered per pixel: every anchor whose stencil touches (y, x) contributes coef * w * robust'(u) * tap
+__global__ void smooth_bwd_kernel(SmoothDev p, const float* __restrict__ gscale, float ch, float cw, float* __restrict__ gflow) {
+  const int64_t HW = (int64_t)p.H * p.W, total = (int64_t)p.B * HW;
+  const float gs = gscale ? gscale[0] : 1.f;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(idx / HW);
+    const int y = (int)((idx % HW) / p.W), x = (int)(idx % p.W);
+    float g[2] = {0.f, 0.f};
+    for (int dir = 0; dir < 2; ++dir) {
+      const float coef = gs * (dir == 0 ? ch : cw);
+      for (int j = 0; j <= p.order; ++j) {               // this pixel is stencil point j of the anchor j steps back
+        const int ay = y - (dir == 0 ? j : 0), ax = x - (dir == 1 ? j : 0);
+        if (!smooth_anchor_ok(p, dir, ay, ax)) continue;
+        const float tap = p.order == 1 ? (j == 0 ? -1.f : 1.f) : (j == 1 ? -2.f : 1.f);
+        const float w = smooth_w(p, b, dir, ay, ax);
+        for (int kf = 0; kf < 2; ++kf) {
+          const float u = smooth_u(p, b, kf, dir, ay, ax);
+          g[kf] += coef * w * u * rsqrtf(u * u + 1e-6f) * tap;
+        }
+      }
+    }
+    gflow[((int64_t)b * 2 + 0) * HW + (idx % HW)] = g[0];
+    gflow[((int64_t)b * 2 + 1) * HW + (idx % HW)] = g[1];
+  }
+}
+
+static int smooth_setup(SmoothDev& p, const float* img, const float* flow, int B, int C, int H, int W, int order, int gauss,
+                        float k, float weight, float& ch, float& cw) {
+  SININN_CHECK(img && flow, "smooth: null pointer");
+  SININN_CHECK(B > 0 && C > 0 && (order == 1 || order == 2) && H > order && W > order, "smooth: bad shape / order");
+  p = SmoothDev{img, flow, B, C, H, W, order, gauss, k};
+  ch = 0.5f * weight / ((float)B * 2.f * (float)(H - order) * (float)W);
+  cw = 0.5f * weight / ((float)B * 2.f * (float)H * (float)(W - order));
+  return 0;
+}
+
+int smooth_fwd_launch(const float* img, const float* flow, int B, int C, int H, int W, int order, int gauss, float k,
+                      float weight, float* acc_zeroed, float* out, hipStream_t st) {
+  SmoothDev p; float ch, cw;
+  if (int rc = smooth_setup(p, img, flow, B, C, H, W, order, gauss, k, weight, ch, cw)) return rc;
+  SININN_CHECK(acc_zeroed && out, "smooth: null pointer");
+  const int64_t total = (int64_t)B * H * W;
+  const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+  hipLaunchKernelGGL(smooth_fwd_kernel, dim3(blocks), dim3(256), 0, st, p, acc_zeroed);
+  SININN_LAUNCH_CHECK("smooth_fwd");
+  hipLaunchKernelGGL(smooth_finish_kernel, dim3(1), dim3(CENSUS_SLOTS), 0, st, acc_zeroed, ch, cw, out);
+  SININN_LAUNCH_CHECK("smooth_finish");
+  return 0;
+}
+
+int smooth_bwd_launch(const float* img, const float* flow, int B, int C, int H, int W, int order, int gauss, float k,
+                      float weight, const float* gscale, float* gflow, hipStream_t st) {
+  SmoothDev p; float ch, cw;
+  if (int rc = smooth_setup(p, img, flow, B, C, H, W, order, gauss, k, weight, ch, cw)) return rc;
+  SININN_CHECK(gflow, "smooth_bwd: null pointer");
+  const int64_t total = (int64_t)B * H * W;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(smooth_bwd_kernel, dim3(blocks), dim3(256), 0, st, p, gscale, ch, cw, gflow);
+  SININN_LAUNCH_CHECK("smooth_bwd");
   return 0;
 }
 

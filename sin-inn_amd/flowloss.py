@@ -3,7 +3,7 @@ error behaviour as the reference; all arithmetic runs in libsininn.so (csrc/flow
 
     FunctionSoftsplat / ModuleSoftsplat   video-interpolation/my_utils/softsplat.py:331-371
     occlusion_wang / occlusion_unity      video-interpolation/my_utils/occlusions.py:96-109
-    CensusLoss                            video-interpolation/my_utils/loss.py:30-72
+    L1Loss / CensusLoss / BilateralSmooth video-interpolation/my_utils/loss.py:17-72,106-132
 
 Tensors are NCHW fp32 CUDA tensors (made contiguous like the reference does); CPU tensors raise NotImplementedError
 (softsplat.py:289-290).  The reference's `occlusion_brox` and the Resample2d warp are served by
@@ -15,6 +15,7 @@ from . import _lib
 from .ops import _stream, ptr
 
 check = _lib.check
+ACC_FLOATS = 130        # SININN_CENSUS_ACC_FLOATS: two sums + 64 x 2 partial slots
 
 
 def _prep(t):
@@ -113,11 +114,11 @@ class _CensusFn(torch.autograd.Function):
         im, im_warp, mask = _prep(im), _prep(im_warp), _prep(mask.to(torch.float32))
         b, c, h, w = im.shape
         assert c == 3 and im_warp.shape == im.shape, 'CensusLoss expects two (B,3,H,W) images'
-        assert mask.shape == (b, 1, h, w), 'CensusLoss expects a (B,1,H,W) mask'
-        acc = im.new_zeros(130)             # SININN_CENSUS_ACC_FLOATS: {sum d, sum mask} + 64 partial slots
+        assert mask.shape in ((b, 1, h, w), (b, 3, h, w)), 'CensusLoss expects a (B,1,H,W) or (B,3,H,W) mask'
+        acc = im.new_zeros(ACC_FLOATS)
         out = im.new_empty(1)
-        check(_lib.lib().sininn_census(ptr(im), ptr(im_warp), ptr(mask), b, h, w, int(max_distance), float(weight),
-                                       ptr(acc), ptr(out), _stream()))
+        check(_lib.lib().sininn_census(ptr(im), ptr(im_warp), ptr(mask), mask.shape[1], b, h, w, int(max_distance),
+                                       float(weight), ptr(acc), ptr(out), _stream()))
         ctx.save_for_backward(im, im_warp, mask, acc)
         ctx.weight, ctx.md = float(weight), int(max_distance)
         return out[0]
@@ -130,8 +131,8 @@ class _CensusFn(torch.autograd.Function):
         g2 = torch.empty_like(im_warp) if ctx.needs_input_grad[1] else None
         if g1 is not None or g2 is not None:
             gs = g.reshape(1).to(torch.float32).contiguous()
-            check(_lib.lib().sininn_census_bwd(ptr(im), ptr(im_warp), ptr(mask), b, h, w, ctx.md, ctx.weight, ptr(acc),
-                                               ptr(gs), ptr(g1), ptr(g2), _stream()))
+            check(_lib.lib().sininn_census_bwd(ptr(im), ptr(im_warp), ptr(mask), mask.shape[1], b, h, w, ctx.md, ctx.weight,
+                                               ptr(acc), ptr(gs), ptr(g1), ptr(g2), _stream()))
         return g1, g2, None, None, None
 
 
@@ -144,6 +145,99 @@ class BaseLoss(torch.nn.Module):
 
     def forward(self, *args):
         return 0
+
+
+def _expand_mask(mask, ref):
+    """The trainer passes (B,1,H,W) or (B,3,H,W) float masks, or the scalar placeholder `torch.ones(2)[i]`; a scalar v
+    gives the same loss value as an all-v (B,1,H,W) map (numel / sum cancel the same way)."""
+    if not torch.is_tensor(mask):
+        mask = torch.as_tensor(float(mask), device=ref.device)
+    if mask.numel() == 1:
+        mask = mask.to(ref.device, torch.float32).reshape(1, 1, 1, 1).expand(ref.shape[0], 1, ref.shape[2], ref.shape[3])
+    return mask.to(torch.float32)
+
+
+class _MaskedL1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, im1, im2, mask, weight):
+        im1, im2, mask = _prep(im1), _prep(im2), _prep(mask)
+        b, c, h, w = im1.shape
+        assert im2.shape == im1.shape and mask.shape in ((b, 1, h, w), (b, c, h, w))
+        acc = im1.new_zeros(ACC_FLOATS)
+        out = im1.new_empty(1)
+        check(_lib.lib().sininn_masked_l1(ptr(im1), ptr(im2), ptr(mask), mask.shape[1], b, c, h, w, float(weight), ptr(acc),
+                                          ptr(out), _stream()))
+        ctx.save_for_backward(im1, im2, mask, acc)
+        ctx.weight = float(weight)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        im1, im2, mask, acc = ctx.saved_tensors
+        b, c, h, w = im1.shape
+        g1 = torch.empty_like(im1) if ctx.needs_input_grad[0] else None
+        g2 = torch.empty_like(im2) if ctx.needs_input_grad[1] else None
+        if g1 is not None or g2 is not None:
+            gs = g.reshape(1).to(torch.float32).contiguous()
+            check(_lib.lib().sininn_masked_l1_bwd(ptr(im1), ptr(im2), ptr(mask), mask.shape[1], b, c, h, w, ctx.weight,
+                                                  ptr(acc), ptr(gs), ptr(g1), ptr(g2), _stream()))
+        return g1, g2, None, None
+
+
+class L1Loss(BaseLoss):
+    """loss.py:17-27: occlusion-masked L1, rescaled by numel(mask) / sum(mask); one fused reduction kernel."""
+
+    def __init__(self, weight):
+        super().__init__(weight)
+
+    def forward(self, im1, im2, mask):
+        if self.weight == 0:
+            return super().forward()
+        return _MaskedL1Fn.apply(im1, im2, _expand_mask(mask, im1), self.weight)
+
+
+class _SmoothFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, flow, weight, gauss, edge_constant, order):
+        img, flow = _prep(img), _prep(flow)
+        b, c, h, w = img.shape
+        assert flow.shape == (b, 2, h, w)
+        acc = img.new_zeros(ACC_FLOATS)
+        out = img.new_empty(1)
+        check(_lib.lib().sininn_bilateral_smooth(ptr(img), ptr(flow), b, c, h, w, int(order), int(gauss),
+                                                 float(edge_constant), float(weight), ptr(acc), ptr(out), _stream()))
+        ctx.save_for_backward(img, flow)
+        ctx.cfg = (float(weight), int(gauss), float(edge_constant), int(order))
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        img, flow = ctx.saved_tensors
+        b, c, h, w = img.shape
+        weight, gauss, k, order = ctx.cfg
+        gflow = None
+        if ctx.needs_input_grad[1]:
+            gflow = torch.empty_like(flow)
+            gs = g.reshape(1).to(torch.float32).contiguous()
+            check(_lib.lib().sininn_bilateral_smooth_bwd(ptr(img), ptr(flow), b, c, h, w, order, gauss, k, weight, ptr(gs),
+                                                         ptr(gflow), _stream()))
+        return None, gflow, None, None, None, None
+
+
+class BilateralSmooth(BaseLoss):
+    """loss.py:106-132: edge-aware first / second order smoothness (the guiding image gets no gradient: it is a frame)."""
+
+    def __init__(self, weight, abs_fun, edge_constant, order):
+        super().__init__(weight)
+        assert abs_fun in ('exp', 'gauss') and order in (1, 2)
+        self.gauss = abs_fun == 'gauss'
+        self.edge_constant = edge_constant
+        self.order = order
+
+    def forward(self, img, flow):
+        if self.weight == 0:
+            return super().forward()
+        return _SmoothFn.apply(img, flow, self.weight, self.gauss, self.edge_constant, self.order)
 
 
 class CensusLoss(BaseLoss):
@@ -159,8 +253,4 @@ class CensusLoss(BaseLoss):
     def forward(self, im, im_warp, mask):
         if self.weight == 0:
             return super().forward()
-        if not torch.is_tensor(mask):
-            mask = torch.as_tensor(float(mask), device=im.device)
-        if mask.numel() == 1:      # the trainer's `torch.ones(2)` placeholder: same value as an all-`mask` (B,1,H,W) map
-            mask = mask.to(im.device, torch.float32).reshape(1, 1, 1, 1).expand(im.shape[0], 1, im.shape[2], im.shape[3])
-        return _CensusFn.apply(im, im_warp, mask, self.weight, self.max_distance)
+        return _CensusFn.apply(im, im_warp, _expand_mask(mask, im), self.weight, self.max_distance)

@@ -38,6 +38,28 @@ def main():
         loss.backward()
         out.update({f'f2_{md}_im': im.detach(), f'f2_{md}_imw': im_w.detach(), f'f2_{md}_mask': mask,
                     f'f2_{md}_loss': loss.detach(), f'f2_{md}_gim': im.grad, f'f2_{md}_gimw': im_w.grad})
+    # F3 CensusLoss / L1Loss with the trainer's 3-channel mask (trainer.py:64: occlusion mask * (softmax != 0))
+    im = torch.rand(2, 3, 18, 21, generator=g).requires_grad_(True)
+    im_w = (im.detach() + 0.08 * torch.randn(2, 3, 18, 21, generator=g)).clamp(0, 1).requires_grad_(True)
+    mask3 = (torch.rand(2, 3, 18, 21, generator=g) > 0.25).float()
+    mask1 = (torch.rand(2, 1, 18, 21, generator=g) > 0.25).float()
+    out.update(f3_im=im.detach(), f3_imw=im_w.detach(), f3_mask3=mask3, f3_mask1=mask1)
+    for tag, fn, m in (('census3', ref_loss.CensusLoss(0.1, max_distance=3), mask3), ('l1_3', ref_loss.L1Loss(1), mask3),
+                       ('l1_1', ref_loss.L1Loss(0.7), mask1)):
+        im.grad = im_w.grad = None
+        loss = fn(im, im_w, m)
+        loss.backward()
+        out.update({f'f3_{tag}_loss': loss.detach(), f'f3_{tag}_gim': im.grad.clone(), f'f3_{tag}_gimw': im_w.grad.clone()})
+    # F4 BilateralSmooth (loss.py:106-132): both edge functions and orders; gradient w.r.t. the flow
+    img = torch.rand(2, 3, 17, 22, generator=g)
+    flow = (torch.randn(2, 2, 17, 22, generator=g) * 1.5).requires_grad_(True)
+    out.update(f4_img=img, f4_flow=flow.detach())
+    for fun, k in (('gauss', 150.0), ('exp', 20.0)):
+        for order in (1, 2):
+            flow.grad = None
+            loss = ref_loss.BilateralSmooth(0.1, fun, k, order)(img, flow)
+            loss.backward()
+            out.update({f'f4_{fun}_{order}_loss': loss.detach(), f'f4_{fun}_{order}_gflow': flow.grad.clone()})
     np.savez_compressed(os.path.join(HERE, 'golden_flow.npz'),
                         **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in out.items()})
     print('wrote golden_flow.npz with', len(out), 'arrays')

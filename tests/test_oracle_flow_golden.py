@@ -55,3 +55,28 @@ def test_softsplat_properties():
     ones = torch.ones(2, 3, 9, 11)
     sm = FO.function_softsplat(ones, flow, torch.randn(2, 1, 9, 11, generator=g), 'softmax')
     assert torch.allclose(sm[sm != 0], torch.ones_like(sm[sm != 0]), rtol=1e-5)
+
+
+def test_masked_losses_with_trainer_masks_match_reference(gold):
+    """3-channel masks (trainer.py:64) and 1-channel masks: CensusLoss and L1Loss values + gradients."""
+    for tag, fn, mk in (('census3', lambda a, b, m: FO.census_loss(a, b, m, 0.1, 3), 'f3_mask3'),
+                        ('l1_3', lambda a, b, m: FO.l1_loss(a, b, m, 1), 'f3_mask3'),
+                        ('l1_1', lambda a, b, m: FO.l1_loss(a, b, m, 0.7), 'f3_mask1')):
+        im = gold['f3_im'].clone().requires_grad_(True)
+        imw = gold['f3_imw'].clone().requires_grad_(True)
+        loss = fn(im, imw, gold[mk])
+        loss.backward()
+        assert abs(float(loss) / float(gold[f'f3_{tag}_loss']) - 1) < 1e-5
+        for got, want in ((im.grad, gold[f'f3_{tag}_gim']), (imw.grad, gold[f'f3_{tag}_gimw'])):
+            assert float((got - want).abs().max() / want.abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize('fun,k', [('gauss', 150.0), ('exp', 20.0)])
+@pytest.mark.parametrize('order', [1, 2])
+def test_bilateral_smooth_matches_reference(gold, fun, k, order):
+    flow = gold['f4_flow'].clone().requires_grad_(True)
+    loss = FO.bilateral_smooth(gold['f4_img'], flow, 0.1, fun, k, order)
+    loss.backward()
+    assert abs(float(loss) / float(gold[f'f4_{fun}_{order}_loss']) - 1) < 1e-5
+    want = gold[f'f4_{fun}_{order}_gflow']
+    assert float((flow.grad - want).abs().max() / want.abs().max()) < 1e-4

@@ -53,11 +53,18 @@ def main():
                  px * 4 * (2 + 1 + 1 + 1)))
     acc = torch.zeros(130, device=dev); o = torch.empty(1, device=dev)
     for md in (2, 3):
-        rows.append((f'census fwd (max_distance {md})', timeit(lambda: lib.sininn_census(ptr(img), ptr(img2), ptr(mask), b, h, w, md, 0.1, ptr(acc), ptr(o), st()), a.reps),
+        rows.append((f'census fwd (max_distance {md})', timeit(lambda: lib.sininn_census(ptr(img), ptr(img2), ptr(mask), 1, b, h, w, md, 0.1, ptr(acc), ptr(o), st()), a.reps),
                      px * 4 * (3 + 3 + 1)))
         g1 = torch.empty_like(img); g2 = torch.empty_like(img)
-        rows.append((f'census bwd (max_distance {md})', timeit(lambda: lib.sininn_census_bwd(ptr(img), ptr(img2), ptr(mask), b, h, w, md, 0.1, ptr(acc), None, ptr(g1), ptr(g2), st()), a.reps),
+        rows.append((f'census bwd (max_distance {md})', timeit(lambda: lib.sininn_census_bwd(ptr(img), ptr(img2), ptr(mask), 1, b, h, w, md, 0.1, ptr(acc), None, ptr(g1), ptr(g2), st()), a.reps),
                      px * 4 * (3 + 3 + 1 + 3 + 3)))
+    g1 = torch.empty_like(img); g2 = torch.empty_like(img)
+    rows.append(('masked L1 fwd', timeit(lambda: lib.sininn_masked_l1(ptr(img), ptr(img2), ptr(mask), 1, b, 3, h, w, 1.0, ptr(acc), ptr(o), st()), a.reps), px * 4 * 7))
+    rows.append(('masked L1 bwd', timeit(lambda: lib.sininn_masked_l1_bwd(ptr(img), ptr(img2), ptr(mask), 1, b, 3, h, w, 1.0, ptr(acc), None, ptr(g1), ptr(g2), st()), a.reps), px * 4 * 13))
+    gf = torch.empty_like(flow)
+    for order in (1, 2):
+        rows.append((f'bilateral smooth fwd (order {order})', timeit(lambda: lib.sininn_bilateral_smooth(ptr(img), ptr(flow), b, 3, h, w, order, 1, 150.0, 0.1, ptr(acc), ptr(o), st()), a.reps), px * 4 * 5))
+        rows.append((f'bilateral smooth bwd (order {order})', timeit(lambda: lib.sininn_bilateral_smooth_bwd(ptr(img), ptr(flow), b, 3, h, w, order, 1, 150.0, 0.1, None, ptr(gf), st()), a.reps), px * 4 * 7))
     for name, ms, nbytes in rows:
         print(f'{name:42s} {ms * 1e3:9.1f} us  {nbytes / ms / 1e6:8.1f} GB/s algorithmic = {nbytes / ms / 1e6 / 8000 * 100:5.1f} % of the HBM roof')
 
