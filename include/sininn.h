@@ -239,7 +239,9 @@ int sininn_sqdiff_sum(const float* x, const int64_t xs[4], const float* y, const
 int sininn_sqdiff_bwd(const float* x, const int64_t xs[4], const float* y, const int64_t ys[4],
                       int B, int C, int H, int W, const float* scale, float gscale,
                       float* gx, const int64_t gxs[4], float* gy, const int64_t gys[4], void* stream);
-/* Gram matrices for loss.mmd (loss.py:15-18): g[0]=x x^T, g[1]=y y^T, g[2]=x y^T, each [B][B]; g zeroed by caller. */
+/* Gram matrices for loss.mmd (loss.py:15-18): g[0]=x x^T, g[1]=y y^T, g[2]=x y^T, each [B][B].  g holds
+ * (1 + SININN_MMD_SLOTS) * 3*B*B floats ZEROED by the caller: the result followed by the partial-sum slots. */
+#define SININN_MMD_SLOTS 16
 int sininn_mmd_gram(const float* x, const int64_t xs[4], const float* y, const int64_t ys[4],
                     int B, int C, int H, int W, float* g, void* stream);
 /* loss.py:20-36 on the three Grams -> out[0] (mean) and coef[3][B][B] = dLoss/dGram (for backward). */

@@ -247,6 +247,7 @@ int sqdiff_bwd_launch(const float* x, const int64_t xs[4], const float* y, const
 
 // Gram matrices of loss.mmd: each block stages a chunk of KC logical positions of all B samples
 constexpr int MMD_KC = 128;
+constexpr int MMD_SLOTS = 16;          // == SININN_MMD_SLOTS
 __global__ void mmd_gram_kernel(const float* __restrict__ x, Str4 xs, const float* __restrict__ y, Str4 ys, int B,
                                 int C, int H, int W, int x_fastest, float* __restrict__ g) {
   extern __shared__ float sm[];
@@ -279,11 +280,21 @@ __global__ void mmd_gram_kernel(const float* __restrict__ x, Str4 xs, const floa
         const float yi = yl[i * (MMD_KC + 1) + kk], yj = yl[j * (MMD_KC + 1) + kk];
         sxx += xi * xj; syy += yi * yj; sxy += xi * yj;
       }
-      atomicAdd(g + pr, sxx);
-      atomicAdd(g + npair + pr, syy);
-      atomicAdd(g + 2 * npair + pr, sxy);
+      // 16 slot copies of the three Grams behind the result: 1024 blocks adding to ONE copy serialise in L2
+      float* gs = g + 3 * npair * (1 + (blockIdx.x & (MMD_SLOTS - 1)));
+      atomicAdd(gs + pr, sxx);
+      atomicAdd(gs + npair + pr, syy);
+      atomicAdd(gs + 2 * npair + pr, sxy);
     }
   }
+}
+
+__global__ void mmd_slots_kernel(float* __restrict__ g, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 1; k <= MMD_SLOTS; ++k) s += g[(size_t)k * n + i];      // fixed order
+  g[i] = s;
 }
 
 int mmd_gram_launch(const float* x, const int64_t xs[4], const float* y, const int64_t ys[4], int B, int C, int H,
@@ -296,6 +307,8 @@ int mmd_gram_launch(const float* x, const int64_t xs[4], const float* y, const i
   hipLaunchKernelGGL(mmd_gram_kernel, dim3(blocks), dim3(256), lds, st, x, mk(xs), y, mk(ys), B, C, H, W,
                      xs[3] == 1 ? 1 : 0, g);
   SININN_LAUNCH_CHECK("mmd_gram");
+  hipLaunchKernelGGL(mmd_slots_kernel, dim3((3 * B * B + 255) / 256), dim3(256), 0, st, g, 3 * B * B);
+  SININN_LAUNCH_CHECK("mmd_slots");
   return 0;
 }
 

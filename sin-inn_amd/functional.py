@@ -58,7 +58,7 @@ class _MMD(torch.autograd.Function):
         x4, y4 = x.detach(), y.detach()
         assert x4.dim() == 4 and x4.shape == y4.shape
         b = x4.shape[0]
-        g = torch.zeros(3 * b * b, device=x.device, dtype=torch.float32)
+        g = torch.zeros(17 * 3 * b * b, device=x.device, dtype=torch.float32)    # result + SININN_MMD_SLOTS partial copies
         ops.mmd_gram(x4, y4, g)
         out = torch.empty(1, device=x.device, dtype=torch.float32)
         coef = torch.empty(4 * b * b, device=x.device, dtype=torch.float32)
