@@ -328,6 +328,11 @@ int sininn_masked_l1(const float* im1, const float* im2, const float* mask, int 
                      float weight, float* acc, float* out, void* stream);
 int sininn_masked_l1_bwd(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int C, int H,
                          int W, float weight, const float* acc, const float* gscale, float* g1, float* g2, void* stream);
+/* SSIMLoss (loss.py:75-103): (2 md + 1)^2 unpadded average pooling, md 1..2; acc / gradients as for sininn_masked_l1. */
+int sininn_ssim(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int C, int H, int W, int md,
+                float weight, float* acc, float* out, void* stream);
+int sininn_ssim_bwd(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int C, int H, int W,
+                    int md, float weight, const float* acc, const float* gscale, float* g1, float* g2, void* stream);
 /* BilateralSmooth (loss.py:106-132): edge-aware smoothness of flow [B][2][H][W] guided by img [B][C][H][W];
  * order 1 | 2, gauss != 0: squared ('gauss') else absolute ('exp') image differences scaled by edge_constant.
  * acc (ZEROED, SININN_CENSUS_ACC_FLOATS) is scratch.  _bwd: gflow = gscale[0] * d loss / d flow (img gets none). */

@@ -125,3 +125,17 @@ def bilateral_smooth(img, flow, weight, abs_fun, edge_constant, order):
         _, fgyy = grads(fgy)
         loss = ((wx * robust(fgxx)).mean() + (wy * robust(fgyy)).mean()) / 2
     return loss * weight
+
+
+def ssim_loss(x, y, mask, weight, md=1):
+    """loss.py:75-103 (SSIMLoss.forward)."""
+    x, y = x * mask, y * mask
+    pool = torch.nn.AvgPool2d(2 * md + 1, 1, 0)
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    mu_x, mu_y = pool(x), pool(y)
+    sx = pool(x * x) - mu_x.pow(2)
+    sy = pool(y * y) - mu_y.pow(2)
+    sxy = pool(x * y) - mu_x * mu_y
+    ssim = (2 * mu_x * mu_y + c1) * (2 * sxy + c2) / ((mu_x.pow(2) + mu_y.pow(2) + c1) * (sx + sy + c2))
+    dist = torch.clamp((1 - ssim) / 2, 0, 1)
+    return dist.mean() / mask.sum() * mask.numel() * weight

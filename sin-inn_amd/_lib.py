@@ -75,6 +75,8 @@ _SIGS = {
     'sininn_census_bwd': (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_f, c_f, c_f, c_f, C.c_void_p]),
     'sininn_masked_l1': (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_f, c_f, C.c_void_p]),
     'sininn_masked_l1_bwd': (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_f, c_f, c_f, c_f, C.c_void_p]),
+    'sininn_ssim': (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_f, c_f, C.c_void_p]),
+    'sininn_ssim_bwd': (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_f, c_f, c_f, c_f, C.c_void_p]),
     'sininn_bilateral_smooth': (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, c_f, c_f, C.c_void_p]),
     'sininn_bilateral_smooth_bwd': (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, c_f, c_f, C.c_void_p]),
     'sininn_coupling_colmap': (None, [C.c_int, C.c_int, C.POINTER(C.c_int)]),

@@ -76,6 +76,10 @@ int masked_l1_fwd_launch(const float* im1, const float* im2, const float* mask, 
                          float weight, float* acc_zeroed, float* out, hipStream_t st);
 int masked_l1_bwd_launch(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int C, int H, int W,
                          float weight, const float* acc, const float* gscale, float* g1, float* g2, hipStream_t st);
+int ssim_fwd_launch(const float* im1, const float* im2, const float* mask, int MC, int B, int C, int H, int W, int md,
+                    float weight, float* acc_zeroed, float* out, hipStream_t st);
+int ssim_bwd_launch(const float* im1, const float* im2, const float* mask, int MC, int B, int C, int H, int W, int md,
+                    float weight, const float* acc, const float* gscale, float* g1, float* g2, hipStream_t st);
 int smooth_fwd_launch(const float* img, const float* flow, int B, int C, int H, int W, int order, int gauss, float k,
                       float weight, float* acc_zeroed, float* out, hipStream_t st);
 int smooth_bwd_launch(const float* img, const float* flow, int B, int C, int H, int W, int order, int gauss, float k,
@@ -131,6 +135,14 @@ int sininn_masked_l1(const float* im1, const float* im2, const float* mask, int 
 int sininn_masked_l1_bwd(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int C, int H,
                          int W, float weight, const float* acc, const float* gscale, float* g1, float* g2, void* stream) {
   return masked_l1_bwd_launch(im1, im2, mask, mask_channels, B, C, H, W, weight, acc, gscale, g1, g2, ST(stream));
+}
+int sininn_ssim(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int C, int H, int W, int md,
+                float weight, float* acc, float* out, void* stream) {
+  return ssim_fwd_launch(im1, im2, mask, mask_channels, B, C, H, W, md, weight, acc, out, ST(stream));
+}
+int sininn_ssim_bwd(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int C, int H, int W,
+                    int md, float weight, const float* acc, const float* gscale, float* g1, float* g2, void* stream) {
+  return ssim_bwd_launch(im1, im2, mask, mask_channels, B, C, H, W, md, weight, acc, gscale, g1, g2, ST(stream));
 }
 int sininn_bilateral_smooth(const float* img, const float* flow, int B, int C, int H, int W, int order, int gauss,
                             float edge_constant, float weight, float* acc, float* out, void* stream) {

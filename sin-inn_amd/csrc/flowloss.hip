@@ -554,4 +554,157 @@ int smooth_bwd_launch(const float* img, const float* flow, int B, int C, int H, 
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// SSIMLoss (loss.py:75-103): x = im1 * mask, y = im2 * mask; (2 md + 1)^2 average pooling WITHOUT padding -> (H - 2 md) x
+// (W - 2 md) windows; dist = clamp((1 - SSIM) / 2, 0, 1); loss = weight * mean(dist) * numel(mask) / sum(mask).
+// One block = 16 x 16 windows (forward) / input pixels (backward) of one (image, channel); the masked tiles live in LDS.
+// ------------------------------------------------------------------------------------------------
+constexpr int SS_T = 16;
+constexpr float SS_C1 = 0.01f * 0.01f, SS_C2 = 0.03f * 0.03f;
+
+__device__ __forceinline__ void ssim_stage(const float* a, const float* bb, const float* mask, int MC, int C, int b, int c, int H,
+                                           int W, int y0, int x0, int TW, float* sx, float* sy) {
+  const int64_t HW = (int64_t)H * W;
+  for (int e = threadIdx.x; e < TW * TW; e += blockDim.x) {
+    const int gy = y0 + e / TW, gx = x0 + e % TW;
+    float vx = 0.f, vy = 0.f;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      const int64_t r = (int64_t)gy * W + gx;
+      const float m = mask[((int64_t)b * MC + (MC == 1 ? 0 : c)) * HW + r];
+      vx = a[((int64_t)b * C + c) * HW + r] * m;
+      vy = bb[((int64_t)b * C + c) * HW + r] * m;
+    }
+    sx[e] = vx; sy[e] = vy;
+  }
+  __syncthreads();
+}
+
+// SSIM of the window whose top-left corner is tile position (wy, wx); also the derivative pieces when D != nullptr:
+//   D = {dS/dex, dS/dey, dS/dexx (== dS/deyy), dS/dexy}
+__device__ __forceinline__ float ssim_window(const float* sx, const float* sy, int TW, int wy, int wx, int P, float* D) {
+  float ex = 0.f, ey = 0.f, exx = 0.f, eyy = 0.f, exy = 0.f;
+  for (int j = 0; j < P; ++j)
+    for (int i = 0; i < P; ++i) {
+      const float x = sx[(wy + j) * TW + wx + i], y = sy[(wy + j) * TW + wx + i];
+      ex += x; ey += y; exx += x * x; eyy += y * y; exy += x * y;
+    }
+  const float inv = 1.f / (float)(P * P);
+  ex *= inv; ey *= inv; exx *= inv; eyy *= inv; exy *= inv;
+  const float n1 = 2.f * ex * ey + SS_C1, n2 = 2.f * (exy - ex * ey) + SS_C2;
+  const float d1 = ex * ex + ey * ey + SS_C1, d2 = (exx - ex * ex) + (eyy - ey * ey) + SS_C2;
+  const float S = n1 * n2 / (d1 * d2);
+  if (D) {
+    const float r = 1.f / (d1 * d2);
+    D[0] = (2.f * ey * n2 - 2.f * ey * n1) * r - S * (2.f * ex / d1 - 2.f * ex / d2);
+    D[1] = (2.f * ex * n2 - 2.f * ex * n1) * r - S * (2.f * ey / d1 - 2.f * ey / d2);
+    D[2] = -S / d2;
+    D[3] = 2.f * n1 * r;
+  }
+  return S;
+}
+
+__global__ __launch_bounds__(SS_T * SS_T) void ssim_fwd_kernel(const float* __restrict__ a, const float* __restrict__ bb,
+                                                               const float* __restrict__ mask, int MC, int B, int C, int H, int W,
+                                                               int md, float* __restrict__ acc) {
+  extern __shared__ float sm[];
+  const int P = 2 * md + 1, TW = SS_T + 2 * md, Ho = H - 2 * md, Wo = W - 2 * md;
+  float* sx = sm; float* sy = sm + TW * TW;
+  const int tiles_x = (Wo + SS_T - 1) / SS_T, tiles_y = (Ho + SS_T - 1) / SS_T;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y; bid /= tiles_y;
+  const int c = bid % C, b = bid / C;
+  const int y0 = ty * SS_T, x0 = tx * SS_T;               // window (== input top-left) coordinates
+  ssim_stage(a, bb, mask, MC, C, b, c, H, W, y0, x0, TW, sx, sy);
+  const int ly = threadIdx.x / SS_T, lx = threadIdx.x % SS_T;
+  float d = 0.f, ms = 0.f;
+  if (y0 + ly < Ho && x0 + lx < Wo) {
+    const float S = ssim_window(sx, sy, TW, ly, lx, P, nullptr);
+    d = fminf(fmaxf((1.f - S) * 0.5f, 0.f), 1.f);
+  }
+  // sum(mask): every (b, mask channel) plane exactly once -- by the blocks of channel c < MC, over the INPUT pixels of
+  // their tile (tiles cover [0, Ho) x [0, Wo); the last row / column of tiles also takes the 2 md border pixels)
+  if (c < MC) {
+    const int64_t HW = (int64_t)H * W;
+    const int y1 = (ty == tiles_y - 1) ? H : y0 + SS_T, x1 = (tx == tiles_x - 1) ? W : x0 + SS_T;
+    for (int gy = y0 + ly; gy < y1; gy += SS_T)
+      for (int gx = x0 + lx; gx < x1; gx += SS_T) ms += mask[((int64_t)b * MC + c) * HW + (int64_t)gy * W + gx];
+  }
+  block_slot_add(d, ms, acc);
+}
+
+__global__ __launch_bounds__(SS_T * SS_T) void ssim_bwd_kernel(const float* __restrict__ a, const float* __restrict__ bb,
+                                                               const float* __restrict__ mask, int MC, int B, int C, int H, int W,
+                                                               int md, const float* __restrict__ acc,
+                                                               const float* __restrict__ gscale, float scale,
+                                                               float* __restrict__ g1, float* __restrict__ g2) {
+  extern __shared__ float sm[];
+  const int P = 2 * md + 1, halo = 2 * md, TW = SS_T + 2 * halo, Ho = H - 2 * md, Wo = W - 2 * md;
+  float* sx = sm; float* sy = sm + TW * TW;
+  const int tiles_x = (W + SS_T - 1) / SS_T, tiles_y = (H + SS_T - 1) / SS_T;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y; bid /= tiles_y;
+  const int c = bid % C, b = bid / C;
+  const int y0 = ty * SS_T, x0 = tx * SS_T;               // input pixel coordinates
+  ssim_stage(a, bb, mask, MC, C, b, c, H, W, y0 - halo, x0 - halo, TW, sx, sy);
+  const int ly = threadIdx.x / SS_T, lx = threadIdx.x % SS_T;
+  const int gy = y0 + ly, gx = x0 + lx;
+  if (gy >= H || gx >= W) return;
+  const float coef = (gscale ? gscale[0] : 1.f) * scale / acc[1] / (float)(P * P);
+  const float xq = sx[(ly + halo) * TW + lx + halo], yq = sy[(ly + halo) * TW + lx + halo];
+  float dx = 0.f, dy = 0.f;
+  for (int j = 0; j < P; ++j)
+    for (int i = 0; i < P; ++i) {
+      const int wy = gy - j, wx = gx - i;                 // window top-left (image coordinates) containing this pixel
+      if (wy < 0 || wy >= Ho || wx < 0 || wx >= Wo) continue;
+      float D[4];
+      const float S = ssim_window(sx, sy, TW, wy - (y0 - halo), wx - (x0 - halo), P, D);
+      const float h = (1.f - S) * 0.5f;
+      if (h <= 0.f || h >= 1.f) continue;                 // clamp inactive only inside (0, 1)
+      dx += -0.5f * (D[0] + 2.f * xq * D[2] + yq * D[3]);
+      dy += -0.5f * (D[1] + 2.f * yq * D[2] + xq * D[3]);
+    }
+  const int64_t HW = (int64_t)H * W, r = (int64_t)gy * W + gx;
+  const float m = mask[((int64_t)b * MC + (MC == 1 ? 0 : c)) * HW + r] * coef;
+  if (g1) g1[((int64_t)b * C + c) * HW + r] = dx * m;
+  if (g2) g2[((int64_t)b * C + c) * HW + r] = dy * m;
+}
+
+static int ssim_check(const float* im1, const float* im2, const float* mask, int MC, int B, int C, int H, int W, int md) {
+  SININN_CHECK(im1 && im2 && mask, "ssim: null pointer");
+  SININN_CHECK(B > 0 && C > 0 && (MC == 1 || MC == C) && md >= 1 && md <= 2 && H > 2 * md && W > 2 * md,
+               "ssim: bad shape (md in 1..2, mask channels 1 or C)");
+  return 0;
+}
+
+int ssim_fwd_launch(const float* im1, const float* im2, const float* mask, int MC, int B, int C, int H, int W, int md,
+                    float weight, float* acc_zeroed, float* out, hipStream_t st) {
+  if (int rc = ssim_check(im1, im2, mask, MC, B, C, H, W, md)) return rc;
+  SININN_CHECK(acc_zeroed && out, "ssim: null pointer");
+  const int Ho = H - 2 * md, Wo = W - 2 * md, TW = SS_T + 2 * md;
+  const int tiles = B * C * ((Ho + SS_T - 1) / SS_T) * ((Wo + SS_T - 1) / SS_T);
+  hipLaunchKernelGGL(ssim_fwd_kernel, dim3(tiles), dim3(SS_T * SS_T), 2 * TW * TW * sizeof(float), st, im1, im2, mask, MC, B, C, H,
+                     W, md, acc_zeroed);
+  SININN_LAUNCH_CHECK("ssim_fwd");
+  // mean over B*C*Ho*Wo windows, times numel(mask) = B*MC*H*W, over sum(mask)
+  const float scale = weight * ((float)B * MC * H * W) / ((float)B * C * Ho * Wo);
+  hipLaunchKernelGGL(census_finish_kernel, dim3(1), dim3(CENSUS_SLOTS), 0, st, acc_zeroed, scale, out);
+  SININN_LAUNCH_CHECK("ssim_finish");
+  return 0;
+}
+
+int ssim_bwd_launch(const float* im1, const float* im2, const float* mask, int MC, int B, int C, int H, int W, int md,
+                    float weight, const float* acc, const float* gscale, float* g1, float* g2, hipStream_t st) {
+  if (int rc = ssim_check(im1, im2, mask, MC, B, C, H, W, md)) return rc;
+  SININN_CHECK(acc && (g1 || g2), "ssim_bwd: null pointer");
+  const int Ho = H - 2 * md, Wo = W - 2 * md, TW = SS_T + 4 * md;
+  const int tiles = B * C * ((H + SS_T - 1) / SS_T) * ((W + SS_T - 1) / SS_T);
+  const float scale = weight * ((float)B * MC * H * W) / ((float)B * C * Ho * Wo);
+  hipLaunchKernelGGL(ssim_bwd_kernel, dim3(tiles), dim3(SS_T * SS_T), 2 * TW * TW * sizeof(float), st, im1, im2, mask, MC, B, C, H,
+                     W, md, acc, gscale, scale, g1, g2);
+  SININN_LAUNCH_CHECK("ssim_bwd");
+  return 0;
+}
+
 }  // namespace sininn

@@ -3,7 +3,7 @@ error behaviour as the reference; all arithmetic runs in libsininn.so (csrc/flow
 
     FunctionSoftsplat / ModuleSoftsplat   video-interpolation/my_utils/softsplat.py:331-371
     occlusion_wang / occlusion_unity      video-interpolation/my_utils/occlusions.py:96-109
-    L1Loss / CensusLoss / BilateralSmooth video-interpolation/my_utils/loss.py:17-72,106-132
+    L1Loss / CensusLoss / SSIMLoss / BilateralSmooth   video-interpolation/my_utils/loss.py:17-132
 
 Tensors are NCHW fp32 CUDA tensors (made contiguous like the reference does); CPU tensors raise NotImplementedError
 (softsplat.py:289-290).  The reference's `occlusion_brox` and the Resample2d warp are served by
@@ -194,6 +194,47 @@ class L1Loss(BaseLoss):
         if self.weight == 0:
             return super().forward()
         return _MaskedL1Fn.apply(im1, im2, _expand_mask(mask, im1), self.weight)
+
+
+class _SSIMFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, mask, weight, md):
+        x, y, mask = _prep(x), _prep(y), _prep(mask)
+        b, c, h, w = x.shape
+        assert y.shape == x.shape and mask.shape in ((b, 1, h, w), (b, c, h, w))
+        acc = x.new_zeros(ACC_FLOATS)
+        out = x.new_empty(1)
+        check(_lib.lib().sininn_ssim(ptr(x), ptr(y), ptr(mask), mask.shape[1], b, c, h, w, int(md), float(weight), ptr(acc),
+                                     ptr(out), _stream()))
+        ctx.save_for_backward(x, y, mask, acc)
+        ctx.cfg = (float(weight), int(md))
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, mask, acc = ctx.saved_tensors
+        b, c, h, w = x.shape
+        weight, md = ctx.cfg
+        g1 = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        g2 = torch.empty_like(y) if ctx.needs_input_grad[1] else None
+        if g1 is not None or g2 is not None:
+            gs = g.reshape(1).to(torch.float32).contiguous()
+            check(_lib.lib().sininn_ssim_bwd(ptr(x), ptr(y), ptr(mask), mask.shape[1], b, c, h, w, md, weight, ptr(acc), ptr(gs),
+                                             ptr(g1), ptr(g2), _stream()))
+        return g1, g2, None, None, None
+
+
+class SSIMLoss(BaseLoss):
+    """loss.py:75-103: (1 - SSIM) / 2 over unpadded (2 md + 1)^2 windows of the masked images, clamped to [0, 1]."""
+
+    def __init__(self, weight, md=1):
+        super().__init__(weight=weight)
+        self.md = md
+
+    def forward(self, x, y, mask):
+        if self.weight == 0:
+            return super().forward()
+        return _SSIMFn.apply(x, y, _expand_mask(mask, x), self.weight, self.md)
 
 
 class _SmoothFn(torch.autograd.Function):

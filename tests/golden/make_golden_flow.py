@@ -50,6 +50,12 @@ def main():
         loss = fn(im, im_w, m)
         loss.backward()
         out.update({f'f3_{tag}_loss': loss.detach(), f'f3_{tag}_gim': im.grad.clone(), f'f3_{tag}_gimw': im_w.grad.clone()})
+    # F5 SSIMLoss (loss.py:75-103), 1- and 3-channel masks, md 1 and 2
+    for tag, m, md in (('ssim1', mask1, 1), ('ssim3', mask3, 1), ('ssim1_md2', mask1, 2)):
+        im.grad = im_w.grad = None
+        loss = ref_loss.SSIMLoss(0.4, md=md)(im, im_w, m)
+        loss.backward()
+        out.update({f'f3_{tag}_loss': loss.detach(), f'f3_{tag}_gim': im.grad.clone(), f'f3_{tag}_gimw': im_w.grad.clone()})
     # F4 BilateralSmooth (loss.py:106-132): both edge functions and orders; gradient w.r.t. the flow
     img = torch.rand(2, 3, 17, 22, generator=g)
     flow = (torch.randn(2, 2, 17, 22, generator=g) * 1.5).requires_grad_(True)

@@ -82,7 +82,7 @@ def test_census_matches_reference_fixture(gold, md):
     im = gold[f'f2_{md}_im'].cuda().requires_grad_(True)
     imw = gold[f'f2_{md}_imw'].cuda().requires_grad_(True)
     loss = CensusLoss(0.1, max_distance=md)(im, imw, gold[f'f2_{md}_mask'].cuda())
-    assert abs(float(loss) / float(gold[f'f2_{md}_loss']) - 1) < RTOL
+    assert abs(float(loss.detach()) / float(gold[f'f2_{md}_loss']) - 1) < RTOL
     (loss * 3.0).backward()
     assert relerr(im.grad / 3.0, gold[f'f2_{md}_gim']) < 3e-4
     assert relerr(imw.grad / 3.0, gold[f'f2_{md}_gimw']) < 3e-4
@@ -112,9 +112,10 @@ def test_census_ragged_sizes_and_placeholders():
 
 
 def test_masked_losses_with_trainer_masks_match_reference_fixture(gold):
-    from sin_inn_amd.flowloss import CensusLoss, L1Loss
+    from sin_inn_amd.flowloss import CensusLoss, L1Loss, SSIMLoss
     for tag, fn, mk in (('census3', CensusLoss(0.1, max_distance=3), 'f3_mask3'), ('l1_3', L1Loss(1), 'f3_mask3'),
-                        ('l1_1', L1Loss(0.7), 'f3_mask1')):
+                        ('l1_1', L1Loss(0.7), 'f3_mask1'), ('ssim1', SSIMLoss(0.4, 1), 'f3_mask1'),
+                        ('ssim3', SSIMLoss(0.4, 1), 'f3_mask3'), ('ssim1_md2', SSIMLoss(0.4, 2), 'f3_mask1')):
         im = gold['f3_im'].cuda().requires_grad_(True)
         imw = gold['f3_imw'].cuda().requires_grad_(True)
         loss = fn(im, imw, gold[mk].cuda())

@@ -61,7 +61,10 @@ def test_masked_losses_with_trainer_masks_match_reference(gold):
     """3-channel masks (trainer.py:64) and 1-channel masks: CensusLoss and L1Loss values + gradients."""
     for tag, fn, mk in (('census3', lambda a, b, m: FO.census_loss(a, b, m, 0.1, 3), 'f3_mask3'),
                         ('l1_3', lambda a, b, m: FO.l1_loss(a, b, m, 1), 'f3_mask3'),
-                        ('l1_1', lambda a, b, m: FO.l1_loss(a, b, m, 0.7), 'f3_mask1')):
+                        ('l1_1', lambda a, b, m: FO.l1_loss(a, b, m, 0.7), 'f3_mask1'),
+                        ('ssim1', lambda a, b, m: FO.ssim_loss(a, b, m, 0.4, 1), 'f3_mask1'),
+                        ('ssim3', lambda a, b, m: FO.ssim_loss(a, b, m, 0.4, 1), 'f3_mask3'),
+                        ('ssim1_md2', lambda a, b, m: FO.ssim_loss(a, b, m, 0.4, 2), 'f3_mask1')):
         im = gold['f3_im'].clone().requires_grad_(True)
         imw = gold['f3_imw'].clone().requires_grad_(True)
         loss = fn(im, imw, gold[mk])
