@@ -317,6 +317,9 @@ int sininn_softsplat_bwd(const float* in, const float* flow, const float* gout, 
                          float* gin, float* gflow, void* stream);
 int sininn_occlusion_wang(const float* flow21, int B, int H, int W, float thresh, float* corr, float* mask, void* stream);
 #define SININN_CENSUS_ACC_FLOATS 130
+/* occlusion_brox (occlusions.py:111-118): mask [B][1][H][W] bytes (1 = inconsistent) from the forward flow and the backward
+ * flow already warped by it (sininn_flow_warp_l1(bw, fw)). */
+int sininn_occlusion_brox(const float* fw, const float* warped_bw, int B, int H, int W, uint8_t* mask, void* stream);
 int sininn_census(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int H, int W,
                   int max_distance, float weight, float* acc, float* out, void* stream);
 int sininn_census_bwd(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int H, int W,

@@ -139,3 +139,13 @@ def ssim_loss(x, y, mask, weight, md=1):
     ssim = (2 * mu_x * mu_y + c1) * (2 * sxy + c2) / ((mu_x.pow(2) + mu_y.pow(2) + c1) * (sx + sy + c2))
     dist = torch.clamp((1 - ssim) / 2, 0, 1)
     return dist.mean() / mask.sum() * mask.numel() * weight
+
+
+def occlusion_brox(orig_fw, orig_bw, thresh=None):
+    """occlusions.py:111-118; the warp is Resample2d restated in oracle/sininn_oracle.py::flow_warp (its CUDA extension is
+    absent, so this function is parity-unpinned like that restatement)."""
+    from oracle import sininn_oracle as O
+    warped_bw = O.flow_warp(orig_bw, orig_fw)
+    sq_sum = ((orig_fw + warped_bw) ** 2).sum(1)
+    sum_sq = (orig_fw ** 2 + warped_bw ** 2).sum(1)
+    return (sq_sum >= 0.01 * sum_sq + 0.5).unsqueeze(1)

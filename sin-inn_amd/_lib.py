@@ -75,6 +75,7 @@ _SIGS = {
     'sininn_census_bwd': (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_f, c_f, c_f, c_f, C.c_void_p]),
     'sininn_masked_l1': (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_f, c_f, C.c_void_p]),
     'sininn_masked_l1_bwd': (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_f, c_f, c_f, c_f, C.c_void_p]),
+    'sininn_occlusion_brox': (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'sininn_ssim': (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_f, c_f, C.c_void_p]),
     'sininn_ssim_bwd': (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_f, c_f, c_f, c_f, C.c_void_p]),
     'sininn_bilateral_smooth': (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, c_f, c_f, C.c_void_p]),

@@ -76,6 +76,7 @@ int masked_l1_fwd_launch(const float* im1, const float* im2, const float* mask, 
                          float weight, float* acc_zeroed, float* out, hipStream_t st);
 int masked_l1_bwd_launch(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int C, int H, int W,
                          float weight, const float* acc, const float* gscale, float* g1, float* g2, hipStream_t st);
+int brox_mask_launch(const float* fw, const float* warped_bw, int B, int H, int W, uint8_t* mask, hipStream_t st);
 int ssim_fwd_launch(const float* im1, const float* im2, const float* mask, int MC, int B, int C, int H, int W, int md,
                     float weight, float* acc_zeroed, float* out, hipStream_t st);
 int ssim_bwd_launch(const float* im1, const float* im2, const float* mask, int MC, int B, int C, int H, int W, int md,
@@ -135,6 +136,9 @@ int sininn_masked_l1(const float* im1, const float* im2, const float* mask, int 
 int sininn_masked_l1_bwd(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int C, int H,
                          int W, float weight, const float* acc, const float* gscale, float* g1, float* g2, void* stream) {
   return masked_l1_bwd_launch(im1, im2, mask, mask_channels, B, C, H, W, weight, acc, gscale, g1, g2, ST(stream));
+}
+int sininn_occlusion_brox(const float* fw, const float* warped_bw, int B, int H, int W, uint8_t* mask, void* stream) {
+  return brox_mask_launch(fw, warped_bw, B, H, W, mask, ST(stream));
 }
 int sininn_ssim(const float* im1, const float* im2, const float* mask, int mask_channels, int B, int C, int H, int W, int md,
                 float weight, float* acc, float* out, void* stream) {

@@ -707,4 +707,30 @@ int ssim_bwd_launch(const float* im1, const float* im2, const float* mask, int M
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// occlusion_brox (occlusions.py:111-118): forward-backward consistency on the backward flow warped by the forward flow
+// (the warp itself is sininn_flow_warp_l1 == Resample2d):  mask = |fw + w(bw)|^2 >= 0.01 (|fw|^2 + |w(bw)|^2) + 0.5
+// ------------------------------------------------------------------------------------------------
+__global__ void brox_mask_kernel(const float* __restrict__ fw, const float* __restrict__ wbw, int B, int H, int W,
+                                 uint8_t* __restrict__ mask) {
+  const int64_t HW = (int64_t)H * W, total = (int64_t)B * HW;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int b = (int)(idx / HW);
+  const int64_t r = idx % HW;
+  const float fx = fw[((int64_t)b * 2 + 0) * HW + r], fy = fw[((int64_t)b * 2 + 1) * HW + r];
+  const float wx = wbw[((int64_t)b * 2 + 0) * HW + r], wy = wbw[((int64_t)b * 2 + 1) * HW + r];
+  const float sq_sum = (fx + wx) * (fx + wx) + (fy + wy) * (fy + wy);
+  const float sum_sq = (fx * fx + wx * wx) + (fy * fy + wy * wy);
+  mask[idx] = sq_sum >= 0.01f * sum_sq + 0.5f ? 1 : 0;
+}
+
+int brox_mask_launch(const float* fw, const float* warped_bw, int B, int H, int W, uint8_t* mask, hipStream_t st) {
+  SININN_CHECK(fw && warped_bw && mask && B > 0 && H > 0 && W > 0, "occlusion_brox: bad arguments");
+  const int64_t total = (int64_t)B * H * W;
+  hipLaunchKernelGGL(brox_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, fw, warped_bw, B, H, W, mask);
+  SININN_LAUNCH_CHECK("occlusion_brox");
+  return 0;
+}
+
 }  // namespace sininn

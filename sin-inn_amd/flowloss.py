@@ -2,12 +2,11 @@
 error behaviour as the reference; all arithmetic runs in libsininn.so (csrc/flowloss.hip):
 
     FunctionSoftsplat / ModuleSoftsplat   video-interpolation/my_utils/softsplat.py:331-371
-    occlusion_wang / occlusion_unity      video-interpolation/my_utils/occlusions.py:96-109
+    occlusion_wang / _brox / _unity       video-interpolation/my_utils/occlusions.py:96-118
     L1Loss / CensusLoss / SSIMLoss / BilateralSmooth   video-interpolation/my_utils/loss.py:17-132
 
 Tensors are NCHW fp32 CUDA tensors (made contiguous like the reference does); CPU tensors raise NotImplementedError
-(softsplat.py:289-290).  The reference's `occlusion_brox` and the Resample2d warp are served by
-`sin_inn_amd.functional.flow_warp_l1`.
+(softsplat.py:289-290).  The Resample2d warp is `sin_inn_amd.functional.flow_warp_l1`.
 """
 import torch
 
@@ -101,6 +100,20 @@ def occlusion_wang(flow12, flow21, thresh):
     mask = torch.empty_like(corr)
     check(_lib.lib().sininn_occlusion_wang(ptr(flow21), b, h, w, float(thresh), ptr(corr), ptr(mask), _stream()))
     return mask
+
+
+def occlusion_brox(orig_fw, orig_bw, thresh):
+    """occlusions.py:111-118: forward-backward consistency (True = inconsistent; `thresh` is unused, as in the reference).
+    The warp is Resample2d (sin_inn_amd.functional.flow_warp_l1), the test one small kernel."""
+    from .functional import flow_warp_l1
+    fw, bw = _prep(orig_fw.detach()), _prep(orig_bw.detach())
+    b, two, h, w = fw.shape
+    assert two == 2 and bw.shape == fw.shape
+    warped_bw, _ = flow_warp_l1(bw, fw)
+    warped_bw = warped_bw.contiguous()
+    mask = torch.empty((b, 1, h, w), device=fw.device, dtype=torch.uint8)
+    check(_lib.lib().sininn_occlusion_brox(ptr(fw), ptr(warped_bw), b, h, w, mask.data_ptr(), _stream()))
+    return mask.bool()
 
 
 def occlusion_unity(flow, *args):
