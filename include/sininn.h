@@ -51,7 +51,8 @@ int sininn_pack_conv_weights(const float* w_oihw, const float* bias, int N, int 
 
 /* Winograd F(2x2,3x3) filter transform of a 3x3 conv weight (U = G g G^T), same row / column conventions as
  * sininn_pack_conv_weights with the tap axis replaced by the 16 transform positions:
- *   u_fwd [16][Np][Cin], u_dgrad [16][Cdp][N] (flipped taps).  Either destination may be NULL. */
+ *   u_fwd [16][Cin/8][Np][8], u_dgrad [16][N/8][Cdp][8] (flipped taps): channel-chunk-major, so the 8-channel chunk a
+ *   kernel iteration stages is contiguous per position.  Either destination may be NULL. */
 int sininn_pack_winograd(const float* w_oihw, int N, int Cin, const int* colmap, int Np, float* u_fwd,
                          int Cdp, float* u_dgrad, void* stream);
 

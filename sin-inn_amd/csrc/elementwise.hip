@@ -925,8 +925,10 @@ int bayer_demosaic_launch(const uint8_t* hr, uint8_t* rgb, int T, int H, int W, 
 // ------------------------------------------------------------------------------------------------
 // Winograd F(2x2,3x3) filter transform U = G g G^T (G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]), packed like the
 // direct weights with the tap axis replaced by the 16 transform positions:
-//   u_fwd  [16][Np ][Cin]  g[a][b] = w[colmap[q]][c][a][b]
-//   u_dgrad[16][Cdp][N  ]  g[a][b] = w[n][c][2-a][2-b]   (data-gradient conv: flipped taps, channel roles swapped)
+//   u_fwd  [16][Cin/8][Np ][8]  g[a][b] = w[colmap[q]][c][a][b]
+//   u_dgrad[16][N/8  ][Cdp][8]  g[a][b] = w[n][c][2-a][2-b]   (data-gradient conv: flipped taps, channel roles swapped)
+// channel-chunk-major: the 8-channel chunk the kernel stages per iteration is one contiguous [columns][8] slab per position,
+// so its loads use whole cache lines (a [column][Cin] row layout gave every wave-level load 32 lines, a quarter used each)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void wino_filter(const float* g, float* u) {   // g[9] row-major -> u[16]
   float t[4][3];
@@ -960,7 +962,7 @@ __global__ void pack_winograd_kernel(const float* __restrict__ w, int N, int Cin
     for (int t = 0; t < 9; ++t) g[t] = ok ? w[((size_t)n * Cin + c) * 9 + t] : 0.f;
     wino_filter(g, u);
 #pragma unroll
-    for (int pz = 0; pz < 16; ++pz) u_fwd[((size_t)pz * Np + q) * Cin + c] = u[pz];
+    for (int pz = 0; pz < 16; ++pz) u_fwd[(((size_t)pz * (Cin / 8) + c / 8) * Np + q) * 8 + (c & 7)] = u[pz];
   } else if (idx < nf + nd) {
     const int k = idx - nf;
     const int n = k % N, c = k / N;
@@ -969,7 +971,7 @@ __global__ void pack_winograd_kernel(const float* __restrict__ w, int N, int Cin
     for (int t = 0; t < 9; ++t) g[t] = ok ? w[((size_t)n * Cin + c) * 9 + (8 - t)] : 0.f;
     wino_filter(g, u);
 #pragma unroll
-    for (int pz = 0; pz < 16; ++pz) u_dgrad[((size_t)pz * Cdp + c) * N + n] = u[pz];
+    for (int pz = 0; pz < 16; ++pz) u_dgrad[(((size_t)pz * (N / 8) + n / 8) * Cdp + c) * 8 + (n & 7)] = u[pz];
   }
 }
 
@@ -1010,7 +1012,7 @@ __global__ void pack_batch_kernel(const sininn_pack_desc* __restrict__ descs, in
       for (int t = 0; t < 9; ++t) g[t] = ok ? d.w[((size_t)nn * d.Cin + c) * 9 + t] : 0.f;
       wino_filter(g, u);
 #pragma unroll
-      for (int pz = 0; pz < 16; ++pz) d.w_fwd[((size_t)pz * d.Np + q) * d.Cin + c] = u[pz];
+      for (int pz = 0; pz < 16; ++pz) d.w_fwd[(((size_t)pz * (d.Cin / 8) + c / 8) * d.Np + q) * 8 + (c & 7)] = u[pz];
     } else {
       const int c = k % d.Cin, q = (k / d.Cin) % d.Np, t = k / (d.Cin * d.Np);
       const int nn = d.colmap ? d.colmap[q] : q;
@@ -1027,7 +1029,7 @@ __global__ void pack_batch_kernel(const sininn_pack_desc* __restrict__ descs, in
       for (int t = 0; t < 9; ++t) g[t] = ok ? d.w[((size_t)nn * d.Cin + c) * 9 + (8 - t)] : 0.f;
       wino_filter(g, u);
 #pragma unroll
-      for (int pz = 0; pz < 16; ++pz) d.w_dgrad[((size_t)pz * d.Cdp + c) * d.N + nn] = u[pz];
+      for (int pz = 0; pz < 16; ++pz) d.w_dgrad[(((size_t)pz * (d.N / 8) + nn / 8) * d.Cdp + c) * 8 + (nn & 7)] = u[pz];
     } else {
       const int nn = k % d.N, c = (k / d.N) % d.Cdp, t = k / (d.N * d.Cdp);
       d.w_dgrad[k] = (c < d.Cin) ? d.w[((size_t)nn * d.Cin + c) * taps + (taps - 1 - t)] : 0.f;
@@ -1053,6 +1055,7 @@ int pack_winograd_launch(const float* w, int N, int Cin, const int* colmap, int 
   SININN_CHECK(w != nullptr && N > 0 && Cin > 0 && (u_fwd || u_dgrad), "pack_winograd: bad arguments");
   SININN_CHECK(!u_fwd || Np >= 1, "pack_winograd: bad Np");
   SININN_CHECK(!u_dgrad || Cdp >= Cin, "pack_winograd: Cdp < Cin");
+  SININN_CHECK((!u_fwd || Cin % 8 == 0) && (!u_dgrad || N % 8 == 0), "pack_winograd: the contraction axis must be a multiple of 8");
   const int total = (u_fwd ? Np * Cin : 0) + (u_dgrad ? Cdp * N : 0);
   hipLaunchKernelGGL(pack_winograd_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, N, Cin, colmap, Np, u_fwd,
                      Cdp, u_dgrad);

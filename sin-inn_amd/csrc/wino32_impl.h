@@ -80,7 +80,8 @@ __global__ __launch_bounds__(256 * CG, 2 / CG) void wino32_kernel(ConvDev p) {
     const int c4 = f & 1, col = (f >> 1) % BN, pos = (f >> 1) / BN;
     const bool inside = pos < 16;
     u_loff[r] = inside ? ((pos * BN + col) * SU + c4 * 4) : -1;
-    u_goff[r] = (inside && (n0 + col) < p.Np) ? ((pos * p.Np + n0 + col) * p.Cin + c4 * 4) : -1;
+    // U pack = [16 positions][Cin / 8 chunks][Np columns][8 channels]
+    u_goff[r] = (inside && (n0 + col) < p.Np) ? ((pos * (p.Cin / CK) * p.Np + n0 + col) * CK + c4 * 4) : -1;
   }
   const int nchunks = p.Cin / CK;
 
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256 * CG, 2 / CG) void wino32_kernel(ConvDev p) {
 #pragma unroll
     for (int r = 0; r < U_F4; ++r) {
       f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      u_reg[r] = (u_goff[r] >= 0) ? *reinterpret_cast<const f32x4*>(p.w + u_goff[r] + chunk * CK) : z;
+      u_reg[r] = (u_goff[r] >= 0) ? *reinterpret_cast<const f32x4*>(p.w + u_goff[r] + chunk * p.Np * CK) : z;
     }
   };
   auto store_chunk = [&](float* idst, float* udst) {

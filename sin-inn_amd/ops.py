@@ -67,7 +67,7 @@ def pad32(n):
 def pack_conv(weight, bias, colmap=None, want_dgrad=True, wino_fwd=False, wino_dgrad=False, out=None):
     """OIHW conv weight -> (w_fwd, b_fwd, w_dgrad).
     tap-major packs: w_fwd [taps][Np][Cin], w_dgrad [taps][pad16(Cin)][N];
-    Winograd packs (3x3 only): w_fwd [16][Np][Cin], w_dgrad [16][pad32(Cin)][N]  (U = G g G^T).
+    Winograd packs (3x3 only): w_fwd [16][Cin/8][Np][8], w_dgrad [16][N/8][pad32(Cin)][8]  (U = G g G^T, chunk-major).
     `out` = a previous result of the same call to refresh in place."""
     _chk(weight)
     n, cin, k, _ = weight.shape
