@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from . import _lib, ops
 from ._lib import CONV_ADD, CONV_LINEAR, check
-from .modules import WEIGHTS_EPOCH, _grad_buf, import_nchw
+from .modules import USE_SIDE_STREAM, USE_WINOGRAD, WEIGHTS_EPOCH, _grad_buf, _side_stream, import_nchw
 
 CONV_LRELU, CONV_IRN_FWD, CONV_IRN_INV = 6, 7, 8
 GC = 32
@@ -95,7 +95,7 @@ class _DensePacks:
 
     def get(self, block):
         convs = block.convs()
-        key = tuple((c.weight.data_ptr(), c.weight._version, c.bias._version) for c in convs) + (WEIGHTS_EPOCH[0],)
+        key = tuple((c.weight.data_ptr(), c.weight._version, c.bias._version) for c in convs) + (WEIGHTS_EPOCH[0], USE_WINOGRAD[0])
         if key != self.key:
             cin, cinp = block.channel_in, block.cinp
             packs = []
@@ -111,7 +111,9 @@ class _DensePacks:
                     bp = torch.zeros(nout, device=w.device, dtype=torch.float32)
                     bp[:w.shape[0]] = bias
                     w, bias = wp, bp
-                packs.append(ops.pack_conv(w.contiguous(), bias.contiguous(), None, True))
+                # all five convs are 3x3: Winograd F(2x2,3x3) packs for the forward and the data-gradient conv
+                packs.append(ops.pack_conv(w.contiguous(), bias.contiguous(), None, True, wino_fwd=USE_WINOGRAD[0],
+                                           wino_dgrad=USE_WINOGRAD[0]))
             self.key, self.packs = key, packs
         return self.packs
 
@@ -138,11 +140,11 @@ class _DenseFn(torch.autograd.Function):
             k = cinp + GC * i
             wf, bf, _ = packs[i]
             ops.conv(in_=_vp(buf), in_stride=bw, Cin=k, w=_vp(wf), bias=_vp(bf), Np=GC, B=b, H=h, W=w, ksize=3,
-                     mode=CONV_LRELU, clamp=SLOPE, out=_vp(buf, k), out_stride=bw, N=GC)
+                     winograd=int(USE_WINOGRAD[0]), mode=CONV_LRELU, clamp=SLOPE, out=_vp(buf, k), out_stride=bw, N=GC)
         wf, bf, _ = packs[4]
         out = torch.empty((b, h, w, cout), device=dev, dtype=torch.float32)
         kw = dict(in_=_vp(buf), in_stride=bw, Cin=bw, w=_vp(wf), bias=_vp(bf), Np=ops.pad16(_pad8(cout)), B=b, H=h, W=w,
-                  ksize=3, out=_vp(out), out_stride=cout, N=cout)
+                  ksize=3, winograd=int(USE_WINOGRAD[0]), out=_vp(out), out_stride=cout, N=cout)
         a1 = a2 = None
         if mode == 'linear':
             kw.update(mode=CONV_LINEAR)
@@ -200,20 +202,32 @@ class _DenseFn(torch.autograd.Function):
             g_aux1, g_aux2 = dv, dh.view(b, h, w, cout)
         dF = torch.zeros((m, bw), device=dev, dtype=torch.float32)
 
+        # weight gradients go to the dedicated side stream (like the GLOW executor's): they only read `buf` and a slice of
+        # the gradient buffer that is final by then, so they overlap the data-gradient chain, and every `+=` into a
+        # parameter gradient is issued on that ONE stream (two pass chains may then run concurrently)
+        main = torch.cuda.current_stream()
+        side = _side_stream(dev) if USE_SIDE_STREAM[0] else main
+
         def wgrad(i, k, dout_t, dout_off, dout_stride, n):
             cv = convs[i]
             if not cv.weight.requires_grad:
                 return
-            if cinp == cin:
-                ops.wgrad(buf, 0, bw, k, dout_t, dout_stride, n, b, h, w, 3, _grad_buf(cv.weight), _grad_buf(cv.bias),
-                          dout_off=dout_off)
-            else:       # gradient w.r.t. the channel-padded weight, then drop the pad channels
-                gwp = torch.zeros((n, k, 3, 3), device=dev, dtype=torch.float32)
-                ops.wgrad(buf, 0, bw, k, dout_t, dout_stride, n, b, h, w, 3, gwp, _grad_buf(cv.bias), dout_off=dout_off)
-                gw = _grad_buf(cv.weight)
-                gw[:, :cin] += gwp[:, :cin]
-                if i:
-                    gw[:, cin:] += gwp[:, cinp:]
+            if side is not main:
+                side.wait_stream(main)
+            with torch.cuda.stream(side):
+                if cinp == cin:
+                    ops.wgrad(buf, 0, bw, k, dout_t, dout_stride, n, b, h, w, 3, _grad_buf(cv.weight), _grad_buf(cv.bias),
+                              dout_off=dout_off)
+                else:   # gradient w.r.t. the channel-padded weight, then drop the pad channels
+                    gwp = torch.zeros((n, k, 3, 3), device=dev, dtype=torch.float32)
+                    ops.wgrad(buf, 0, bw, k, dout_t, dout_stride, n, b, h, w, 3, gwp, _grad_buf(cv.bias), dout_off=dout_off)
+                    gw = _grad_buf(cv.weight)
+                    gw[:, :cin] += gwp[:, :cin]
+                    if i:
+                        gw[:, cin:] += gwp[:, cinp:]
+            if side is not main:
+                for t in (buf, dout_t):
+                    t.record_stream(side)
 
         # conv5: weight gradient, then dF[:, :bw] = its data gradient
         wgrad(4, bw, dD, 0, coutp, cout)
@@ -229,8 +243,9 @@ class _DenseFn(torch.autograd.Function):
 
 def _dgrad(src, src_off, src_stride, n_src, w_dgrad, n_out, dst, dst_stride, b, h, w, accumulate):
     """dst[:, :n_out] (+)= conv(src[:, src_off : src_off+n_src], w_dgrad)   (data gradient of one dense conv)."""
-    kw = dict(in_=_vp(src, src_off), in_stride=src_stride, Cin=n_src, w=_vp(w_dgrad), Np=ops.pad16(n_out), B=b, H=h, W=w,
-              ksize=3, out=_vp(dst), out_stride=dst_stride, N=n_out)
+    wino = USE_WINOGRAD[0]
+    kw = dict(in_=_vp(src, src_off), in_stride=src_stride, Cin=n_src, w=_vp(w_dgrad),
+              Np=ops.pad32(n_out) if wino else ops.pad16(n_out), winograd=int(wino), B=b, H=h, W=w, ksize=3, out=_vp(dst), out_stride=dst_stride, N=n_out)
     if accumulate:
         kw.update(mode=CONV_ADD, addend=_vp(dst), addend_stride=dst_stride)
     else:
@@ -325,6 +340,11 @@ class InvRescaleNet(nn.Module):
             for _ in range(opt.num_coupling):
                 operations.append(InvBlockExp(current, min(channel_out, current // 2)))
         self.operations = nn.ModuleList(operations)
+
+    @property
+    def concurrent_passes_safe(self):
+        """Two pass chains may run on two streams at once: all parameter gradients accumulate on the side stream."""
+        return bool(USE_SIDE_STREAM[0])
 
     def forward(self, x, rev=False):
         if not x.is_cuda:

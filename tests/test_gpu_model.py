@@ -228,7 +228,8 @@ def test_bigger_configs_properties():
         torch.cuda.empty_cache()
 
 
-def test_training_is_bitwise_reproducible():
+@pytest.mark.parametrize('arch', ['SRF', 'IRN'])
+def test_training_is_bitwise_reproducible(arch):
     """Two identical runs (same seed, frames, latents) give bitwise identical weights after 3 steps: the forward / reverse
     chains run on two streams and all weight gradients on a third, but every `+=` into a gradient buffer is issued on
     that ONE stream in host order and the split-K slabs are reduced in a fixed order -- a race between the chains would
@@ -239,7 +240,7 @@ def test_training_is_bitwise_reproducible():
 
     def run():
         torch.manual_seed(5)
-        opt = make_opt(num_coupling=2, lr_window=2)
+        opt = make_opt(num_coupling=2, lr_window=2, architecture=arch)
         model = lit_wrapper.SingleVideoINN(3, 128, 128, opt).cuda()
         optim = model.attach_optimizer()
         assert model.overlap_passes and model.inn.concurrent_passes_safe
