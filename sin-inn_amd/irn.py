@@ -132,7 +132,10 @@ class _DenseFn(torch.autograd.Function):
         cinp, cout = block.cinp, block.channel_out
         bw = cinp + 4 * GC
         packs = block._packs.get(block)
-        buf = torch.zeros((m, bw), device=dev, dtype=torch.float32)
+        # only the pad channels [cin, cinp) must be zero: x fills [0, cin), the four convs their 32-channel slots
+        buf = torch.empty((m, bw), device=dev, dtype=torch.float32)
+        if cinp != cin:
+            buf[:, cin:cinp].zero_()
         ar = block.arange(dev)
         check(_lib.lib().sininn_permute_channels(_vp(xd), xs, _vp(buf), bw, m, cin, _vp(ar, dtype=torch.int32),
                                                  ops._stream()))
@@ -200,7 +203,7 @@ class _DenseFn(torch.autograd.Function):
                                               _vp(dh), _vp(dv), cout, ops._stream()))
             dD = padded(dG)
             g_aux1, g_aux2 = dv, dh.view(b, h, w, cout)
-        dF = torch.zeros((m, bw), device=dev, dtype=torch.float32)
+        dF = torch.empty((m, bw), device=dev, dtype=torch.float32)      # fully written by conv5's data gradient below
 
         # weight gradients go to the dedicated side stream (like the GLOW executor's): they only read `buf` and a slice of
         # the gradient buffer that is final by then, so they overlap the data-gradient chain, and every `+=` into a
