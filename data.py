@@ -62,8 +62,16 @@ class FrameStore:
         hr_dir = os.path.join(dataset, 'hr_frames', scene)
         listed = len(os.listdir(lr_dir))
         names = sorted(f for f in os.listdir(lr_dir) if f.startswith('frame_') and f.endswith('.png'))
+        if not names:
+            raise FileNotFoundError(f'no frame_%05d.png files in {lr_dir}')
         count = int(names[-1][6:11]) + 1
+        # the reference opens files by index (io.imread of frame_{x:05d}.png, data.py:33-38) and so fails on the first gap;
+        # a resident store must not paper over one with zero frames either
+        gaps = sorted(set(range(int(names[0][6:11]), count)) - {int(n[6:11]) for n in names})
+        if gaps:
+            raise FileNotFoundError(f'{lr_dir}: LR frame(s) missing: ' + ', '.join(f'frame_{t:05d}.png' for t in gaps[:8]))
         hr, lr = None, None
+        have_hr = np.zeros(count, bool)
         for name in names:
             t = int(name[6:11])
             a = np.asarray(Image.open(os.path.join(lr_dir, name)))
@@ -76,7 +84,20 @@ class FrameStore:
                 if hr is None:
                     hr = np.zeros((count,) + b.shape, np.uint8)
                 hr[t] = b
-        return cls(torch.from_numpy(hr), torch.from_numpy(lr), num_listed=listed)
+                have_hr[t] = True
+        if hr is None:
+            raise FileNotFoundError(f'no HR frames for scene {scene!r} in {hr_dir}')
+        store = cls(torch.from_numpy(hr), torch.from_numpy(lr), num_listed=listed)
+        store.have_hr = have_hr
+        return store
+
+    def require_hr(self, frames):
+        """Raise (like the reference's io.imread, data.py:38) when a dataset would sample an HR frame that was not on disk."""
+        have = getattr(self, 'have_hr', None)
+        if have is not None:
+            missing = [t for t in frames if not have[t]]
+            if missing:
+                raise FileNotFoundError('HR frame(s) missing: ' + ', '.join(f'frame_{t:05d}.png' for t in missing[:8]))
 
 
 def _store_for(opt):
@@ -95,6 +116,7 @@ class VideoDataset(torch.utils.data.Dataset):
         self.store = _store_for(opt)
         self.frames = []
         self.populate_files(self.store.num_lr, opt)
+        self.store.require_hr(self.frames)
 
     def __len__(self):
         return len(self.frames)
@@ -174,7 +196,8 @@ class ConcatDataset(torch.utils.data.Dataset):
 
 class DeviceLoader:
     """Iterates a dataset in batches built on the GPU by the sampler kernel (stands in for torch DataLoader +
-    default_collate + H2D copy).  Under data parallel each rank walks positions rank::world."""
+    default_collate + H2D copy).  Under data parallel each rank walks positions rank::world of the order padded to a
+    multiple of the world size."""
 
     def __init__(self, dataset, batch_size, shuffle=False, device=None):
         self.dataset, self.batch_size, self.shuffle, self.device = dataset, batch_size, shuffle, device
@@ -183,10 +206,12 @@ class DeviceLoader:
         ds = self.dataset.sup if isinstance(self.dataset, ConcatDataset) else self.dataset
         return ds.store
 
+    def _per_rank(self):
+        _, ws = sdist.world()
+        return (len(self.dataset) + ws - 1) // ws
+
     def __len__(self):
-        rank, ws = sdist.world()
-        n = len(range(rank, len(self.dataset), ws))
-        return (n + self.batch_size - 1) // self.batch_size
+        return (self._per_rank() + self.batch_size - 1) // self.batch_size
 
     def __iter__(self):
         store = self._store()
@@ -195,6 +220,12 @@ class DeviceLoader:
             store.to(dev)
         rank, ws = sdist.world()
         order = torch.randperm(len(self.dataset)).tolist() if self.shuffle else list(range(len(self.dataset)))
+        # DistributedSampler semantics (what Lightning DDP gives the reference): pad by wrapping around so that every rank
+        # walks the same number of positions -- same number of batches and the same last-batch size on every rank, hence
+        # the same number of gradient all-reduces (a rank with one batch more would hang in the collective)
+        total = self._per_rank() * ws
+        if order:
+            order = (order * (total // len(order) + 1))[:total]
         order = order[rank::ws]
         for s in range(0, len(order), self.batch_size):
             yield self.dataset.batch(order[s:s + self.batch_size])

@@ -73,10 +73,13 @@ class SingleVideoINN(pl.LightningModule):
         # (sin_inn_amd.modules), so the += into the shared gradient buffers stays ordered.
         main = torch.cuda.current_stream()
         # only networks whose parameter gradients are all accumulated on the dedicated side stream may run two
-        # backward chains at once (the SRF graph does; the Python-orchestrated IRN path accumulates on the calling stream)
+        # backward chains at once (both the SRF graph and the IRN network do)
         concurrent = self.overlap_passes and getattr(self.inn, 'concurrent_passes_safe', False)
         second = _second_stream(hr.device) if concurrent else main
         if second is not main:
+            # every packed-weight buffer must be complete on `main` before the fork: a cache miss inside one chain would
+            # pack on that chain's stream while the other chain reads the same buffers (unsynchronised read)
+            self.inn.prepare_packs()
             ready = torch.cuda.Event()
             ready.record(main)                       # inputs produced, gradients zeroed
             second.wait_event(ready)

@@ -10,13 +10,14 @@ all-reduce per step.
 import argparse
 import logging
 import os
+import re
 
 import torch
 
 from data import (ConcatDataset, FrameStore, LitTrainLoader, VideoAllDataset, VideoTrainDataset, VideoValDataset,
                   get_loader)
 from lit_wrapper import SingleVideoINN
-from sin_inn_amd.lightning import ModelCheckpoint, Trainer, WandbLogger
+from sin_inn_amd.lightning import ModelCheckpoint, Trainer, WandbLogger, load_checkpoint
 
 # (flags, kwargs) -- one row per option of the reference CLI
 _OPTIONS = [
@@ -51,6 +52,7 @@ _OPTIONS = [
     (('-t', '--temp',), dict(type=float, default=0.8, help='latent sampling temperature at test time')),
     (('--lr_dims',), dict(type=int, default=-1, help='internal: LR channels')),
     (('--z_dims',), dict(type=int, default=-1, help='internal: latent channels')),
+    (('--allow_partial_load',), dict(action='store_true', help='test: load a checkpoint whose keys do not all match')),
     (('--synthetic',), dict(type=int, nargs=3, default=None, metavar=('T', 'H', 'W'),
                             help='use a synthetic uint8 clip of T frames of HxW instead of --dataset')),
 ]
@@ -75,6 +77,29 @@ def get_args(argv=None):
         t, h, w = args.synthetic
         args.frame_store = FrameStore.synthetic(t, h, w)
     return args
+
+
+# state-dict entries that differ between FrEIA versions without changing the function: the fixed permutations (derived
+# from the seed, archs.py:65-68) and bookkeeping tensors some versions register (github.com/VLL-HD/FrEIA/issues/10, the
+# mismatch the reference asks about interactively at main.py:128-136)
+_FREIA_BOOKKEEPING = re.compile(r'\.(perm|perm_inv|w_perm|w_perm_inv|last_jac|tmp_var\d*)$')
+
+
+def load_weights(model, state_dict, allow_partial=False):
+    """Strict load; a mismatch is tolerated only when every offending key is FrEIA bookkeeping (or --allow_partial_load
+    is given).  The reference stops and asks (main.py:128-136); a batch job cannot, so anything else exits non-zero
+    instead of silently running inference with random weights."""
+    try:
+        model.load_state_dict(state_dict)
+        return
+    except RuntimeError as e:
+        logging.warning(str(e))
+    res = model.load_state_dict(state_dict, strict=False)
+    odd = [k for k in list(res.missing_keys) + list(res.unexpected_keys) if not _FREIA_BOOKKEEPING.search(k)]
+    if odd and not allow_partial:
+        logging.error(f'checkpoint does not match the model ({len(odd)} keys, e.g. {odd[:4]}); '
+                      'pass --allow_partial_load to load what matches anyway')
+        raise SystemExit(1)
 
 
 def main(argv=None):
@@ -102,11 +127,8 @@ def main(argv=None):
         os.makedirs(exp_dir, exist_ok=True)
         video_path = os.path.join(exp_dir, f'{args.architecture}_{args.suffix}_t{args.temp}.avi')
         device = torch.device('cuda', args.gpu_ids[0])
-        checkpoint = torch.load(args.resume_state, map_location=device)
-        missing = model.load_state_dict(checkpoint['state_dict'], strict=False)
-        if missing.missing_keys or missing.unexpected_keys:
-            # the reference asks interactively whether this is the known FrEIA key mismatch (main.py:128-136)
-            logging.warning(f'state_dict mismatch: missing={missing.missing_keys} unexpected={missing.unexpected_keys}')
+        checkpoint = load_checkpoint(args.resume_state, map_location=device)
+        load_weights(model, checkpoint['state_dict'], args.allow_partial_load)
         model.to(device)
         model.infer(get_loader(unsup_data, 40), args, save_video=video_path)
     return model

@@ -2,8 +2,9 @@
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
 
 Pinning:
-  * occlusion_wang / get_corresponding_map / CensusLoss are checked against fixtures produced by the reference's OWN code
-    (tests/golden/make_golden_flow.py imports video-interpolation/my_utils/{occlusions,loss}.py; golden_flow.npz).
+  * occlusion_wang / get_corresponding_map / occlusion_brox / CensusLoss / L1Loss / SSIMLoss / BilateralSmooth are checked
+    against fixtures produced by the reference's OWN code (tests/golden/make_golden_flow.py imports
+    video-interpolation/my_utils/{occlusions,loss}.py; golden_flow.npz).
   * softsplat: the reference implementation is three CUDA kernels compiled through cupy (absent here), so it cannot run in
     the build container: **parity unpinned** for softsplat -- restated from the kernel text
     (video-interpolation/my_utils/softsplat.py:8-177) and anchored by properties: the gradients of this restatement come
@@ -142,8 +143,9 @@ def ssim_loss(x, y, mask, weight, md=1):
 
 
 def occlusion_brox(orig_fw, orig_bw, thresh=None):
-    """occlusions.py:111-118; the warp is Resample2d restated in oracle/sininn_oracle.py::flow_warp (its CUDA extension is
-    absent, so this function is parity-unpinned like that restatement)."""
+    """occlusions.py:111-118; the warp is Resample2d restated in oracle/sininn_oracle.py::flow_warp.  Both are pinned by
+    fixture F6 (the live Resample2d class is pure torch and runs on CPU; only the dead Resample2d_old needs the CUDA
+    extension)."""
     from oracle import sininn_oracle as O
     warped_bw = O.flow_warp(orig_bw, orig_fw)
     sq_sum = ((orig_fw + warped_bw) ** 2).sum(1)

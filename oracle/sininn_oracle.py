@@ -8,15 +8,17 @@ Parity status (see DESIGN.md "Oracle"):
   * pinned against the reference's own importable code through the committed fixtures in
     ``tests/golden/`` (made by ``tests/golden/make_golden.py``): conv subnets
     (archs.py:11-17), HaarDownsampling / DenseBlock / InvBlockExp / InvRescaleNet
-    (archs.py:74-233), loss.reconstruction / loss.latent_nll (loss.py:3-5,38-39) and the
-    legacy numpy permutation stream used by FrEIA's PermuteRandom.
+    (archs.py:74-233), loss.reconstruction / loss.latent_nll (loss.py:3-5,38-39), loss.mmd
+    (loss.py:9-36, fixture G7: the reference function itself run on CPU with its three
+    `.to('cuda')` calls made no-ops by the fixture script), the legacy numpy permutation stream
+    used by FrEIA's PermuteRandom, and -- through tests/golden/make_golden_flow.py, fixture F6 --
+    flow_warp / photometric_l1 (= Resample2d.forward, video-interpolation/my_utils/
+    resample2d.py:52-72, + the trainer's metric, trainer.py:61-62), values and gradients.
   * PARITY UNPINNED (third-party arithmetic that is not under /root/reference and is not
     installed here): FrEIA (un-pinned version, pre-0.2 API; call sites archs.py:26-71) and
     kornia==0.4.1 (requirements.txt:1; call sites tcr.py:35,43).  Their published algorithms are
     restated below and checked by known-answer tests only
-    (round trip, log-det vs autograd Jacobian, identity warps).  loss.mmd (loss.py:9-36) cannot
-    run on CPU in the reference (hard-coded 'cuda'); it is restated and pinned by a hand
-    computed case.
+    (round trip, log-det vs autograd Jacobian, identity warps).
 
 All reference citations are file:line into /root/reference.
 """

@@ -178,6 +178,18 @@ class ReversibleGraphNet(nn.Module):
                 pixel_major = True
         return cur.permute(0, 3, 1, 2) if pixel_major else cur
 
+    def prepare_packs(self):
+        """Build (or refresh) every packed-weight buffer of the graph on the CURRENT stream.  Packs are otherwise built
+        lazily by the first pass that misses the cache, on that pass's stream; with the forward and the reverse chain on
+        two streams the other chain would then read half-written packs.  lit_wrapper.training_step calls this on the main
+        stream before it forks the second one (cache hits cost nothing)."""
+        from .modules import _subnet_args
+        for m in self.module_list:
+            if isinstance(m, GLOWCouplingBlock):
+                dev = m.s1[0].weight.device
+                _subnet_args(m, m.s1, m.split_len2, dev, True, False)
+                _subnet_args(m, m.s2, m.split_len1, dev, True, False)
+
     @property
     def concurrent_passes_safe(self):
         """True when two passes (forward + backward each) may run on two streams at once: every parameter gradient of

@@ -344,6 +344,15 @@ class InvRescaleNet(nn.Module):
                 operations.append(InvBlockExp(current, min(channel_out, current // 2)))
         self.operations = nn.ModuleList(operations)
 
+    def prepare_packs(self):
+        """Build every DenseBlock's packed weights on the CURRENT stream (they are keyed on the optimiser epoch, i.e.
+        rebuilt once per step): called on the main stream before the two pass chains fork, see
+        ReversibleGraphNet.prepare_packs."""
+        for op in self.operations:
+            if isinstance(op, InvBlockExp):
+                for blk in (op.F, op.G, op.H):
+                    blk._packs.get(blk)
+
     @property
     def concurrent_passes_safe(self):
         """Two pass chains may run on two streams at once: all parameter gradients accumulate on the side stream."""

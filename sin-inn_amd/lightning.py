@@ -124,6 +124,34 @@ def _to_device(batch, device):
     return batch
 
 
+_DROP = object()
+
+
+def _plain(v):
+    """Hyper-parameters as they go into a checkpoint: numbers / strings / None and lists / dicts of those.  Anything else
+    (the decoded clip ``opt.frame_store``, modules, tensors) is dropped: a checkpoint holds tensors and primitives only,
+    so it loads under torch.load's default ``weights_only=True`` and does not carry the video."""
+    if isinstance(v, (bool, int, float, str, type(None))):
+        return v
+    if isinstance(v, (list, tuple)):
+        items = [_plain(x) for x in v]
+        return _DROP if any(x is _DROP for x in items) else items
+    if isinstance(v, dict):
+        return {str(k): x for k, x in ((k, _plain(x)) for k, x in v.items()) if x is not _DROP}
+    return _DROP
+
+
+def load_checkpoint(path, map_location=None):
+    """torch.load for checkpoints of this trainer (tensors + primitives: loads with weights_only=True) and for
+    Lightning checkpoints written by the reference (they pickle an argparse.Namespace under 'hyper_parameters',
+    main.py:127): those need the full unpickler, which is what the reference itself uses."""
+    import pickle
+    try:
+        return torch.load(path, map_location=map_location, weights_only=True)
+    except pickle.UnpicklingError:
+        return torch.load(path, map_location=map_location, weights_only=False)
+
+
 class Trainer:
     def __init__(self, gpus=None, max_epochs=1000, check_val_every_n_epoch=1, default_root_dir='.', logger=None,
                  resume_from_checkpoint=None, callbacks=(), auto_lr_find=False, auto_scale_batch_size=False,
@@ -149,7 +177,8 @@ class Trainer:
         if rank != 0:
             return
         os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
-        hp = {k: (vars(v) if hasattr(v, '__dict__') else v) for k, v in model.hparams.items()}
+        hp = {k: (_plain(vars(v)) if hasattr(v, '__dict__') else _plain(v)) for k, v in model.hparams.items()}
+        hp = {k: v for k, v in hp.items() if v is not _DROP}
         torch.save({'state_dict': model.state_dict(), 'epoch': self.current_epoch, 'global_step': self.global_step,
                     'optimizer_states': [self.optimizer.state_dict()], 'hyper_parameters': hp}, path)
 
@@ -159,7 +188,7 @@ class Trainer:
         model.trainer = self
         self.optimizer = _OptimizerProxy(model.configure_optimizers())
         if self.resume:
-            ck = torch.load(self.resume, map_location=device)
+            ck = load_checkpoint(self.resume, map_location=device)
             model.load_state_dict(ck['state_dict'])
             if ck.get('optimizer_states'):
                 self.optimizer.load_state_dict(ck['optimizer_states'][0])

@@ -204,8 +204,11 @@ def _subnet_args(block, seq, co, dev, need_grad, with_grads):
     cmap = ops.coupling_colmap(co, dev)
     wino = USE_WINOGRAD[0] and k == 3
     wino_w2 = wino                                  # conv2 forward: (s|t) interleave of either width
-    w1, b1, wd1 = block._packs.get(conv1, None, need_grad, wino, wino)
-    w2, b2, wd2 = block._packs.get(conv2, cmap, need_grad, wino_w2, wino)
+    # The data-gradient packs are built whenever the conv is trainable, not only when this call needs them: the cache key
+    # then does not flip between no_grad (validation) and training passes, so an entry is never REPLACED mid-training --
+    # a replacement would be packed lazily on whichever stream first misses (see ReversibleGraphNet.prepare_packs).
+    w1, b1, wd1 = block._packs.get(conv1, None, need_grad or conv1.weight.requires_grad, wino, wino)
+    w2, b2, wd2 = block._packs.get(conv2, cmap, need_grad or conv2.weight.requires_grad, wino_w2, wino)
     a = SubnetArgs(w1=_pv(w1), b1=_pv(b1), w2=_pv(w2), b2=_pv(b2), w1_dgrad=_pv(wd1), w2_dgrad=_pv(wd2),
                    winograd=(1 if wino else 0) | (2 if wino_w2 else 0) | (12 if wino else 0))
     if with_grads:

@@ -89,6 +89,32 @@ def main():
             np.random.seed(k)
             out[f'g6_perm_{c}_{k}'] = np.random.permutation(c)
 
+    # G7 loss.mmd (loss.py:9-36), forward and reverse kernel sets, values + gradients.  The function hard-codes
+    # `.to('cuda')` for three zero buffers (loss.py:27-29); for the duration of the call Tensor.to is
+    # wrapped so that a 'cuda' target is a no-op -- the arithmetic that runs is the reference's own, on CPU.
+    real_to = torch.Tensor.to
+
+    def cpu_to(self, *a, **k):
+        if a and isinstance(a[0], str) and a[0].startswith('cuda'):
+            return self
+        return real_to(self, *a, **k)
+
+    torch.Tensor.to = cpu_to
+    try:
+        for tag, shape, spread in (('a', (4, 3, 5, 6), 0.35), ('b', (6, 8, 4, 4), 0.15)):
+            x = (torch.randn(*shape, generator=g) * spread).requires_grad_(True)
+            y = (torch.randn(*shape, generator=g) * spread).requires_grad_(True)
+            out.update({f'g7_{tag}_x': x.detach().clone(), f'g7_{tag}_y': y.detach().clone()})
+            for rev in (False, True):
+                x.grad = y.grad = None
+                val = loss.mmd(x, y, rev=rev)
+                val.backward()
+                r = 'rev' if rev else 'fwd'
+                out.update({f'g7_{tag}_{r}': val.detach().clone(), f'g7_{tag}_{r}_gx': x.grad.clone(),
+                            f'g7_{tag}_{r}_gy': y.grad.clone()})
+    finally:
+        torch.Tensor.to = real_to
+
     np.savez_compressed(os.path.join(HERE, 'golden_reference.npz'), **t2n(out))
     print('wrote', os.path.join(HERE, 'golden_reference.npz'),
           os.path.getsize(os.path.join(HERE, 'golden_reference.npz')), 'bytes')

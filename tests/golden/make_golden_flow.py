@@ -3,8 +3,8 @@
 Run once in the build container (needs /root/reference; never runs on the GPU box):
     python tests/golden/make_golden_flow.py
 Imports video-interpolation/my_utils/occlusions.py and my_utils/loss.py unmodified (pure torch; occlusions.py's
-`Resample2d` import resolves because resample2d.py only references its absent CUDA extension at call time, and it is
-not called here).  softsplat.py needs cupy and is NOT imported (its oracle is pinned by properties instead).
+`Resample2d` import resolves because resample2d.py only references its absent CUDA extension inside the dead
+`Resample2d_old` class; the live `Resample2d` is grid_sample and runs on CPU: fixture F6).  softsplat.py needs cupy and is NOT imported (its oracle is pinned by properties instead).
 Outputs are data only: inputs and expected outputs.
 """
 import os, sys
@@ -66,6 +66,28 @@ def main():
             loss = ref_loss.BilateralSmooth(0.1, fun, k, order)(img, flow)
             loss.backward()
             out.update({f'f4_{fun}_{order}_loss': loss.detach(), f'f4_{fun}_{order}_gflow': flow.grad.clone()})
+    # F6 Resample2d.forward (resample2d.py:52-72, pure torch: runs on CPU) + the trainer's photometric metric
+    # (trainer.py:61-62) with gradients w.r.t. image and flow, and occlusion_brox (occlusions.py:111-118) built on it.
+    # Flows include sub-pixel, multi-pixel and out-of-image displacements (zeros padding + the (W-1,H-1) / align_corners
+    # =False half-pixel quirk, SURVEY C-18).
+    resample = ref_occ.Resample2d()
+    img = torch.rand(2, 3, 13, 18, generator=g).requires_grad_(True)
+    tgt = torch.rand(2, 3, 13, 18, generator=g)
+    flow = (torch.randn(2, 2, 13, 18, generator=g) * 2.0)
+    flow[1, :, :3] *= 5                                      # some taps far outside the image
+    flow = flow.requires_grad_(True)
+    warped = resample(img, flow)
+    metric = torch.nn.functional.l1_loss(tgt, warped, reduction='none').mean(1, True)
+    gw = torch.randn(2, 3, 13, 18, generator=g)
+    gm = torch.randn(2, 1, 13, 18, generator=g)
+    ((warped * gw).sum() + (metric * gm).sum()).backward()
+    out.update(f6_img=img.detach(), f6_tgt=tgt, f6_flow=flow.detach(), f6_warped=warped.detach(),
+               f6_metric=metric.detach(), f6_gw=gw, f6_gm=gm, f6_gimg=img.grad.clone(), f6_gflow=flow.grad.clone())
+    zero = resample(img.detach(), torch.zeros(2, 2, 13, 18))  # quirk C-18: zero flow is NOT the identity
+    out.update(f6_zero_flow_warped=zero)
+    fw = torch.randn(2, 2, 13, 18, generator=g) * 1.5
+    bw = -fw + 0.6 * torch.randn(2, 2, 13, 18, generator=g)
+    out.update(f6_fw=fw, f6_bw=bw, f6_brox=ref_occ.occlusion_brox(fw, bw, 0.5).to(torch.uint8))
     np.savez_compressed(os.path.join(HERE, 'golden_flow.npz'),
                         **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in out.items()})
     print('wrote golden_flow.npz with', len(out), 'arrays')

@@ -171,3 +171,32 @@ def test_occlusion_brox_matches_oracle():
     margin = (((fw + wb) ** 2).sum(1) - 0.01 * (fw ** 2 + wb ** 2).sum(1) - 0.5).abs().unsqueeze(1)
     assert not bool(((got.cpu() != want) & (margin > 1e-4)).any())
     assert 0.02 < float(want.float().mean()) < 0.98
+
+
+def test_flow_warp_l1_matches_reference_fixture(gold):
+    """F6: the fused flow-warp + photometric-L1 kernel against Resample2d.forward + l1_loss(...).mean(1, True) as the
+    reference's own code evaluates them, values and gradients (taps outside the image, the C-18 half-pixel quirk)."""
+    from sin_inn_amd.functional import flow_warp_l1
+    img = gold['f6_img'].cuda().requires_grad_(True)
+    flow = gold['f6_flow'].cuda().requires_grad_(True)
+    warped, metric = flow_warp_l1(img, flow, gold['f6_tgt'].cuda())
+    assert relerr(warped, gold['f6_warped']) < RTOL and relerr(metric, gold['f6_metric']) < RTOL
+    ((warped * gold['f6_gw'].cuda()).sum() + (metric * gold['f6_gm'].cuda()).sum()).backward()
+    assert relerr(img.grad, gold['f6_gimg']) < RTOL
+    # d/dflow multiplies differences of neighbouring pixels by (W/(W-1), H/(H-1)) and the L1 sign: fp32 re-association
+    # of the 4-tap sum flips no signs here, but leaves ~1e-4 of the max-norm
+    assert relerr(flow.grad, gold['f6_gflow']) < 3e-4
+    zero, _ = flow_warp_l1(gold['f6_img'].cuda(), torch.zeros_like(gold['f6_flow']).cuda())
+    assert relerr(zero, gold['f6_zero_flow_warped']) < RTOL
+
+
+def test_occlusion_brox_matches_reference_fixture(gold):
+    from sin_inn_amd.flowloss import occlusion_brox
+    from oracle import sininn_oracle as O
+    fw, bw = gold['f6_fw'], gold['f6_bw']
+    got = occlusion_brox(fw.cuda(), bw.cuda(), 0.5).cpu()
+    want = gold['f6_brox'].bool()
+    wb = O.flow_warp(bw, fw)
+    margin = (((fw + wb) ** 2).sum(1) - 0.01 * (fw ** 2 + wb ** 2).sum(1) - 0.5).abs().unsqueeze(1)
+    assert not bool(((got != want) & (margin > 1e-4)).any())     # a threshold on float sums: ties within rounding only
+    assert float((got == want).float().mean()) > 0.995

@@ -207,6 +207,24 @@ def test_mmd(env, rev):
     assert relerr(xg.grad, xc.grad) < 1e-3 and relerr(yg.grad, yc.grad) < 1e-3
 
 
+@pytest.mark.parametrize('tag', ['a', 'b'])
+@pytest.mark.parametrize('rev', [False, True])
+def test_mmd_matches_reference_fixture(env, golden, tag, rev):
+    """HIP loss.mmd against fixture G7 = the reference's own loss.mmd (loss.py:9-36) evaluated on CPU."""
+    import loss
+    r = 'rev' if rev else 'fwd'
+    x = torch.from_numpy(golden[f'g7_{tag}_x']).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = torch.from_numpy(golden[f'g7_{tag}_y']).cuda().requires_grad_(True)
+    val = loss.mmd(x, y, rev=rev)
+    val.backward()
+    want = float(golden[f'g7_{tag}_{r}'])
+    assert abs(float(val) - want) <= 1e-5 * max(1.0, abs(want))
+    # gradient tolerance: the b x b distance matrix is a difference of Gram entries (r_i + r_j - 2 g_ij) whose fp32
+    # cancellation error is amplified by d/dd (C+d)^-a for small d; 1e-3 of the max-norm (stated in DESIGN 4)
+    assert relerr(x.grad, torch.from_numpy(golden[f'g7_{tag}_{r}_gx'])) < 1e-3
+    assert relerr(y.grad, torch.from_numpy(golden[f'g7_{tag}_{r}_gy'])) < 1e-3
+
+
 def test_tcr_affine_warp(env):
     S, O, dev = env
     from tcr import TCR

@@ -83,3 +83,28 @@ def test_bilateral_smooth_matches_reference(gold, fun, k, order):
     assert abs(float(loss) / float(gold[f'f4_{fun}_{order}_loss']) - 1) < 1e-5
     want = gold[f'f4_{fun}_{order}_gflow']
     assert float((flow.grad - want).abs().max() / want.abs().max()) < 1e-4
+
+
+def test_resample2d_and_metric_match_reference(gold):
+    """F6: the oracle's flow_warp / photometric_l1 against Resample2d.forward + the trainer's metric as the reference's own
+    code evaluates them (resample2d.py:52-72, trainer.py:61-62), values and both gradients."""
+    from oracle import sininn_oracle as O
+    img = gold['f6_img'].clone().requires_grad_(True)
+    flow = gold['f6_flow'].clone().requires_grad_(True)
+    warped = O.flow_warp(img, flow)
+    metric = O.photometric_l1(gold['f6_tgt'], warped)
+    assert torch.allclose(warped, gold['f6_warped'], rtol=1e-6, atol=1e-6)
+    assert torch.allclose(metric, gold['f6_metric'], rtol=1e-6, atol=1e-6)
+    ((warped * gold['f6_gw']).sum() + (metric * gold['f6_gm']).sum()).backward()
+    assert torch.allclose(img.grad, gold['f6_gimg'], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(flow.grad, gold['f6_gflow'], rtol=1e-5, atol=1e-5)
+    zero = O.flow_warp(gold['f6_img'], torch.zeros_like(gold['f6_flow']))
+    assert torch.allclose(zero, gold['f6_zero_flow_warped'], rtol=1e-6, atol=1e-6)
+    assert not torch.allclose(zero, gold['f6_img'], atol=1e-3)           # quirk C-18 is in the fixture
+
+
+def test_occlusion_brox_matches_reference(gold):
+    want = gold['f6_brox'].bool()
+    got = FO.occlusion_brox(gold['f6_fw'], gold['f6_bw'], 0.5)
+    assert got.shape == want.shape and torch.equal(got, want)
+    assert 0.02 < float(want.float().mean()) < 0.98

@@ -118,6 +118,22 @@ def test_mmd_hand_case():
     assert math.isclose(float(O.mmd(x, y)), want, rel_tol=1e-5)
 
 
+@pytest.mark.parametrize('tag', ['a', 'b'])
+@pytest.mark.parametrize('rev', [False, True])
+def test_g7_mmd_matches_reference(golden, tag, rev):
+    """loss.mmd as the reference itself computes it (loss.py:9-36 run on CPU by make_golden.py), both kernel sets."""
+    r = 'rev' if rev else 'fwd'
+    x = torch.from_numpy(golden[f'g7_{tag}_x']).requires_grad_(True)
+    y = torch.from_numpy(golden[f'g7_{tag}_y']).requires_grad_(True)
+    val = O.mmd(x, y, rev=rev)
+    val.backward()
+    want = float(golden[f'g7_{tag}_{r}'])
+    assert abs(float(val) - want) <= 1e-6 * max(1.0, abs(want))
+    for got, key in ((x.grad, 'gx'), (y.grad, 'gy')):
+        w = torch.from_numpy(golden[f'g7_{tag}_{r}_{key}'])
+        assert float((got - w).abs().max() / w.abs().max()) < 1e-5
+
+
 def test_tcr_identity_and_translation():
     img = torch.rand(1, 2, 8, 8)
     rand = torch.tensor([[0.5, 0.5, 0.5]])               # zero angle, zero shift
