@@ -110,6 +110,49 @@ def cpu_baseline(args, opt, seconds_budget=30.0):
                       f'{args.size}x{args.size}, -c {args.num_coupling}, fp32'}
 
 
+def self_launch(n):
+    """Run this script under torch.distributed.run with n ranks (one per GPU) and relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:                 # rank 0 prints exactly one JSON line on stdout; stderr passes through
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+def rehearse(args, rank, ws):
+    """The distributed skeleton of the benchmark without the GPU work (runs on the CPU-only build container)."""
+    from sin_inn_amd import dist as sdist
+    flat = torch.full((1 << 16,), float(rank + 1))
+    if ws > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sdist.allreduce_sum_([flat])
+        flat.mul_(1.0 / ws)
+    if ws > 1:
+        torch.distributed.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if ws > 1:
+        torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
+    assert abs(float(flat[0]) - (ws + 1) / 2.0) < 1e-5
+    if rank == 0:
+        print(json.dumps({'metric': 'training frames/sec at 256x256 bs=16', 'value': None, 'unit': 'frames/s', 'n_gpus': ws,
+                          'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': float(dt) / args.steps * 1e3,
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+                          'data': 'synthetic', 'rehearsal': True,
+                          'config': {'workload': 'REHEARSAL of the multi-rank plumbing on CPU (gloo): no kernels run',
+                                     'global_batch': ws * args.batch, 'parallelism': f'dp{ws}'}}))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -124,13 +167,22 @@ def main():
     ap.add_argument('--cpu-batch', type=int, default=2)
     ap.add_argument('--conv-cfg', type=int, default=0, help='diagnostic (sininn_conv_test_hooks force_cfg): 1 / 2 pin 32- / 64-column Winograd blocks')
     ap.add_argument('--wgrad16', type=int, default=0, help='diagnostic (sininn_wgrad_test_hooks): bit0 16x16x4 tiles, bit1 no Winograd wgrad, bit2 8-row tiles, bit3 8-wave k-split blocks')
+    ap.add_argument('--rehearse', action='store_true', help='CPU rehearsal of the multi-rank plumbing (gloo): rendezvous, '
+                    'flat-gradient all-reduce, barrier + max-over-ranks timing, rank-0 JSON line; no kernels run, value is null')
     ap.add_argument('--no-overlap', action='store_true', help='diagnostic: single stream (no pass / wgrad overlap)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing in this process has touched the GPU yet (torch
+        # is imported, no device call), and the ranks are fresh child processes -- never an exec of a GPU-initialised one.
+        sys.exit(self_launch(args.gpus))
+
     import sin_inn_amd
     from sin_inn_amd import dist as sdist
-    rank, ws = sdist.init_from_env()
+    rank, ws = sdist.init_from_env('gloo' if args.rehearse else None)
     assert ws == args.gpus or (ws == 1 and args.gpus == 1), f'--gpus {args.gpus} but WORLD_SIZE={ws}'
+    if args.rehearse:
+        return rehearse(args, rank, ws)
     local = sdist.local_device_index()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)

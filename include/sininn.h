@@ -294,6 +294,15 @@ int sininn_bayer_bin(const uint8_t* hr, uint8_t* lr, int T, int H, int W, int sc
 int sininn_bayer_demosaic(const uint8_t* hr, uint8_t* rgb, int T, int H, int W, int scale, int reduce_sum, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Output pixels of the inference path (SingleVideoINN.infer, lit_wrapper.py:91-128): float frames `in` (logical
+ * (B,C,H,W), element strides) -> uint8 images out[B][H][W][C] on the device, so only bytes cross PCIe.
+ *   wrap == 0: clamp(x,0,1)*255 truncated;  wrap != 0: (uint8)(int)(x*255) = torchvision ToPILImage's
+ *   pic.mul(255).byte() with its wrap-around on out-of-range values (what the reference does, lit_wrapper.py:94,120).
+ * ---------------------------------------------------------------------------------------------- */
+int sininn_frames_to_u8(const float* in, const int64_t in_strides[4], uint8_t* out, int B, int C, int H, int W, int wrap,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Adam exactly as torch.optim.Adam (lit_wrapper.py:131-138: L2 weight decay, not AdamW):
  *   g = grad*grad_scale + wd*p ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
  *   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)

@@ -5,16 +5,22 @@ Same method names and step structure as the reference: forward pass HR -> (LR | 
 latent terms, backward; reverse pass (LR | z) -> HR with reconstruction + MMD, backward; optional TCR iterations;
 one optimizer step.  Differences, all deliberate: device-agnostic construction (no hard-coded 'cuda' strings),
 ``tcr_iters`` is cast to int (the reference feeds a float to range(), main.py:63 / lit_wrapper.py:63), latents are
-drawn directly in the pixel-major layout the kernels use, and Adam is the fused single-launch HIP optimizer.
+drawn directly in the pixel-major layout the kernels use, Adam is the fused single-launch HIP optimizer, and ``infer``
+clamps frames to [0,1] before the uint8 conversion (the reference's ToPILImage wraps out-of-range values around;
+``opt.pixel_mode='wrap'`` restores that bit for bit).
 """
 import logging
 import os
+import queue
+import shutil
 import subprocess as sp
+import threading
 
 import torch
 
 import sin_inn_amd.lightning as pl
 from sin_inn_amd import FusedAdam
+from sin_inn_amd.functional import frames_to_u8
 
 import loss
 from archs import InvRescaleNet, UncondSRFlow
@@ -42,6 +48,70 @@ def _latent(b, z_dims, h, w, device, temp=1.0):
 def _cat_channels(a, b):
     """torch.cat on dim 1 that keeps the pixel-major layout."""
     return torch.cat((a.permute(0, 2, 3, 1), b.permute(0, 2, 3, 1)), dim=3).permute(0, 3, 1, 2)
+
+
+class _FrameWriter:
+    """Writer side of SingleVideoINN.infer: PNG-encodes uint8 frames on a worker thread and writes them to
+    ``save_images/out_{batch:04d}_{i:02d}.png`` or to the stdin of an ffmpeg process (reference lit_wrapper.py:96-103,117-124).
+    The device -> host copies land in a ring of pinned buffers; the GPU never waits for the encoder unless all buffers are
+    still being written out."""
+    RING = 3
+
+    def __init__(self, save_images=None, save_video=None):
+        self.save_images, self.video = save_images, None
+        if save_images:
+            os.makedirs(save_images, exist_ok=True)
+        elif save_video:
+            if shutil.which('ffmpeg') is None:
+                raise FileNotFoundError('ffmpeg is not on PATH (needed for save_video); use save_images instead')
+            self.video = sp.Popen(['ffmpeg', '-framerate', '30', '-i', '-', '-c:v', 'libx264', '-preset', 'veryslow',
+                                   '-crf', '18', '-y', save_video], stdin=sp.PIPE, stderr=sp.DEVNULL)
+        self.free, self.work = queue.Queue(), queue.Queue()
+        for _ in range(self.RING):
+            self.free.put(None)                     # pinned buffers are allocated on first use (batch shape unknown yet)
+        self.error = None
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def submit(self, batch_index, frames_u8):
+        """frames_u8: (n,H,W,C) uint8 on the device.  Returns as soon as the copy is queued."""
+        if self.error is not None:
+            raise self.error
+        buf = self.free.get()
+        if buf is None or buf.shape != frames_u8.shape:
+            buf = torch.empty(frames_u8.shape, dtype=torch.uint8, pin_memory=True)
+        buf.copy_(frames_u8, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        self.work.put((batch_index, buf, done, frames_u8))      # frames_u8 kept alive until the copy has finished
+
+    def _run(self):
+        from PIL import Image
+        while True:
+            item = self.work.get()
+            if item is None:
+                return
+            bb, buf, done, _keep = item
+            try:
+                done.synchronize()
+                for i, frame in enumerate(buf.numpy()):
+                    im = Image.fromarray(frame)
+                    if self.save_images:
+                        im.save(os.path.join(self.save_images, f'out_{bb:04d}_{i:02d}.png'))
+                    else:
+                        im.save(self.video.stdin, 'PNG')
+            except Exception as e:              # surfaced on the next submit() / close()
+                self.error = e
+            self.free.put(buf)
+
+    def close(self):
+        self.work.put(None)
+        self.thread.join()
+        if self.video is not None:
+            self.video.stdin.close()
+            self.video.communicate()
+        if self.error is not None:
+            raise self.error
 
 
 class SingleVideoINN(pl.LightningModule):
@@ -133,37 +203,36 @@ class SingleVideoINN(pl.LightningModule):
 
     # ---- inference -------------------------------------------------------------------------------
     def infer(self, loader, opt, save_images=None, save_video=None):
-        """Reverse pass over every LR window; frames go to PNG files or are piped to ffmpeg (reference :91-128)."""
-        from PIL import Image
+        """Reverse pass over every LR window; frames go to PNG files or are piped to ffmpeg (reference :91-128).
+
+        Pipeline: inverse pass (no autograd) -> on-device float->uint8 (sininn_frames_to_u8) -> asynchronous copy of the
+        BYTES into one of three pinned host buffers -> a writer thread encodes PNGs and feeds the files / the ffmpeg pipe
+        while the GPU already runs the next batch.  Pixel conversion: ``opt.pixel_mode`` 'clamp' (default: clamp to
+        [0,1], then *255) or 'wrap' (the reference's ToPILImage = mul(255).byte(), which wraps out-of-range values
+        around, lit_wrapper.py:94,120 -- kept selectable for bit-compatibility, not the default because it turns a
+        slightly over-exposed pixel into a black one)."""
         self.inn.eval()
         device = self.device if self.device.type == 'cuda' else torch.device('cuda', opt.gpu_ids[0])
         self.inn.to(device)
-        video = None
-        if save_video:
-            video = sp.Popen(['ffmpeg', '-framerate', '30', '-i', '-', '-c:v', 'libx264', '-preset', 'veryslow',
-                              '-crf', '18', '-y', save_video], stdin=sp.PIPE, stderr=sp.DEVNULL)
-        if save_images:
-            os.makedirs(save_images, exist_ok=True)
+        wrap = getattr(opt, 'pixel_mode', 'clamp') == 'wrap'
+        writer = None
+        if save_video or save_images:
+            writer = _FrameWriter(save_images, save_video)
         outputs = []
-        for bb, batch in enumerate(loader):
-            lr = batch['lr'].to(device)
-            b, _, h, w = lr.shape
-            lr_z = _cat_channels(lr, _latent(b, opt.z_dims, h, w, device, temp=opt.temp))
-            with torch.no_grad():
-                hr_hat = self.inn(lr_z, rev=True)
-            if save_images or video is not None:
-                frames = (hr_hat.permute(0, 2, 3, 1).clamp(0, 1) * 255).to(torch.uint8).cpu().numpy()
-                for i, frame in enumerate(frames):
-                    im = Image.fromarray(frame)
-                    if save_images:
-                        im.save(os.path.join(save_images, f'out_{bb:04d}_{i:02d}.png'))
-                    else:
-                        im.save(video.stdin, 'PNG')
-            else:
-                outputs.append(hr_hat)
-        if video is not None:
-            video.stdin.close()
-            video.communicate()
+        try:
+            for bb, batch in enumerate(loader):
+                lr = batch['lr'].to(device)
+                b, _, h, w = lr.shape
+                lr_z = _cat_channels(lr, _latent(b, opt.z_dims, h, w, device, temp=opt.temp))
+                with torch.no_grad():
+                    hr_hat = self.inn(lr_z, rev=True)
+                if writer is not None:
+                    writer.submit(bb, frames_to_u8(hr_hat, wrap=wrap))
+                else:
+                    outputs.append(hr_hat)
+        finally:
+            if writer is not None:
+                writer.close()
         return outputs
 
     def configure_optimizers(self):

@@ -52,6 +52,9 @@ _OPTIONS = [
     (('-t', '--temp',), dict(type=float, default=0.8, help='latent sampling temperature at test time')),
     (('--lr_dims',), dict(type=int, default=-1, help='internal: LR channels')),
     (('--z_dims',), dict(type=int, default=-1, help='internal: latent channels')),
+    (('--pixel_mode',), dict(choices=['clamp', 'wrap'], default='clamp',
+                             help='test: float->uint8 conversion; wrap = the reference ToPILImage wrap-around')),
+    (('--save_images',), dict(default=None, help='test: write PNG frames to this directory instead of the ffmpeg pipe')),
     (('--allow_partial_load',), dict(action='store_true', help='test: load a checkpoint whose keys do not all match')),
     (('--synthetic',), dict(type=int, nargs=3, default=None, metavar=('T', 'H', 'W'),
                             help='use a synthetic uint8 clip of T frames of HxW instead of --dataset')),
@@ -130,7 +133,10 @@ def main(argv=None):
         checkpoint = load_checkpoint(args.resume_state, map_location=device)
         load_weights(model, checkpoint['state_dict'], args.allow_partial_load)
         model.to(device)
-        model.infer(get_loader(unsup_data, 40), args, save_video=video_path)
+        if args.save_images:
+            model.infer(get_loader(unsup_data, 40), args, save_images=args.save_images)
+        else:
+            model.infer(get_loader(unsup_data, 40), args, save_video=video_path)
     return model
 
 

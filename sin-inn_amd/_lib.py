@@ -120,6 +120,7 @@ _SIGS = {
                                         C.c_int, C.c_int, c_f, I64x4, c_f, I64x4, C.c_void_p]),
     'sininn_bayer_bin': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'sininn_bayer_demosaic': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'sininn_frames_to_u8': (C.c_int, [c_f, I64x4, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'sininn_adam_step': (C.c_int, [c_f, c_f, c_f, c_f, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_int, C.c_float, C.c_void_p]),
 }

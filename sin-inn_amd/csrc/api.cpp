@@ -60,6 +60,8 @@ int lrelu_bwd_launch(float* g, int g_stride, const float* f, int f_stride, int64
 int irn_coupling_bwd_launch(const float* dy, int dy_stride, const float* vy, int vy_stride, const float* hval, int64_t M,
                             int Co, float clamp, int inverse, float* dG, float* dh, float* dv, int dv_stride,
                             hipStream_t st);
+int frames_to_u8_launch(const float* in, const int64_t is[4], uint8_t* out, int B, int C, int H, int W, int wrap,
+                        hipStream_t st);
 void profile_begin(int h, unsigned long long* stamps, int max_launches);
 int profile_end(int* count, float* total_ms);
 int softsplat_fwd_launch(const float* in, const float* flow, int B, int C, int H, int W, float* out, hipStream_t st);
@@ -286,6 +288,11 @@ int sininn_bayer_demosaic(const uint8_t* hr, uint8_t* rgb, int T, int H, int W, 
 }
 int sininn_bayer_bin(const uint8_t* hr, uint8_t* lr, int T, int H, int W, int scale, int reduce_sum, void* stream) {
   return bayer_bin_launch(hr, lr, T, H, W, scale, reduce_sum, ST(stream));
+}
+
+int sininn_frames_to_u8(const float* in, const int64_t in_strides[4], uint8_t* out, int B, int C, int H, int W, int wrap,
+                        void* stream) {
+  return frames_to_u8_launch(in, in_strides, out, B, C, H, W, wrap, ST(stream));
 }
 
 int sininn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

@@ -46,6 +46,16 @@ def allreduce_mean_(flat_buffers):
         buf.div_(ws)
 
 
+def allreduce_sum_(flat_buffers):
+    """In-place SUM of each flat gradient buffer over the ranks; the 1/world factor is folded into the fused Adam launch
+    (sininn_adam_step's grad_scale) instead of a separate pass over the buffer."""
+    _, ws = world()
+    if ws == 1:
+        return
+    for buf in flat_buffers:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+
+
 def broadcast_(tensors, src=0):
     _, ws = world()
     if ws == 1:

@@ -186,3 +186,17 @@ def bayer_demosaic(hr_clip, scale=4, reduction='mean'):
     _lib.check(_lib.lib().sininn_bayer_demosaic(hr_clip.data_ptr(), rgb.data_ptr(), t, h, w, scale,
                                                 1 if reduction == 'sum' else 0, ops._stream()))
     return rgb
+
+
+def frames_to_u8(frames, wrap=False):
+    """(B,C,H,W)-shaped float frames (any strides) -> (B,H,W,C) uint8 on the device.  wrap=False clamps to [0,1] before the
+    *255; wrap=True reproduces torchvision's ToPILImage (mul(255).byte(), wrap-around) that the reference's infer uses."""
+    from . import _lib
+    assert frames.dim() == 4 and frames.dtype == torch.float32
+    if not frames.is_cuda:
+        raise NotImplementedError('sin-inn_amd ops run on the GPU only (got a CPU tensor)')
+    b, c, h, w = frames.shape
+    out = torch.empty((b, h, w, c), device=frames.device, dtype=torch.uint8)
+    _lib.check(_lib.lib().sininn_frames_to_u8(ops.ptr(frames), ops.strides4(frames), out.data_ptr(), b, c, h, w,
+                                              1 if wrap else 0, ops._stream()))
+    return out

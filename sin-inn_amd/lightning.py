@@ -76,7 +76,12 @@ class _OptimizerProxy:
         _, ws = sdist.world()
         if ws > 1:
             if hasattr(self.optimizer, 'flat_grads'):
-                sdist.allreduce_mean_(self.optimizer.flat_grads())
+                # ONE collective on the flat buffer; the mean's 1/world rides on the Adam kernel's gradient scale.
+                # (No bucketing: the forward chain's backward walks the blocks last -> first and the reverse chain's
+                # first -> last, both accumulating into the same buffer, so no block's gradient is final before the tail
+                # of the step -- there is no window to overlap an earlier bucket with.)
+                sdist.allreduce_sum_(self.optimizer.flat_grads())
+                kw = dict(kw, grad_scale=kw.get('grad_scale', 1.0) / ws)
             else:
                 sdist.allreduce_mean_([p.grad for g in self.optimizer.param_groups for p in g['params']
                                        if p.grad is not None])

@@ -139,6 +139,14 @@ class L(data.DeviceLoader):
 import types
 seen = [x for b in L(D(), 4) for x in b]
 assert seen == D.frames[rank::2], seen
+# ADVICE r1: a length that does not divide by the world size must still give every rank the same number of batches (and
+# the same last-batch size), or one rank issues an extra gradient all-reduce and the job hangs
+class D41(D):
+    frames = list(range(3, 44))
+batches = list(L(D41(), 4))
+assert len(batches) == len(L(D41(), 4)) == 6 and [len(b) for b in batches] == [4, 4, 4, 4, 4, 1], batches
+mine = [x for b in batches for x in b]
+assert mine == (D41.frames + D41.frames[:1])[rank::2]
 print('rank', rank, 'ok')
 '''
 
@@ -152,3 +160,103 @@ def test_data_parallel_glue_world2_gloo(tmp_path):
                          capture_output=True, text=True, env=env, timeout=240)
     assert out.returncode == 0, out.stdout + out.stderr
     assert 'rank 0 ok' in out.stdout and 'rank 1 ok' in out.stdout
+
+
+def test_bench_self_launches_its_ranks_cpu_rehearsal():
+    """`python bench.py --gpus 2` with no WORLD_SIZE must spawn its own ranks (torch.distributed.run children, before any
+    GPU call) and relay rank 0's JSON line; --rehearse runs that plumbing on gloo without kernels."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--rehearse', '--steps', '3'],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['steps'] == 3 and rec['rehearsal'] is True and rec['scaling'] == 'weak'
+
+
+def test_checkpoint_holds_tensors_and_primitives_only(tmp_path):
+    """a checkpoint must load back (torch.load default weights_only=True) and must not carry the clip."""
+    import argparse
+    import sin_inn_amd
+    from sin_inn_amd import lightning as pl
+    import data
+
+    class Tiny(pl.LightningModule):
+        def __init__(self, c, opt):
+            super().__init__()
+            self.save_hyperparameters()
+            self.lin = torch.nn.Linear(3, 2)
+
+    opt = argparse.Namespace(scale=4, adam_betas=[0.9, 0.99], scene='x', resume_state=None,
+                             frame_store=data.FrameStore.synthetic(4, 16, 16))
+    m = Tiny(3, opt)
+    tr = pl.Trainer.__new__(pl.Trainer)
+    tr.current_epoch, tr.global_step = 3, 17
+    tr.optimizer = types.SimpleNamespace(state_dict=lambda: {'flat': [dict(m=torch.zeros(4), v=torch.ones(4), step=5)],
+                                                             'param_groups': [{'lr': 1e-4, 'betas': (0.9, 0.99)}]})
+    path = str(tmp_path / 'ck' / 'epoch=3.ckpt')
+    tr.save_checkpoint(m, path)
+    assert os.path.getsize(path) < 20000                       # the uint8 clip is not in there
+    ck = torch.load(path)                                      # default weights_only=True must work
+    assert set(ck['state_dict']) == {'lin.weight', 'lin.bias'} and ck['epoch'] == 3 and ck['global_step'] == 17
+    hp = ck['hyper_parameters']
+    assert hp['c'] == 3 and hp['opt']['scale'] == 4 and hp['opt']['adam_betas'] == [0.9, 0.99]
+    assert 'frame_store' not in hp['opt']
+    assert pl.load_checkpoint(path)['optimizer_states'][0]['flat'][0]['step'] == 5
+    # a Lightning checkpoint as the reference writes it: argparse.Namespace pickled under hyper_parameters
+    ref_path = str(tmp_path / 'ref.ckpt')
+    torch.save({'state_dict': m.state_dict(), 'hyper_parameters': {'opt': argparse.Namespace(scale=4)}, 'epoch': 1}, ref_path)
+    assert pl.load_checkpoint(ref_path)['hyper_parameters']['opt'].scale == 4
+
+
+def test_test_mode_loads_strictly_and_tolerates_only_freia_bookkeeping():
+    import main
+    net = torch.nn.Sequential(torch.nn.Linear(2, 2))
+    good = {k: v.clone() for k, v in net.state_dict().items()}
+    main.load_weights(net, good)
+    main.load_weights(net, dict(good, **{'module_list.4.perm': torch.arange(3), 'module_list.4.perm_inv': torch.arange(3)}))
+    with pytest.raises(SystemExit):
+        main.load_weights(net, {'0.weight': good['0.weight']})                 # a real parameter is missing
+    with pytest.raises(SystemExit):
+        main.load_weights(net, dict(good, **{'1.weight': torch.zeros(2, 2)}))  # wrong architecture
+    main.load_weights(net, {'0.weight': good['0.weight']}, allow_partial=True)
+
+
+def _write_png_tree(root, scene, t, h, w, skip_lr=(), skip_hr=()):
+    from PIL import Image
+    import numpy as np
+    rng = np.random.RandomState(0)
+    hr = rng.randint(0, 256, (t, h, w, 3), dtype=np.uint8)
+    lr = rng.randint(0, 256, (t, h // 8, w // 8, 4), dtype=np.uint8)
+    for kind in ('hr_frames', 'lr_frames'):
+        os.makedirs(os.path.join(root, kind, scene), exist_ok=True)
+    for i in range(t):
+        if i not in skip_lr:
+            Image.fromarray(lr[i], 'RGBA').save(os.path.join(root, 'lr_frames', scene, f'frame_{i:05d}.png'))
+        if i not in skip_hr:
+            Image.fromarray(hr[i], 'RGB').save(os.path.join(root, 'hr_frames', scene, f'frame_{i:05d}.png'))
+    return hr, lr
+
+
+def test_frame_store_from_directory_layout_and_missing_frames(tmp_path):
+    """<dataset>/{hr_frames,lr_frames}/<scene>/frame_%05d.png (data.py:20-21,57-59); a missing PNG fails loudly like the
+    reference's io.imread instead of leaving a zero frame."""
+    import numpy as np
+    import data
+    hr, lr = _write_png_tree(str(tmp_path / 'ok'), 'clip', 30, 16, 16)
+    st = data.FrameStore.from_directory(str(tmp_path / 'ok'), 'clip')
+    assert st.num_lr == 29 and np.array_equal(st.hr.numpy(), hr) and np.array_equal(st.lr.numpy(), lr)
+    opt = types.SimpleNamespace(fps=10, lr_window=1, operation='train', dataset=str(tmp_path / 'ok'), scene='clip')
+    assert data.VideoTrainDataset(opt).frames == list(range(11, 19, 12))
+    assert opt.frame_store is not None                                          # decoded once, shared
+    # HR frames exist only where the reference would read them: sparse HR directories are fine ...
+    _write_png_tree(str(tmp_path / 'sparse'), 'clip', 30, 16, 16, skip_hr=set(range(30)) - {11})
+    opt2 = types.SimpleNamespace(fps=10, lr_window=1, operation='train', dataset=str(tmp_path / 'sparse'), scene='clip')
+    assert data.VideoTrainDataset(opt2).frames == [11]
+    with pytest.raises(FileNotFoundError):                                       # ... but not for a dataset that needs them
+        data.VideoAllDataset(opt2)
+    _write_png_tree(str(tmp_path / 'gap'), 'clip', 30, 16, 16, skip_lr={12})
+    with pytest.raises(FileNotFoundError):
+        data.FrameStore.from_directory(str(tmp_path / 'gap'), 'clip')
