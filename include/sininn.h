@@ -134,6 +134,19 @@ int sininn_wgrad(const float* in, int in_stride, int Cin, const float* dout, int
                  int B, int H, int W, int ksize, float* gw_oihw, float* gbias,
                  void* workspace, size_t workspace_bytes, void* stream);
 
+/* Grouped form: the weight gradients of up to 8 convs that see the same pixels (B,H,W) and kernel size -- the four
+ * convs of one GLOW block -- in two launches (gradient kernel + ordered slab reduce).  The convs share the launch
+ * grid, so each needs far fewer split-K slabs than on its own (3-6x less slab traffic); results are bitwise
+ * reproducible like sininn_wgrad's.  3x3: Winograd F(3x3,2x2) kernel, 64 x 32 output tiles; 1x1: 32 x 32 tiles. */
+typedef struct sininn_wgrad_item {
+  const float* in;   int in_stride;   int Cin;     /* conv input  [M][in_stride], Cin % 4 == 0                      */
+  const float* dout; int dout_stride; int N;       /* output gradient [M][dout_stride], N % 4 == 0                  */
+  float* gw; float* gb;                            /* OIHW weight gradient (+=), bias gradient (+=, may be NULL)    */
+} sininn_wgrad_item;
+size_t sininn_wgrad_group_workspace_bytes(const sininn_wgrad_item* items, int n, int B, int H, int W, int ksize);
+int sininn_wgrad_group(const sininn_wgrad_item* items, int n, int B, int H, int W, int ksize,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Backward of the coupling tail (the elementwise part of GLOWCouplingBlock).
  *   inverse==0: y = e(s) v + t      dv = dy e ; dt = dy  ; ds = (dy v e + gld) L'(s)

@@ -52,6 +52,12 @@ class GlowArgs(C.Structure):
                 ('dout', c_f), ('gld', c_f), ('dx', c_f), ('skip_dx', C.c_int)]
 
 
+class WgradItem(C.Structure):
+    """Mirror of sininn_wgrad_item."""
+    _fields_ = [('inp', c_f), ('in_stride', C.c_int), ('Cin', C.c_int), ('dout', c_f), ('dout_stride', C.c_int),
+                ('N', C.c_int), ('gw', c_f), ('gb', c_f)]
+
+
 class PackDesc(C.Structure):
     """Mirror of sininn_pack_desc."""
     _fields_ = [('w', c_f), ('bias', c_f), ('N', C.c_int), ('Cin', C.c_int), ('ksize', C.c_int), ('colmap', c_i),
@@ -87,6 +93,9 @@ _SIGS = {
     'sininn_wgrad_workspace_bytes': (C.c_size_t, [C.c_int] * 6),
     'sininn_wgrad': (C.c_int, [c_f, C.c_int, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'sininn_wgrad_group_workspace_bytes': (C.c_size_t, [C.POINTER(WgradItem), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'sininn_wgrad_group': (C.c_int, [C.POINTER(WgradItem), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                     C.c_size_t, C.c_void_p]),
     'sininn_coupling_bwd': (C.c_int, [c_f, C.c_int, c_i, c_f, C.c_int, c_i, c_f, c_f, C.c_int, C.c_int, C.c_int,
                                       C.c_float, C.c_int, c_f, c_f, C.c_int, C.c_void_p]),
     'sininn_profile_begin': (None, [C.c_int, C.c_void_p, C.c_int]),

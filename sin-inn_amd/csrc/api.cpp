@@ -20,6 +20,9 @@ void wgrad_set_force16(int on);
 size_t wgrad_workspace_bytes(int N, int Cin, int ksize, int B, int H, int W);
 int wgrad_launch(const float* in, int in_stride, int Cin, const float* dout, int dout_stride, int N, int B, int H, int W,
                  int ksize, float* gw, float* gb, void* ws, size_t ws_bytes, hipStream_t st);
+size_t wgrad_group_workspace_bytes(const sininn_wgrad_item* items, int n, int B, int H, int W, int ksize);
+int wgrad_group_launch(const sininn_wgrad_item* items, int n, int B, int H, int W, int ksize, void* ws, size_t ws_bytes,
+                       hipStream_t st);
 int pack_launch(const float* w, const float* bias, int N, int Cin, int ksize, const int* colmap, int Np, float* w_fwd,
                 float* b_fwd, int Cdp, float* w_dgrad, hipStream_t st);
 int coupling_bwd_launch(const float* dy, int dy_stride, const int* dy_map, const float* vy, int vy_stride,
@@ -288,6 +291,14 @@ int sininn_bayer_demosaic(const uint8_t* hr, uint8_t* rgb, int T, int H, int W, 
 }
 int sininn_bayer_bin(const uint8_t* hr, uint8_t* lr, int T, int H, int W, int scale, int reduce_sum, void* stream) {
   return bayer_bin_launch(hr, lr, T, H, W, scale, reduce_sum, ST(stream));
+}
+
+size_t sininn_wgrad_group_workspace_bytes(const sininn_wgrad_item* items, int n, int B, int H, int W, int ksize) {
+  return wgrad_group_workspace_bytes(items, n, B, H, W, ksize);
+}
+int sininn_wgrad_group(const sininn_wgrad_item* items, int n, int B, int H, int W, int ksize, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+  return wgrad_group_launch(items, n, B, H, W, ksize, workspace, workspace_bytes, ST(stream));
 }
 
 int sininn_frames_to_u8(const float* in, const int64_t in_strides[4], uint8_t* out, int B, int C, int H, int W, int wrap,

@@ -15,6 +15,10 @@ int conv_launch(const sininn_conv_args* a, hipStream_t st);
 size_t wgrad_workspace_bytes(int N, int Cin, int ksize, int B, int H, int W);
 int wgrad_launch(const float* in, int in_stride, int Cin, const float* dout, int dout_stride, int N, int B, int H, int W,
                  int ksize, float* gw, float* gb, void* ws, size_t ws_bytes, hipStream_t st);
+size_t wgrad_group_workspace_bytes(const sininn_wgrad_item* items, int n, int B, int H, int W, int ksize);
+int wgrad_group_launch(const sininn_wgrad_item* items, int n, int B, int H, int W, int ksize, void* ws, size_t ws_bytes,
+                       hipStream_t st);
+bool wgrad_grouping_enabled();
 int coupling_bwd_launch(const float* dy, int dy_stride, const int* dy_map, const float* vy, int vy_stride,
                         const int* vy_map, const float* s, const float* gld, int B, int HW, int Co, float clamp,
                         int inverse, float* dr, float* dv, int dv_stride, hipStream_t st);
@@ -146,6 +150,16 @@ static Scratch scratch_layout(void* basep, int B, int H, int W, int C, int ksize
                            wgrad_workspace_bytes(2 * co_a, SININN_HIDDEN, ksize, B, H, W),
                            wgrad_workspace_bytes(SININN_HIDDEN, cond_a, ksize, B, H, W)};
   for (size_t c : cands) w = c > w ? c : w;
+  {  // grouped weight gradients: the four convs' slabs live side by side
+    const int cond_b = co_a;
+    sininn_wgrad_item it[4] = {};
+    it[0].Cin = SININN_HIDDEN; it[0].N = 2 * co_b;
+    it[1].Cin = cond_b;        it[1].N = SININN_HIDDEN;
+    it[2].Cin = SININN_HIDDEN; it[2].N = 2 * co_a;
+    it[3].Cin = cond_a;        it[3].N = SININN_HIDDEN;
+    const size_t gbytes = wgrad_group_workspace_bytes(it, 4, B, H, W, ksize);
+    w = gbytes > w ? gbytes : w;
+  }
   s.ws = base + o;
   s.ws_bytes = w;
   s.total_bytes = o * sizeof(float) + w;
@@ -227,6 +241,16 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
   const int* map_a = a->dst_map ? a->dst_map + base_a : nullptr;
   const int* map_b = a->dst_map ? a->dst_map + base_b : nullptr;
 
+  // grouped weight gradients: the four problems are collected and launched together once the last of their inputs (the
+  // first half's dh) has been queued; one launch pair on the weight-gradient stream instead of four
+  const bool grouped = wgrad_grouping_enabled();
+  sininn_wgrad_item items[4];
+  int n_items = 0;
+  auto add_item = [&](const float* in, int in_stride, int cin, const float* dout, int dout_stride, int n, float* gw, float* gb) {
+    sininn_wgrad_item& it = items[n_items++];
+    it.in = in; it.in_stride = in_stride; it.Cin = cin; it.dout = dout; it.dout_stride = dout_stride; it.N = n; it.gw = gw; it.gb = gb;
+  };
+
   // fuse: when set, the dgrad of this half's first conv also performs the coupling-tail backward of the OTHER
   // (first-executed) half in its epilogue, writing dr_a / dx instead of the intermediate gradient
   struct Fuse { const float* vy; int vy_stride; const float* s; float* dr; };
@@ -234,15 +258,18 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
                       const float* dy, int dy_stride, const int* dy_map, const float* vy, int vy_stride, const int* vy_map,
                       const float* cond, int cond_stride, int cond_cin,
                       const float* addend, int add_stride, const int* add_map, float* dcond, int dcond_stride,
-                      bool do_coupling, const Fuse* fuse, bool skip_d1) -> int {
+                      bool do_coupling, const Fuse* fuse, bool skip_d1, bool last_half) -> int {
     const sininn_subnet* net = h.net;
     if (do_coupling)
       if (int rc = coupling_bwd_launch(dy, dy_stride, dy_map, vy, vy_stride, vy_map, sbuf, a->gld, B, HW, h.co, a->clamp, inv,
                                        dr, a->dx + h.base, C, st)) return rc;
     if (net->gw2) {
-      if (int rc = order_after(wst, st)) return rc;
-      if (int rc = wgrad_launch(hbuf, SININN_HIDDEN, SININN_HIDDEN, dr, 2 * h.co, 2 * h.co, B, H, W, k, net->gw2, net->gb2,
-                                sc.ws, sc.ws_bytes, wst)) return rc;
+      if (grouped) add_item(hbuf, SININN_HIDDEN, SININN_HIDDEN, dr, 2 * h.co, 2 * h.co, net->gw2, net->gb2);
+      else {
+        if (int rc = order_after(wst, st)) return rc;
+        if (int rc = wgrad_launch(hbuf, SININN_HIDDEN, SININN_HIDDEN, dr, 2 * h.co, 2 * h.co, B, H, W, k, net->gw2, net->gb2,
+                                  sc.ws, sc.ws_bytes, wst)) return rc;
+      }
     }
     sininn_conv_args d2 = {};
     d2.in = dr; d2.in_stride = 2 * h.co; d2.Cin = 2 * h.co; d2.w = net->w2_dgrad; d2.Np = SININN_HIDDEN;
@@ -251,9 +278,17 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
     d2.out = dh; d2.out_stride = SININN_HIDDEN; d2.N = SININN_HIDDEN; d2.mask = hbuf; d2.mask_stride = SININN_HIDDEN;
     if (int rc = conv_launch(&d2, st)) return rc;
     if (net->gw1) {
-      if (int rc = order_after(wst, st)) return rc;
-      if (int rc = wgrad_launch(cond, cond_stride, cond_cin, dh, SININN_HIDDEN, SININN_HIDDEN, B, H, W, k, net->gw1, net->gb1,
-                                sc.ws, sc.ws_bytes, wst)) return rc;
+      if (grouped) add_item(cond, cond_stride, cond_cin, dh, SININN_HIDDEN, SININN_HIDDEN, net->gw1, net->gb1);
+      else {
+        if (int rc = order_after(wst, st)) return rc;
+        if (int rc = wgrad_launch(cond, cond_stride, cond_cin, dh, SININN_HIDDEN, SININN_HIDDEN, B, H, W, k, net->gw1, net->gb1,
+                                  sc.ws, sc.ws_bytes, wst)) return rc;
+      }
+      if (grouped && last_half && n_items > 0) {     // every input of the group is queued on `st` now
+        if (int rc = order_after(wst, st)) return rc;
+        if (int rc = wgrad_group_launch(items, n_items, B, H, W, k, sc.ws, sc.ws_bytes, wst)) return rc;
+        n_items = 0;
+      }
     }
     if (skip_d1) return 0;                           // the gradient w.r.t. this half's condition is not needed
     sininn_conv_args d1 = {};
@@ -287,7 +322,7 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
     fz.s = sv.s_a;
     fz.dr = sc.dr_a;
     if (int rc = half_bwd(hv[1], sv.h_b, sv.s_b, sc.dr_b, sc.dh_b, dy, C, map_b, vy, vy_stride, vy_map,
-                          sv.ybuf, co_a, co_a, addend, C, map_a, sc.dy_first, co_a, true, &fz, false)) return rc;
+                          sv.ybuf, co_a, co_a, addend, C, map_a, sc.dy_first, co_a, true, &fz, false, false)) return rc;
   }
   // ---- first half: condition = x[:, cond range]; its data gradient accumulates in place into dx ----
   {
@@ -296,7 +331,11 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
     const int vy_stride = a->rev ? co_a : C;
     if (int rc = half_bwd(hv[0], sv.h_a, sv.s_a, sc.dr_a, sc.dh_a, sc.dy_first, co_a, nullptr, vy, vy_stride, nullptr,
                           a->x + cond_off, C, cond_cin, a->dx + cond_off, C, nullptr, a->dx + cond_off, C, false,
-                          nullptr, a->skip_dx != 0)) return rc;
+                          nullptr, a->skip_dx != 0, true)) return rc;
+  }
+  if (grouped && n_items > 0) {                      // a frozen conv1 in the last half: flush what was collected
+    if (int rc = order_after(wst, st)) return rc;
+    if (int rc = wgrad_group_launch(items, n_items, B, H, W, k, sc.ws, sc.ws_bytes, wst)) return rc;
   }
   return 0;
 }

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradDev p) {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int KS>
-__global__ __launch_bounds__(256, 2) void wgrad32_kernel(WgradDev p) {
+__device__ __forceinline__ void wgrad32_body(const WgradDev& p, const int split, const int n0, const int c0, const int zblock) {
   constexpr int HALO = KS / 2;
   constexpr int IW = 16 + 2 * HALO;
   constexpr int IH = WG_TH + 2 * HALO;
@@ -198,8 +198,6 @@ __global__ __launch_bounds__(256, 2) void wgrad32_kernel(WgradDev p) {
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, kh = lane >> 5;
-  const int split = blockIdx.x;
-  const int n0 = blockIdx.y * 32, c0 = blockIdx.z * 32;
 
   f32x16 acc[TAPS];
 #pragma unroll
@@ -300,10 +298,15 @@ __global__ __launch_bounds__(256, 2) void wgrad32_kernel(WgradDev p) {
   bsum += __shfl_xor(bsum, 32);
   if (lane < 32) lds[wave * 32 + lane] = bsum;
   __syncthreads();
-  if (blockIdx.z == 0 && tid < 32) {
+  if (zblock == 0 && tid < 32) {
     const int n = n0 + tid;
     if (n < p.Nr) p.bpartial[(size_t)split * p.Nr + n] = (lds[tid] + lds[32 + tid]) + (lds[64 + tid] + lds[96 + tid]);
   }
+}
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void wgrad32_kernel(WgradDev p) {
+  wgrad32_body<KS>(p, blockIdx.x, blockIdx.y * 32, blockIdx.z * 32, blockIdx.z);
 }
 
 
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void wgrad32_kernel(WgradDev p) {
 //   (128 accumulator VGPRs); pixel tiles of 8x16 (32 Winograd tiles = 8 k-steps) are walked split-K style.
 // ------------------------------------------------------------------------------------------------
 template <int TH, int UNR, int KH>
-__global__ __launch_bounds__(256 * KH, 2 / KH) void wgrad_wino_kernel(WgradDev p) {
+__device__ __forceinline__ void wgrad_wino_body(const WgradDev& p, const int split, const int n0, const int c0, const int zblock) {
   // KH = 2: eight waves; the two wave quads take alternate halves of every pixel tile's k-steps and are summed through
   // LDS at the end -> one slab per CU instead of two (half the split-K slab traffic), one staged tile per 8 waves.
   constexpr int NTHR = 256 * KH;
@@ -338,8 +341,6 @@ __global__ __launch_bounds__(256 * KH, 2 / KH) void wgrad_wino_kernel(WgradDev p
   const int wave = (tid >> 6) & 3, kh = tid >> 8, lane = tid & 63;
   const int li = lane & 15, kq = lane >> 4;
   const int wr = wave & 1, wc = wave >> 1;
-  const int split = blockIdx.x;
-  const int n0 = blockIdx.y * BNW, c0 = blockIdx.z * BCW;
 
   f32x4 acc[16][2];
 #pragma unroll
@@ -505,11 +506,16 @@ __global__ __launch_bounds__(256 * KH, 2 / KH) void wgrad_wino_kernel(WgradDev p
     float bs = bsum[a];
     bs += __shfl_xor(bs, 16);
     bs += __shfl_xor(bs, 32);
-    if (blockIdx.z == 0 && wc == 0 && kq == 0) {
+    if (zblock == 0 && wc == 0 && kq == 0) {
       const int n = n0 + 32 * wr + 16 * a + li;
       if (n < p.Nr) p.bpartial[(size_t)split * p.Nr + n] = bs;
     }
   }
+}
+
+template <int TH, int UNR, int KH>
+__global__ __launch_bounds__(256 * KH, 2 / KH) void wgrad_wino_kernel(WgradDev p) {
+  wgrad_wino_body<TH, UNR, KH>(p, blockIdx.x, blockIdx.y * 64, blockIdx.z * 32, blockIdx.z);
 }
 
 // Reduce S slabs in a fixed order and accumulate into the OIHW gradient:  gw[n][c][tap] += sum_s partial[s][tap][n][c]
@@ -575,6 +581,101 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Grouped weight gradients: the four convs of a GLOW block (two subnets x two convs) in ONE launch.
+// A single conv offers only N*C / (64*32) = 4 .. 24 output tiles, so filling 512 blocks took 21 .. 128 pixel splits
+// per conv, i.e. ~38 MB of split-K slabs written and re-read per conv (1.3 GB per training step) and a reduce launch
+// each.  Grouped, the block's 24 (level 0) / 72 (level 1) tiles share the grid: 7 .. 21 splits, slabs 3-6x smaller,
+// two launches (gradient + ordered reduce) per block instead of eight.  Results stay bitwise reproducible: every slab
+// is summed in split order and each gradient element is touched by exactly one thread.
+// ------------------------------------------------------------------------------------------------
+constexpr int WG_MAXP = 8;
+struct WgradProb {
+  WgradDev d;
+  float* gw; float* gb;
+  int S, nblk, cblk;
+  int block_begin;       // first block of this problem in the grouped gradient grid
+  int red_begin;         // first block of this problem in the grouped reduce grid
+};
+struct WgradGroup { WgradProb p[WG_MAXP]; int n; int taps; };
+
+__device__ __forceinline__ int group_problem(const WgradGroup& g, int bid, bool reduce) {
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < WG_MAXP; ++i)
+    if (i < g.n && bid >= (reduce ? g.p[i].red_begin : g.p[i].block_begin)) pi = i;
+  return pi;
+}
+
+template <int TH, int UNR>
+__global__ __launch_bounds__(256, 2) void wgrad_wino_group_kernel(WgradGroup g) {
+  const int pi = group_problem(g, blockIdx.x, false);
+  const WgradProb& q = g.p[pi];
+  const int lb = blockIdx.x - q.block_begin;
+  const int split = lb % q.S, nb = (lb / q.S) % q.nblk, cb = lb / (q.S * q.nblk);
+  wgrad_wino_body<TH, UNR, 1>(q.d, split, nb * 64, cb * 32, cb);
+}
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void wgrad32_group_kernel(WgradGroup g) {
+  const int pi = group_problem(g, blockIdx.x, false);
+  const WgradProb& q = g.p[pi];
+  const int lb = blockIdx.x - q.block_begin;
+  const int split = lb % q.S, nb = (lb / q.S) % q.nblk, cb = lb / (q.S * q.nblk);
+  wgrad32_body<KS>(q.d, split, nb * 32, cb * 32, cb);
+}
+
+// Ordered slab reduce of a whole group:  gw[n][c][tap] += sum_s partial[s][tap][n][c]  (+ the bias sums).
+// Block = RC float4 columns (4 consecutive c of one n) x taps: thread (tap, column) sums its S slab entries in split
+// order with coalesced 16-byte loads, the block then transposes through LDS so that the OIHW gradient (taps innermost)
+// is updated with contiguous runs instead of a 4-byte scatter at a 36-byte stride.
+template <int TAPS>
+__global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(WgradGroup g) {
+  constexpr int RC = 256 / TAPS;                     // columns per block (28 for 3x3, 256 for 1x1)
+  __shared__ float tile[RC * 4 * TAPS];
+  const int pi = group_problem(g, blockIdx.x, true);
+  const WgradProb& q = g.p[pi];
+  const WgradDev& d = q.d;
+  const int c4n = d.Cc >> 2;
+  const int ncol = d.Nr * c4n;                       // float4 columns of one tap plane
+  const int wblocks = (ncol + RC - 1) / RC;
+  const int lb = blockIdx.x - q.red_begin;
+  const int tid = threadIdx.x;
+  if (lb >= wblocks) {                               // ---- bias rows: db[n] += sum_s bpartial[s][n] ----
+    const int n = (lb - wblocks) * 256 + tid;
+    if (q.gb != nullptr && n < d.N) {
+      float acc = 0.f;
+      for (int k = 0; k < q.S; ++k) acc += d.bpartial[(size_t)k * d.Nr + n];
+      q.gb[n] += acc;
+    }
+    return;
+  }
+  const int t = tid / RC, cl = tid - t * RC;         // tap, block-local column
+  const int col = lb * RC + cl;
+  if (t < TAPS && col < ncol) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(d.partial) + (size_t)t * ncol + col;
+    const size_t slab = (size_t)TAPS * ncol;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    int k = 0;
+    for (; k + 1 < q.S; k += 2) { a0 += src[(size_t)k * slab]; a1 += src[(size_t)(k + 1) * slab]; }
+    if (k < q.S) a0 += src[(size_t)k * slab];
+    a0 += a1;                                        // fixed association: (even splits) + (odd splits)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[(cl * 4 + j) * TAPS + t] = a0[j];
+  }
+  __syncthreads();
+  // element e of the block = (column cl, channel j, tap t), consecutive in the OIHW gradient for consecutive e
+  for (int e = tid; e < RC * 4 * TAPS; e += 256) {
+    const int cl2 = e / (4 * TAPS), r = e - cl2 * 4 * TAPS;
+    const int j = r / TAPS, t2 = r - j * TAPS;
+    const int col2 = lb * RC + cl2;
+    if (col2 < ncol) {
+      const int n = col2 / c4n, c = (col2 - n * c4n) * 4 + j;
+      if (n < d.N && c < d.Cin) q.gw[((size_t)n * d.Cin + c) * TAPS + t2] += tile[e];
+    }
+  }
+}
+
 struct WgradPlan { int RT, CT, Nr, Cc, nblk, cblk, S, tiles_per_split, ntiles, tiles_x, tiles_y; size_t bytes; bool use32; bool wino; int th; int kh; };
 
 static bool g_wgrad_force16 = false;   // test hook
@@ -582,7 +683,9 @@ static bool g_wgrad_wino = true;       // Winograd weight gradient for 3x3 (test
 static bool g_wgrad_wino_th8 = false;  // test hook bit 2: 8-row pixel tiles in the Winograd weight gradient
 static bool g_wgrad_wino_kh2 = false;  // test hook bit 3: 8-wave blocks with an in-block k split (half the slabs; same kernel
                                        // time, but 3 % slower end to end when other streams' kernels co-run) -- off
-void wgrad_set_force16(int on) { g_wgrad_force16 = (on & 1) != 0; g_wgrad_wino = (on & 2) == 0; g_wgrad_wino_th8 = (on & 4) != 0; g_wgrad_wino_kh2 = (on & 8) != 0; }
+static bool g_wgrad_grouped = true;    // test hook bit 4 clears: the block executor issues one launch pair per conv (round-1 path)
+void wgrad_set_force16(int on) { g_wgrad_force16 = (on & 1) != 0; g_wgrad_wino = (on & 2) == 0; g_wgrad_wino_th8 = (on & 4) != 0; g_wgrad_wino_kh2 = (on & 8) != 0; g_wgrad_grouped = (on & 16) == 0; }
+bool wgrad_grouping_enabled() { return g_wgrad_grouped && g_wgrad_wino && !g_wgrad_force16; }
 
 static WgradPlan make_plan(int N, int Cin, int ksize, int B, int H, int W) {
   WgradPlan pl;
@@ -659,6 +762,86 @@ int wgrad_launch(const float* in, int in_stride, int Cin, const float* dout, int
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total4 + 63) / 64 + bias_blocks), dim3(256), 0, st,
                      d.partial, d.bpartial, pl.S, taps, pl.Nr, pl.Cc, N, Cin, gw, gb);
   SININN_LAUNCH_CHECK("wgrad_reduce");
+  return 0;
+}
+
+// ---- grouped launch (host) ---------------------------------------------------------------------------------------
+struct WgradGroupPlan { WgradGroup g; int grad_blocks, red_blocks; size_t bytes; bool wino; int th; };
+
+static int plan_group(const sininn_wgrad_item* items, int n, int B, int H, int W, int ksize, float* ws, WgradGroupPlan& pl) {
+  SININN_CHECK(items && n >= 1 && n <= WG_MAXP, "wgrad_group: 1..%d problems per group", WG_MAXP);
+  SININN_CHECK(ksize == 1 || ksize == 3, "wgrad_group: ksize %d not in {1,3}", ksize);
+  SININN_CHECK(B > 0 && H > 0 && W > 0, "wgrad_group: bad shape");
+  pl.wino = (ksize == 3);
+  pl.th = pl.wino ? 4 : WG_TH;
+  const int bnw = pl.wino ? 64 : 32, bcw = 32;
+  const int taps = ksize * ksize;
+  const int tiles_x = (W + 15) / 16, tiles_y = (H + pl.th - 1) / pl.th;
+  const int ntiles = B * tiles_x * tiles_y;
+  int out_tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    const sininn_wgrad_item& it = items[i];
+    SININN_CHECK(it.Cin > 0 && it.Cin % 4 == 0 && it.N > 0 && it.N % 4 == 0, "wgrad_group: Cin=%d and N=%d must be multiples of 4", it.Cin, it.N);
+    out_tiles += ((it.N + bnw - 1) / bnw) * ((it.Cin + bcw - 1) / bcw);
+  }
+  // two blocks per CU; all problems of a group see the same pixels, so one split count serves them all
+  int S = 512 / out_tiles;
+  if (S < 1) S = 1;
+  if (S > ntiles) S = ntiles;
+  const int tps = (ntiles + S - 1) / S;
+  S = (ntiles + tps - 1) / tps;
+  pl.g.n = n; pl.g.taps = taps;
+  size_t off = 0;                                    // floats
+  int gb = 0, rb = 0;
+  constexpr int RC3 = 256 / 9, RC1 = 256;
+  for (int i = 0; i < n; ++i) {
+    const sininn_wgrad_item& it = items[i];
+    WgradProb& q = pl.g.p[i];
+    q.nblk = (it.N + bnw - 1) / bnw; q.cblk = (it.Cin + bcw - 1) / bcw; q.S = S;
+    WgradDev& d = q.d;
+    d.in = it.in; d.in_stride = it.in_stride; d.Cin = it.Cin; d.dout = it.dout; d.dout_stride = it.dout_stride; d.N = it.N;
+    d.B = B; d.H = H; d.W = W; d.tiles_x = tiles_x; d.tiles_y = tiles_y; d.ntiles = ntiles; d.tiles_per_split = tps;
+    d.Nr = q.nblk * bnw; d.Cc = q.cblk * bcw;
+    d.partial = ws ? ws + off : nullptr; off += (size_t)S * taps * d.Nr * d.Cc;
+    d.bpartial = ws ? ws + off : nullptr; off += ((size_t)S * d.Nr + 3) / 4 * 4;
+    q.gw = it.gw; q.gb = it.gb;
+    q.block_begin = gb; gb += S * q.nblk * q.cblk;
+    q.red_begin = rb;
+    const int ncol = d.Nr * (d.Cc / 4), rc = (taps == 9) ? RC3 : RC1;
+    rb += (ncol + rc - 1) / rc + (it.gb ? (it.N + 255) / 256 : 0);
+  }
+  pl.grad_blocks = gb; pl.red_blocks = rb; pl.bytes = off * sizeof(float);
+  return 0;
+}
+
+size_t wgrad_group_workspace_bytes(const sininn_wgrad_item* items, int n, int B, int H, int W, int ksize) {
+  WgradGroupPlan pl;
+  if (plan_group(items, n, B, H, W, ksize, nullptr, pl)) return 0;
+  return pl.bytes;
+}
+
+int wgrad_group_launch(const sininn_wgrad_item* items, int n, int B, int H, int W, int ksize, void* ws, size_t ws_bytes,
+                       hipStream_t st) {
+  SININN_CHECK(ws != nullptr && aligned16(ws), "wgrad_group: workspace must be 16-byte aligned");
+  WgradGroupPlan pl;
+  if (int rc = plan_group(items, n, B, H, W, ksize, static_cast<float*>(ws), pl)) return rc;
+  SININN_CHECK(ws_bytes >= pl.bytes, "wgrad_group: workspace too small (%zu < %zu)", ws_bytes, pl.bytes);
+  for (int i = 0; i < n; ++i) {
+    const sininn_wgrad_item& it = items[i];
+    SININN_CHECK(it.in && it.dout && it.gw, "wgrad_group: null pointer in problem %d", i);
+    SININN_CHECK(it.in_stride >= it.Cin && it.in_stride % 4 == 0 && aligned16(it.in), "wgrad_group: in must be 16-byte aligned, stride %% 4 == 0");
+    SININN_CHECK(it.dout_stride >= it.N && it.dout_stride % 4 == 0 && aligned16(it.dout), "wgrad_group: dout must be 16-byte aligned, stride %% 4 == 0");
+  }
+  if (pl.wino) {
+    hipLaunchKernelGGL((wgrad_wino_group_kernel<4, 2>), dim3(pl.grad_blocks), dim3(256), 0, st, pl.g);
+    SININN_LAUNCH_CHECK("wgrad_wino_group");
+    hipLaunchKernelGGL((wgrad_reduce_group_kernel<9>), dim3(pl.red_blocks), dim3(256), 0, st, pl.g);
+  } else {
+    hipLaunchKernelGGL((wgrad32_group_kernel<1>), dim3(pl.grad_blocks), dim3(256), 0, st, pl.g);
+    SININN_LAUNCH_CHECK("wgrad32_group");
+    hipLaunchKernelGGL((wgrad_reduce_group_kernel<1>), dim3(pl.red_blocks), dim3(256), 0, st, pl.g);
+  }
+  SININN_LAUNCH_CHECK("wgrad_reduce_group");
   return 0;
 }
 

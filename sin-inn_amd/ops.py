@@ -148,6 +148,20 @@ def wgrad(in_t, in_off, in_stride, cin, dout, dout_stride, n, b, h, w, ksize, gw
                            ptr(gw), ptr(gb), ptr(ws), nbytes, _stream()))
 
 
+def wgrad_group(problems, b, h, w, ksize):
+    """problems: list of (in_t, in_off, in_stride, cin, dout, dout_off, dout_stride, n, gw, gb): all += in two launches."""
+    lib = _lib.lib()
+    arr = (_lib.WgradItem * len(problems))()
+    for it, (in_t, in_off, in_stride, cin, dout, dout_off, dout_stride, n, gw, gb) in zip(arr, problems):
+        assert gw.is_contiguous() and (gb is None or gb.is_contiguous())
+        it.inp, it.in_stride, it.Cin = ptr(in_t, in_off), in_stride, cin
+        it.dout, it.dout_stride, it.N = ptr(dout, dout_off), dout_stride, n
+        it.gw, it.gb = ptr(gw), ptr(gb)
+    nbytes = lib.sininn_wgrad_group_workspace_bytes(arr, len(problems), b, h, w, ksize)
+    ws = torch.empty((nbytes + 3) // 4, device=problems[0][0].device, dtype=torch.float32)
+    check(lib.sininn_wgrad_group(arr, len(problems), b, h, w, ksize, ptr(ws), nbytes, _stream()))
+
+
 def coupling_bwd(dy, dy_off, dy_stride, dy_map, vy, vy_off, vy_stride, vy_map, s, gld, b, hw, co, clamp, inverse,
                  dr, dv, dv_off, dv_stride):
     check(_lib.lib().sininn_coupling_bwd(ptr(dy, dy_off), dy_stride, dy_map, ptr(vy, vy_off), vy_stride, vy_map,

@@ -105,9 +105,7 @@ def test_infer_frames_match_oracle_inverse(tmp_path, mode):
     from PIL import Image
     from data import FrameStore, VideoAllDataset, get_loader
     model, ref, opt = _model_and_oracle(size=32, num_coupling=2)
-    for p in model.parameters():           # make the output leave [0,1] in places so clamp and wrap differ
-        p.data.mul_(2.5)
-    ref.load_state_dict({k[len('inn.'):]: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    # a random-init network fed z ~ N(0, temp^2) leaves [0,1] in many pixels, so clamp and wrap really differ here
     opt.frame_store = FrameStore.synthetic(40, 32, 32)
     opt.operation, opt.pixel_mode, opt.temp = 'test', mode, 0.8
     data = VideoAllDataset(opt)
@@ -132,8 +130,12 @@ def test_infer_frames_match_oracle_inverse(tmp_path, mode):
     got = torch.stack([torch.from_numpy(np.asarray(Image.open(tmp_path / 'f' / f))) for f in files]).permute(0, 3, 1, 2)
     diff = (got.int() - want.int()).abs()
     diff = torch.minimum(diff, 256 - diff) if mode == 'wrap' else diff             # 255 <-> 0 is one step when wrapping
-    near_edge = ((hr_hat * 255 - (hr_hat * 255).round()).abs() < 0.05) | (hr_hat.abs() * 255 < 0.05)
-    assert int(diff.max()) <= 1 and not bool(((diff > 0) & ~near_edge).any())
+    # float tolerance of the path (1e-4 of the max-norm) in LSBs: a pixel may differ by one step only where the oracle
+    # value sits within that distance of a truncation boundary (an integer of 255*x; 0 and 1 themselves when clamping)
+    tol = 255.0 * 1e-4 * float(hr_hat.abs().max()) + 1e-3
+    scaled = hr_hat * 255
+    near_edge = (scaled - scaled.round()).abs() < tol
+    assert int(diff.max()) <= 1 and not bool(((diff > 0) & ~near_edge).any()), (int(diff.max()), tol)
 
 
 def test_frames_to_u8_modes_bit_exact():

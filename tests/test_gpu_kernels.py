@@ -130,6 +130,45 @@ def test_wgrad(env, ksize, cin, n, force16):
     assert relerr(gb.cpu() - 1, conv.bias.grad) < RTOL
 
 
+@pytest.mark.parametrize('ksize', [3, 1])
+@pytest.mark.parametrize('level', [0, 1])
+def test_wgrad_group(env, ksize, level):
+    """The four weight gradients of a GLOW block in one grouped launch pair (sininn_wgrad_group) against torch autograd:
+    level-0 shapes (24 -> 256, 256 -> 48) and level-1 shapes (96 -> 256, 256 -> 192), odd image sizes (partial pixel /
+    Winograd tiles), strided inputs, += semantics; run twice -> bitwise identical."""
+    S, O, dev = env
+    from sin_inn_amd import ops
+    torch.manual_seed(40 + ksize + level)
+    b, h, w = 3, 13, 21
+    half = 24 if level == 0 else 96
+    shapes = [(256, 2 * half), (half, 256), (256, 2 * half), (half, 256)]
+    problems, wants = [], []
+    for cin, n in shapes:
+        conv = torch.nn.Conv2d(cin, n, ksize, padding=ksize // 2)
+        x = torch.randn(b, cin + 8, h, w)
+        g = torch.randn(b, n + 4, h, w)
+        conv(x[:, 8:]).backward(g[:, :n])
+        wants.append((conv.weight.grad, conv.bias.grad))
+        problems.append([nhwc(x), 8, cin + 8, cin, nhwc(g), 0, n + 4, n])
+
+    def run():
+        outs = []
+        probs = []
+        for pr, (gw_ref, gb_ref) in zip(problems, wants):
+            gw, gb = torch.ones_like(gw_ref).cuda(), torch.ones_like(gb_ref).cuda()
+            outs.append((gw, gb))
+            probs.append(tuple(pr) + (gw, gb))
+        ops.wgrad_group(probs, b, h, w, ksize)
+        torch.cuda.synchronize()
+        return outs
+
+    first, second = run(), run()
+    for (gw, gb), (gw2, gb2), (gw_ref, gb_ref) in zip(first, second, wants):
+        assert relerr(gw.cpu() - 1, gw_ref) < RTOL
+        assert relerr(gb.cpu() - 1, gb_ref) < RTOL
+        assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+
+
 def test_golden_subnets_on_gpu(env, golden):
     """the reference's own subnet_conv / subnet_conv_1x1 outputs (tests/golden) through the HIP conv engine."""
     S, O, dev = env
