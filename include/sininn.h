@@ -238,6 +238,14 @@ int sininn_squeeze(const float* in, const int64_t in_strides[4], float* out, con
                    int B, int C, int H, int W, int levels, int inverse,
                    const int* chan_map, int map_on_out, void* stream);
 
+/* The same index maps between two DENSE pixel-major tensors (fine [B][H][W][C], coarse [B][H/2^l][W/2^l][C*4^l]), in
+ * gather form: four consecutive output floats per thread, 16-byte stores.  fine_map (device, may be NULL) acts on the
+ * fine tensor's channel index:  forward  coarse[.., q*C + c] = fine[.., fine_map[c]];
+ *                               inverse  fine[.., c] = coarse[.., q*C + fine_map[c]].
+ * levels == 0: out[.., c] = in[.., fine_map[c]].  Needs B*C*H*W % 4 == 0 and (C*4^levels) % 4 == 0. */
+int sininn_squeeze_rows(const float* in, float* out, int B, int C, int H, int W, int levels, int inverse,
+                        const int* fine_map, void* stream);
+
 /* out[m][j] = in[m][idx[j]] on pixel-major tensors (PermuteRandom.forward: x[:, perm]). */
 int sininn_permute_channels(const float* in, int in_stride, float* out, int out_stride,
                             int64_t M, int C, const int* idx, void* stream);

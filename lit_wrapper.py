@@ -50,6 +50,22 @@ def _cat_channels(a, b):
     return torch.cat((a.permute(0, 2, 3, 1), b.permute(0, 2, 3, 1)), dim=3).permute(0, 3, 1, 2)
 
 
+def _weighted_sum(*terms):
+    """sum_i w_i * term_i() over the terms whose weight is non-zero.  The reference evaluates every term and multiplies by
+    its weight, also when that is 0 (loss.mmd at the default flags, lit_wrapper.py:47,55); a term with
+    weight 0 contributes exactly 0 to the loss and to every gradient, so it is not launched here, and a weight of 1 is
+    not multiplied in (both bit-identical for finite values)."""
+    total = None
+    for weight, term in terms:
+        if weight == 0:
+            continue
+        value = term()
+        if weight != 1:
+            value = weight * value
+        total = value if total is None else total + value
+    return total if total is not None else torch.zeros(())
+
+
 class _FrameWriter:
     """Writer side of SingleVideoINN.infer: PNG-encodes uint8 frames on a worker thread and writes them to
     ``save_images/out_{batch:04d}_{i:02d}.png`` or to the stdin of an ffmpeg process (reference lit_wrapper.py:96-103,117-124).
@@ -156,16 +172,18 @@ class SingleVideoINN(pl.LightningModule):
         with torch.cuda.stream(second):
             # reverse pass: (LR | z) -> HR
             hr_hat = self.inn(lr_z, rev=True)
-            bwd_loss = o.lambda_bwd_rec * loss.reconstruction(hr_hat, hr)
-            bwd_loss = bwd_loss + o.lambda_bwd_mmd * loss.mmd(hr_hat, hr, rev=True)
-            self.manual_backward(bwd_loss)
+            bwd_loss = _weighted_sum((o.lambda_bwd_rec, lambda: loss.reconstruction(hr_hat, hr)),
+                                     (o.lambda_bwd_mmd, lambda: loss.mmd(hr_hat, hr, rev=True)))
+            if bwd_loss.requires_grad:
+                self.manual_backward(bwd_loss)
 
         # forward pass: HR -> (LR | z)
         lr_z_hat = self.inn(hr)
-        fwd_loss = o.lambda_fwd_rec * loss.reconstruction(lr_z_hat[:, :o.lr_dims], lr)
-        fwd_loss = fwd_loss + o.lambda_fwd_mmd * loss.mmd(lr_z_hat, lr_z)
-        fwd_loss = fwd_loss + o.lambda_latent_nll * loss.latent_nll(lr_z_hat[:, o.lr_dims:])
-        self.manual_backward(fwd_loss)
+        fwd_loss = _weighted_sum((o.lambda_fwd_rec, lambda: loss.reconstruction(lr_z_hat[:, :o.lr_dims], lr)),
+                                 (o.lambda_fwd_mmd, lambda: loss.mmd(lr_z_hat, lr_z)),
+                                 (o.lambda_latent_nll, lambda: loss.latent_nll(lr_z_hat[:, o.lr_dims:])))
+        if fwd_loss.requires_grad:
+            self.manual_backward(fwd_loss)
 
         if second is not main:
             for t in (hr, lr, lr_z):
@@ -186,9 +204,10 @@ class SingleVideoINN(pl.LightningModule):
                 hr_hat_tcr = self.tcr(self.inn(plain, rev=True), rand)
                 tcr_loss = o.lambda_bwd_tcr / iters * loss.reconstruction(tcr_hr_hat, hr_hat_tcr)
                 self.manual_backward(tcr_loss)
+                tcr_loss = tcr_loss.detach()
 
         optim.step()
-        self.log('train', (fwd_loss + bwd_loss + tcr_loss).detach())
+        self.log('train', (fwd_loss.detach() + bwd_loss.detach().to(fwd_loss.device) + tcr_loss))
 
     def validation_step(self, batch, batch_idx):
         o = self.opt

@@ -111,6 +111,7 @@ _SIGS = {
                                           c_f, c_f, c_f, C.c_int, C.c_void_p]),
     'sininn_squeeze': (C.c_int, [c_f, I64x4, c_f, I64x4, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i,
                                  C.c_int, C.c_void_p]),
+    'sininn_squeeze_rows': (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i, C.c_void_p]),
     'sininn_permute_channels': (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int64, C.c_int, c_i, C.c_void_p]),
     'sininn_sqdiff_sum': (C.c_int, [c_f, I64x4, c_f, I64x4, C.c_int, C.c_int, C.c_int, C.c_int, c_f, C.c_void_p]),
     'sininn_sqdiff_bwd': (C.c_int, [c_f, I64x4, c_f, I64x4, C.c_int, C.c_int, C.c_int, C.c_int, c_f, C.c_float,

@@ -63,6 +63,8 @@ int lrelu_bwd_launch(float* g, int g_stride, const float* f, int f_stride, int64
 int irn_coupling_bwd_launch(const float* dy, int dy_stride, const float* vy, int vy_stride, const float* hval, int64_t M,
                             int Co, float clamp, int inverse, float* dG, float* dh, float* dv, int dv_stride,
                             hipStream_t st);
+int squeeze_rows_launch(const float* in, float* out, int B, int C, int H, int W, int levels, int inverse, const int* map,
+                        hipStream_t st);
 int frames_to_u8_launch(const float* in, const int64_t is[4], uint8_t* out, int B, int C, int H, int W, int wrap,
                         hipStream_t st);
 void profile_begin(int h, unsigned long long* stamps, int max_launches);
@@ -299,6 +301,11 @@ size_t sininn_wgrad_group_workspace_bytes(const sininn_wgrad_item* items, int n,
 int sininn_wgrad_group(const sininn_wgrad_item* items, int n, int B, int H, int W, int ksize, void* workspace,
                        size_t workspace_bytes, void* stream) {
   return wgrad_group_launch(items, n, B, H, W, ksize, workspace, workspace_bytes, ST(stream));
+}
+
+int sininn_squeeze_rows(const float* in, float* out, int B, int C, int H, int W, int levels, int inverse,
+                        const int* fine_map, void* stream) {
+  return squeeze_rows_launch(in, out, B, C, H, W, levels, inverse, fine_map, ST(stream));
 }
 
 int sininn_frames_to_u8(const float* in, const int64_t in_strides[4], uint8_t* out, int B, int C, int H, int W, int wrap,

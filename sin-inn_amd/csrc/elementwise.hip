@@ -657,11 +657,19 @@ __global__ void sample_windows_kernel(const uint8_t* __restrict__ hr_clip, const
   }
 }
 
+bool sample_windows_dense_try(const uint8_t* hr_clip, const uint8_t* lr_clip, const int* idx, int n, int T, int H, int W, int h,
+                              int w, int win, float* hr_out, const int64_t hs[4], float* lr_out, const int64_t ls[4],
+                              hipStream_t st);
+
 int sample_windows_launch(const uint8_t* hr_clip, const uint8_t* lr_clip, const int* idx, int n, int T, int H, int W,
                           int h, int w, int win, float* hr_out, const int64_t hs[4], float* lr_out,
                           const int64_t ls[4], hipStream_t st) {
   SININN_CHECK(hr_clip && lr_clip && idx && hr_out && lr_out && hs && ls, "sample_windows: null pointer");
   SININN_CHECK(n > 0 && T > 0 && H > 0 && W > 0 && h > 0 && w > 0 && win >= 0, "sample_windows: bad shape");
+  if (sample_windows_dense_try(hr_clip, lr_clip, idx, n, T, H, W, h, w, win, hr_out, hs, lr_out, ls, st)) {
+    SININN_LAUNCH_CHECK("sample_windows_dense");
+    return 0;
+  }
   const int64_t total = (int64_t)n * H * W * 3 + (int64_t)n * h * w * (2 * win + 1) * 4;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(sample_windows_kernel, dim3(blocks), dim3(256), 0, st, hr_clip, lr_clip, idx, n, T, H, W, h, w,

@@ -76,4 +76,139 @@ int frames_to_u8_launch(const float* in, const int64_t is[4], uint8_t* out, int 
   return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Squeeze / unsqueeze / channel permutation between two DENSE pixel-major tensors, gather form: every thread produces
+// four consecutive floats of the output (one 16-byte store) and computes where each comes from.  `map` (may be NULL) acts
+// on the channel index of the FINE tensor: forward  coarse[.., q*C + c] = fine[.., map[c]],
+//                                          inverse  fine[.., c] = coarse[.., q*C + map[c]]   (q = the 2x2 sub-position digits).
+// levels == 0 is the plain permutation out[.., c] = in[.., map[c]].  (IRevNetDownsampling + PermuteRandom, archs.py:28-38,65-68.)
+// ------------------------------------------------------------------------------------------------
+__global__ void squeeze_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int H, int W,
+                                    int levels, int inverse, const int* __restrict__ map, int64_t total4) {
+  const int CC = C << (2 * levels);
+  const int h = H >> levels, w = W >> levels;
+  const bool vec = (map == nullptr) && (C % 4 == 0);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t o = i * 4;
+    f32x4 val;
+    if (!inverse) {
+      // output = coarse [B][h][w][CC]
+      const int cc0 = (int)(o % CC);
+      int64_t pix = o / CC;
+      const int cx = (int)(pix % w); pix /= w;
+      const int cy = (int)(pix % h);
+      const int b = (int)(pix / h);
+      auto src = [&](int cc) -> int64_t {
+        int c = cc % C, r = cc / C, y = cy << levels, x = cx << levels;
+        for (int l = 0; l < levels; ++l) { const int q = r & 3; r >>= 2; y += (q >> 1) << l; x += (q & 1) << l; }
+        if (map) c = map[c];
+        return (((int64_t)b * H + y) * W + x) * C + c;
+      };
+      if (vec) val = *reinterpret_cast<const f32x4*>(in + src(cc0));
+      else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) val[j] = in[src(cc0 + j)];      // CC % 4 == 0: the four stay inside one coarse pixel
+      }
+    } else {
+      // output = fine [B][H][W][C]
+      auto src = [&](int64_t e) -> int64_t {
+        int c = (int)(e % C);
+        int64_t pix = e / C;
+        const int x = (int)(pix % W); pix /= W;
+        const int y = (int)(pix % H);
+        const int b = (int)(pix / H);
+        if (map) c = map[c];
+        int cc = c, mul = C;
+        for (int l = 0; l < levels; ++l) { cc += ((((y >> l) & 1) << 1) | ((x >> l) & 1)) * mul; mul <<= 2; }
+        return (((int64_t)b * h + (y >> levels)) * w + (x >> levels)) * CC + cc;
+      };
+      if (vec) val = *reinterpret_cast<const f32x4*>(in + src(o));
+      else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) val[j] = in[src(o + j)];
+      }
+    }
+    *reinterpret_cast<f32x4*>(out + o) = val;
+  }
+}
+
+int squeeze_rows_launch(const float* in, float* out, int B, int C, int H, int W, int levels, int inverse, const int* map,
+                        hipStream_t st) {
+  SININN_CHECK(in && out && B > 0 && C > 0 && H > 0 && W > 0 && levels >= 0 && levels <= 4, "squeeze_rows: bad arguments");
+  SININN_CHECK((H % (1 << levels)) == 0 && (W % (1 << levels)) == 0, "squeeze_rows: H=%d W=%d not divisible by 2^%d", H, W, levels);
+  const int64_t total = (int64_t)B * C * H * W;
+  SININN_CHECK(total % 4 == 0 && aligned16(in) && aligned16(out), "squeeze_rows: needs a multiple of 4 elements and 16-byte aligned tensors");
+  SININN_CHECK(levels > 0 || map != nullptr || true, "squeeze_rows");
+  SININN_CHECK(((C << (2 * levels)) % 4) == 0, "squeeze_rows: coarse channel count must be a multiple of 4");
+  const int64_t total4 = total / 4;
+  const int64_t blocks = (total4 + 255) / 256 < 16384 ? (total4 + 255) / 256 : 16384;
+  hipLaunchKernelGGL(squeeze_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, B, C, H, W, levels, inverse, map,
+                     total4);
+  SININN_LAUNCH_CHECK("squeeze_rows");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Frame-window sampler, dense pixel-major outputs (data.py:31-45): 16 clip bytes -> four float4 stores per thread for
+// the HR frames, one uchar4 -> float4 per (pixel, LR frame) for the window.  x / 255.f is a true division (bit-exact
+// with the reference's FloatTensor(...) / 255.).
+// ------------------------------------------------------------------------------------------------
+__global__ void sample_windows_dense_kernel(const uint8_t* __restrict__ hr_clip, const uint8_t* __restrict__ lr_clip,
+                                            const int* __restrict__ idx, int n, int T, int64_t hr_frame16, int64_t lr_pix,
+                                            int win, float* __restrict__ hr_out, float* __restrict__ lr_out,
+                                            int64_t hr_items) {
+  const int frames = 2 * win + 1;
+  const int64_t lr_items = (int64_t)n * lr_pix * frames;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hr_items + lr_items;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < hr_items) {
+      const int s = (int)(i / hr_frame16);
+      const int64_t j = i - (int64_t)s * hr_frame16;
+      int t = idx[s]; t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+      const uint4 raw = reinterpret_cast<const uint4*>(hr_clip)[(int64_t)t * hr_frame16 + j];
+      const unsigned wds[4] = {raw.x, raw.y, raw.z, raw.w};
+      f32x4* dst = reinterpret_cast<f32x4*>(hr_out) + i * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (float)((wds[q] >> (8 * k)) & 255u) / 255.f;
+        dst[q] = v;
+      }
+    } else {
+      const int64_t r = i - hr_items;
+      const int f = (int)(r % frames);
+      const int64_t sp = r / frames;                       // sample * lr_pix + pixel
+      const int s = (int)(sp / lr_pix);
+      const int64_t pix = sp - (int64_t)s * lr_pix;
+      int t = idx[s] - win + f; t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+      const unsigned raw = reinterpret_cast<const unsigned*>(lr_clip)[(int64_t)t * lr_pix + pix];
+      f32x4 v;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = (float)((raw >> (8 * k)) & 255u) / 255.f;
+      reinterpret_cast<f32x4*>(lr_out)[r] = v;            // out[s][pix][f*4 .. f*4+3]
+    }
+  }
+}
+
+bool sample_windows_dense_try(const uint8_t* hr_clip, const uint8_t* lr_clip, const int* idx, int n, int T, int H, int W, int h,
+                              int w, int win, float* hr_out, const int64_t hs[4], float* lr_out, const int64_t ls[4],
+                              hipStream_t st) {
+  const int lrc = (2 * win + 1) * 4;
+  const bool hr_dense = hs[1] == 1 && hs[3] == 3 && hs[2] == (int64_t)W * 3 && hs[0] == (int64_t)H * W * 3;
+  const bool lr_dense = ls[1] == 1 && ls[3] == lrc && ls[2] == (int64_t)w * lrc && ls[0] == (int64_t)h * w * lrc;
+  const int64_t frame_bytes = (int64_t)H * W * 3;
+  if (!hr_dense || !lr_dense || frame_bytes % 16 != 0 || !aligned16(hr_clip) || !aligned16(hr_out) || !aligned16(lr_out) ||
+      (reinterpret_cast<uintptr_t>(lr_clip) & 3u))
+    return false;
+  const int64_t hr_frame16 = frame_bytes / 16, lr_pix = (int64_t)h * w;
+  const int64_t hr_items = (int64_t)n * hr_frame16;
+  const int64_t items = hr_items + (int64_t)n * lr_pix * (2 * win + 1);
+  const int64_t blocks = (items + 255) / 256 < 16384 ? (items + 255) / 256 : 16384;
+  hipLaunchKernelGGL(sample_windows_dense_kernel, dim3((unsigned)blocks), dim3(256), 0, st, hr_clip, lr_clip, idx, n, T,
+                     hr_frame16, lr_pix, win, hr_out, lr_out, hr_items);
+  return true;
+}
+
 }  // namespace sininn

@@ -683,9 +683,11 @@ static bool g_wgrad_wino = true;       // Winograd weight gradient for 3x3 (test
 static bool g_wgrad_wino_th8 = false;  // test hook bit 2: 8-row pixel tiles in the Winograd weight gradient
 static bool g_wgrad_wino_kh2 = false;  // test hook bit 3: 8-wave blocks with an in-block k split (half the slabs; same kernel
                                        // time, but 3 % slower end to end when other streams' kernels co-run) -- off
+static int g_wgrad_group_mode = 1;     // 1: whole block (4 convs), 2: per half-coupling (2 convs); test hook bit 5 selects 2
 static bool g_wgrad_grouped = true;    // test hook bit 4 clears: the block executor issues one launch pair per conv (round-1 path)
-void wgrad_set_force16(int on) { g_wgrad_force16 = (on & 1) != 0; g_wgrad_wino = (on & 2) == 0; g_wgrad_wino_th8 = (on & 4) != 0; g_wgrad_wino_kh2 = (on & 8) != 0; g_wgrad_grouped = (on & 16) == 0; }
+void wgrad_set_force16(int on) { g_wgrad_force16 = (on & 1) != 0; g_wgrad_wino = (on & 2) == 0; g_wgrad_wino_th8 = (on & 4) != 0; g_wgrad_wino_kh2 = (on & 8) != 0; g_wgrad_grouped = (on & 16) == 0; g_wgrad_group_mode = (on & 32) ? 2 : 1; }
 bool wgrad_grouping_enabled() { return g_wgrad_grouped && g_wgrad_wino && !g_wgrad_force16; }
+int wgrad_group_mode() { return g_wgrad_group_mode; }
 
 static WgradPlan make_plan(int N, int Cin, int ksize, int B, int H, int W) {
   WgradPlan pl;

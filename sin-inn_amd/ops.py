@@ -170,8 +170,38 @@ def coupling_bwd(dy, dy_off, dy_stride, dy_map, vy, vy_off, vy_stride, vy_map, s
 
 
 # ---- index maps ----------------------------------------------------------------------------------
+_inverse_maps = {}
+
+
+def _inverse_map(m):
+    """Inverse permutation of a device int32 map, cached per tensor (the maps are persistent module buffers)."""
+    key = (m.data_ptr(), m.numel())
+    hit = _inverse_maps.get(key)
+    if hit is None or hit[0] is not m:
+        inv = torch.empty_like(m)
+        inv[m.long()] = torch.arange(m.numel(), dtype=m.dtype, device=m.device)
+        hit = _inverse_maps[key] = (m, inv)
+    return hit[1]
+
+
+def _dense_pixel_major(t):
+    b, c, h, w = t.shape
+    return t.stride() == (h * w * c, 1, w * c, c) or (c == 1 and t.is_contiguous())
+
+
 def squeeze(x, out, b, c, h, w, levels, inverse, chan_map=None, map_on_out=False):
     """x / out are 4-D (B,C,H,W)-shaped tensors of ANY strides (fine side has C,H,W; coarse side C*4^l,H/2^l,W/2^l)."""
+    # fast path: both tensors dense pixel-major and the map (if any) on the fine tensor's channels -> gather-form kernel
+    # with 16-byte stores.  Forward reads the fine side (map used as is); inverse writes it (scatter form -> inverse map).
+    fine_map_side = (chan_map is None) or levels == 0 or (map_on_out == bool(inverse))
+    if (fine_map_side and _dense_pixel_major(x) and _dense_pixel_major(out) and (b * c * h * w) % 4 == 0
+            and (c << (2 * levels)) % 4 == 0 and x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0):
+        gmap = chan_map
+        if chan_map is not None and map_on_out:
+            gmap = _inverse_map(chan_map)               # out[map[j]] = in[j]  <=>  out[j'] = in[inv[j']]
+        check(_lib.lib().sininn_squeeze_rows(ptr(x), ptr(out), b, c, h, w, levels, 1 if inverse else 0,
+                                             ptr(gmap, dtype=torch.int32), _stream()))
+        return
     check(_lib.lib().sininn_squeeze(ptr(x), strides4(x), ptr(out), strides4(out), b, c, h, w, levels,
                                     1 if inverse else 0, ptr(chan_map, dtype=torch.int32), 1 if map_on_out else 0,
                                     _stream()))

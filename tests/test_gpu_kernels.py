@@ -213,6 +213,50 @@ def test_squeeze_permute(env):
     assert torch.equal(zc.grad[0, :, 0, 0].cpu(), want)
 
 
+@pytest.mark.parametrize('c,levels', [(3, 2), (3, 1), (48, 1), (12, 2), (48, 0)])
+def test_squeeze_rows_fast_path_is_bit_exact(env, c, levels):
+    """The gather-form kernel for dense pixel-major tensors (16-byte stores) against the oracle's index formula: forward,
+    inverse, with the channel map on the fine side in read form (forward) and in written form (inverse), and the adjoints
+    autograd asks for."""
+    S, O, dev = env
+    from sin_inn_amd import ops
+    torch.manual_seed(c + levels)
+    b, h, w = 2, 8, 12
+    x = torch.randn(b, c, h, w)
+    want = x
+    for _ in range(levels):
+        want = O.squeeze_fwd(want)
+    xg = x.cuda().contiguous(memory_format=torch.channels_last)
+    f = 1 << levels
+    cc = c * f * f
+
+    def coarse_buf():
+        return torch.empty((b, h // f, w // f, cc), device=dev).permute(0, 3, 1, 2)
+
+    def fine_buf():
+        return torch.empty((b, h, w, c), device=dev).permute(0, 3, 1, 2)
+
+    assert ops._dense_pixel_major(xg) and ops._dense_pixel_major(coarse_buf())
+    out = coarse_buf()
+    ops.squeeze(xg, out, b, c, h, w, levels, False)
+    assert torch.equal(out.cpu(), want)
+    back = fine_buf()
+    ops.squeeze(out, back, b, c, h, w, levels, True)
+    assert torch.equal(back.cpu(), x)
+    perm = torch.randperm(c).to(torch.int32).cuda()
+    pl = perm.long().cpu()
+    # forward, map on the side READ (fine): coarse = squeeze(x[:, perm])
+    ops.squeeze(xg, out, b, c, h, w, levels, False, perm, False)
+    w2 = x[:, pl]
+    for _ in range(levels):
+        w2 = O.squeeze_fwd(w2)
+    assert torch.equal(out.cpu(), w2)
+    # inverse, map on the side WRITTEN (fine): fine[:, perm[c]] = unsqueeze(coarse)[:, c]
+    ops.squeeze(want.cuda().contiguous(memory_format=torch.channels_last), back, b, c, h, w, levels, True, perm, True)
+    w3 = torch.empty_like(x); w3[:, pl] = x
+    assert torch.equal(back.cpu(), w3)
+
+
 def test_losses(env, golden):
     S, O, dev = env
     import loss

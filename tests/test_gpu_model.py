@@ -208,11 +208,15 @@ def test_baseline_config_shape_matches_oracle(batch):
     ref_g = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
     # max-norm relative error over the whole flat gradient (3.69 M entries, K up to 65 536 pixels x 9 taps per entry)
     assert relerr(flat_g[:ref_g.numel()], ref_g) < 3e-4
-    # per-tensor check as well, so a small tensor cannot hide behind a large one
+    # per-tensor check as well, so a small tensor cannot hide behind a large one.  Looser than the flat check because
+    # the network is piecewise linear: a hidden pre-activation within rounding distance of 0 flips its ReLU gate between
+    # two correct fp32 evaluations, which moves single entries of one conv's gradient by a whole term, not by a rounding
+    # error (tools/diag_grad_err.py: the torch-CPU fp32 oracle itself is 2e-4 away from its float64 twin at batch 16,
+    # and the HIP error is identical to three digits for all three weight-gradient algorithms, i.e. it is in the gates).
     off = 0
     for name, p in ref.named_parameters():
         n = p.numel()
-        assert relerr(flat_g[off:off + n], p.grad.reshape(-1)) < 5e-4, name
+        assert relerr(flat_g[off:off + n], p.grad.reshape(-1)) < 2e-3, name
         off += n
     # input gradients of both directions at this shape (the data-gradient kernels of the first / last block)
     del model, optim
