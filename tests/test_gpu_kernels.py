@@ -405,28 +405,28 @@ def test_winograd_conv(env, cin, n, hw, cg):
         _lib.lib().sininn_conv_test_hooks(0, 0)
 
 
-def _winograd_conv_case(dev, ops, _lib, cin, n, hw):
+def _winograd_conv_case(dev, ops, _lib, cin, n, hw, nb=2):
     torch.manual_seed(cin + n)
     h, w = hw
     conv = torch.nn.Conv2d(cin, n, 3, padding=1)
-    x = torch.randn(2, cin, h, w)
+    x = torch.randn(nb, cin, h, w)
     want = conv(x)
     wf, bf, wd = ops.pack_conv(conv.weight.detach().cuda().contiguous(), conv.bias.detach().cuda().contiguous(), None, True,
                                wino_fwd=True, wino_dgrad=True)
     npk = ops.pad16(n)
     xg = nhwc(x)
     for mode, ref in ((_lib.CONV_LINEAR, want), (_lib.CONV_RELU, F.relu(want))):
-        out = torch.full((2, h, w, n), float('nan'), device=dev)
+        out = torch.full((nb, h, w, n), float('nan'), device=dev)
         ops.conv(in_=ops.ptr(xg), in_stride=cin, Cin=cin, w=ops.ptr(wf), bias=ops.ptr(bf), Np=npk, winograd=1,
-                 B=2, H=h, W=w, ksize=3, mode=mode, out=ops.ptr(out), out_stride=n, N=n)
+                 B=nb, H=h, W=w, ksize=3, mode=mode, out=ops.ptr(out), out_stride=n, N=n)
         assert relerr(nchw(out), ref) < RTOL
     # data gradient: d/dx sum(conv(x) * g) + addend
-    g = torch.randn(2, n, h, w)
+    g = torch.randn(nb, n, h, w)
     xin = x.clone().requires_grad_(True)
     conv(xin).backward(g)
-    add = torch.randn(2, h, w, cin, device=dev)
-    dx = torch.empty((2, h, w, cin), device=dev)
-    ops.conv(in_=ops.ptr(nhwc(g)), in_stride=n, Cin=n, w=ops.ptr(wd), Np=ops.pad32(cin), winograd=1, B=2, H=h, W=w, ksize=3,
+    add = torch.randn(nb, h, w, cin, device=dev)
+    dx = torch.empty((nb, h, w, cin), device=dev)
+    ops.conv(in_=ops.ptr(nhwc(g)), in_stride=n, Cin=n, w=ops.ptr(wd), Np=ops.pad32(cin), winograd=1, B=nb, H=h, W=w, ksize=3,
              mode=_lib.CONV_ADD, out=ops.ptr(dx), out_stride=cin, N=cin, addend=ops.ptr(add), addend_stride=cin)
     assert relerr(nchw(dx), xin.grad + nchw(add)) < RTOL
 
@@ -470,3 +470,30 @@ def test_bayer_demosaic_preview_is_byte_exact(env, scale, reduction):
     want = O.bayer_demosaic(hr.numpy(), scale, reduction)
     assert got.shape == (2, 32 // scale, 48 // scale, 3)
     assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize('cin,n,hw', [(24, 256, (64, 64)), (256, 48, (64, 64)), (96, 256, (32, 32)), (256, 192, (32, 32))])
+def test_conv_kernels_at_baseline_config_shapes(env, cin, n, hw):
+    """The LINEAR pieces of the step at BASELINE configs[1]'s own shapes (batch 16; level 0: 64x64, level 1: 32x32), with
+    the dispatch bench.py gets (no test hooks): 3x3 Winograd forward / data-gradient convs and the weight gradients (per
+    conv and grouped), against torch's conv2d and its autograd on the CPU.  These kernels are linear in their inputs, so
+    unlike the composed network (whose ReLU gates can flip between two fp32 evaluations) the max-norm bound of the path
+    holds at full size."""
+    S, O, dev = env
+    from sin_inn_amd import ops, _lib
+    torch.set_num_threads(min(16, len(__import__('os').sched_getaffinity(0))))
+    _winograd_conv_case(dev, ops, _lib, cin, n, hw, nb=16)
+    h, w = hw
+    torch.manual_seed(n)
+    for ksize in (3, 1):
+        conv = torch.nn.Conv2d(cin, n, ksize, padding=ksize // 2)
+        x = torch.randn(16, cin, h, w)
+        g = torch.randn(16, n, h, w) * 0.1
+        conv(x).backward(g)
+        xg, gg = nhwc(x), nhwc(g)
+        gw, gb = torch.zeros_like(conv.weight).cuda(), torch.zeros_like(conv.bias).cuda()
+        ops.wgrad(xg, 0, cin, cin, gg, n, n, 16, h, w, ksize, gw, gb)
+        assert relerr(gw, conv.weight.grad) < RTOL and relerr(gb, conv.bias.grad) < RTOL
+        gw2, gb2 = torch.zeros_like(gw), torch.zeros_like(gb)
+        ops.wgrad_group([(xg, 0, cin, cin, gg, 0, n, n, gw2, gb2)], 16, h, w, ksize)
+        assert relerr(gw2, conv.weight.grad) < RTOL and relerr(gb2, conv.bias.grad) < RTOL

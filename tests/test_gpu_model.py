@@ -15,6 +15,14 @@ def relerr(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
 
 
+def rel_l2(a, b):
+    """||a - b||_2 / ||b||_2: the metric for gradients at full size, where a handful of ReLU gates whose pre-activation lies
+    within rounding distance of 0 open in one fp32 evaluation and not in the other (each flip moves a few entries by a whole
+    term; the max-norm then measures the flips, the L2 norm the arithmetic)."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
 def make_opt(**kw):
     d = dict(scale=4, num_coupling=2, lr_window=1, architecture='SRF', gpu_ids=[0], rotation=5.0, translation=5.0,
              tcr_iters=2, lambda_fwd_rec=1.0, lambda_fwd_mmd=0.0, lambda_latent_nll=0.0, lambda_bwd_rec=1.0,
@@ -208,14 +216,17 @@ def test_baseline_config_shape_matches_oracle(batch):
     ref_g = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
     # max-norm relative error over the whole flat gradient (3.69 M entries, K up to 65 536 pixels x 9 taps per entry)
     assert relerr(flat_g[:ref_g.numel()], ref_g) < 3e-4
-    # per-tensor check as well, so a small tensor cannot hide behind a large one.  Looser than the flat check because
-    # the network is piecewise linear: a hidden pre-activation within rounding distance of 0 flips its ReLU gate between
-    # two correct fp32 evaluations, which moves single entries of one conv's gradient by a whole term, not by a rounding
-    # error (tools/diag_grad_err.py: the torch-CPU fp32 oracle itself is 2e-4 away from its float64 twin at batch 16,
-    # and the HIP error is identical to three digits for all three weight-gradient algorithms, i.e. it is in the gates).
+    assert rel_l2(flat_g[:ref_g.numel()], ref_g) < RTOL
+    # per-tensor check as well, so a small tensor cannot hide behind a large one: L2 at the path's tolerance; max-norm
+    # looser, because the network is piecewise linear: at this size (21 M hidden units at batch 2) a few tens of ReLU gates
+    # have a pre-activation within rounding distance of 0 and open in one correct fp32 evaluation but not in the other,
+    # which moves single entries by a whole term, not by a rounding error (tools/diag_grad_err.py: the torch-CPU fp32
+    # oracle itself is 2e-4 away from its float64 twin at batch 16, and the HIP error is identical to three digits for all
+    # three weight-gradient algorithms, i.e. it sits in the gates, not in the arithmetic).
     off = 0
     for name, p in ref.named_parameters():
         n = p.numel()
+        assert rel_l2(flat_g[off:off + n], p.grad.reshape(-1)) < 2e-4, name
         assert relerr(flat_g[off:off + n], p.grad.reshape(-1)) < 2e-3, name
         off += n
     # input gradients of both directions at this shape (the data-gradient kernels of the first / last block)
@@ -225,13 +236,19 @@ def test_baseline_config_shape_matches_oracle(batch):
     net.cuda()
     xg = hr_g.detach().clone().requires_grad_(True); xc = hr_c.clone().requires_grad_(True)
     wgt = torch.randn(batch, 192, 32, 32, generator=g)
-    (net(xg) * wgt.cuda()).sum().backward(); (ref(xc) * wgt).sum().backward()
-    assert relerr(xg.grad, xc.grad) < RTOL
+    yg, yc = net(xg), ref(xc)
+    assert relerr(yg, yc) < RTOL                                   # forward values: max-norm at the path's tolerance
+    (yg * wgt.cuda()).sum().backward(); (yc * wgt).sum().backward()
+    # input gradients: a flipped gate changes dx in one 3x3 neighbourhood by a whole term -> L2 5e-4, max-norm 2e-2 (the
+    # linear kernels themselves hold 1e-4 in max-norm at these shapes: test_conv_kernels_at_baseline_config_shapes)
+    assert rel_l2(xg.grad, xc.grad) < 5e-4 and relerr(xg.grad, xc.grad) < 2e-2
     zin = torch.cat((lr_c, z), 1)
     zg = zin.cuda().requires_grad_(True); zc = zin.clone().requires_grad_(True)
     w2 = torch.randn(batch, 3, 256, 256, generator=g)
-    (net(zg, rev=True) * w2.cuda()).sum().backward(); (ref(zc, rev=True) * w2).sum().backward()
-    assert relerr(zg.grad, zc.grad) < RTOL
+    hg, hc = net(zg, rev=True), ref(zc, rev=True)
+    assert relerr(hg, hc) < RTOL
+    (hg * w2.cuda()).sum().backward(); (hc * w2).sum().backward()
+    assert rel_l2(zg.grad, zc.grad) < 5e-4 and relerr(zg.grad, zc.grad) < 2e-2
     sin_inn_amd.modules.join_side_streams()
 
 
