@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SININN_ABI_VERSION 1
+#define SININN_ABI_VERSION 2
 #define SININN_HIDDEN 256 /* hidden width of subnet_conv / subnet_conv_1x1, archs.py:12,16 */
 
 int sininn_version(void);
@@ -48,6 +48,12 @@ const char* sininn_last_error(void);
 int sininn_pack_conv_weights(const float* w_oihw, const float* bias, int N, int Cin, int ksize,
                              const int* colmap, int Np, float* w_fwd, float* b_fwd,
                              int Cdp, float* w_dgrad, void* stream);
+
+/* bf16 packs for the mixed-precision convs: wb_fwd [taps][Np][Kp] (Kp = Cin rounded up to 16, zero filled), b_fwd [Np]
+ * fp32 (packed bias), wb_dgrad [taps][Cdp][Kd] (Kd = N rounded up to 16; flipped taps).  Either destination may be NULL. */
+int sininn_pack_conv_weights_bf16(const float* w_oihw, const float* bias, int N, int Cin, int ksize,
+                                  const int* colmap, int Np, void* wb_fwd, float* b_fwd,
+                                  int Cdp, void* wb_dgrad, void* stream);
 
 /* Winograd F(2x2,3x3) filter transform of a 3x3 conv weight (U = G g G^T), same row / column conventions as
  * sininn_pack_conv_weights with the tap axis replaced by the 16 transform positions:
@@ -120,6 +126,14 @@ typedef struct sininn_conv_args {
   unsigned long long* stamp;                       /* optional device words {start, end}: every block folds its entry /
                                                       exit time (wall-clock ticks, sininn_wall_clock_khz) in with atomic
                                                       min / max; initialise to {~0ull >> 1, 0}                       */
+  /* ---- mixed-precision path (ABI version 2): bf16 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulate + epilogue ---- */
+  int w_bf16;                                      /* w is a bf16 pack [taps][Np][Kp] (sininn_pack_conv_weights_bf16): selects
+                                                      the bf16 kernel; the fields below apply only then                   */
+  int in_bf16;                                     /* `in` holds bf16 (stride in elements, Cin % 8 == 0); else fp32, converted
+                                                      to bf16 (round to nearest even) while it is staged                  */
+  int out_bf16;                                    /* `out` holds bf16 (RELU / LINEAR / MASK modes; an fp32-input conv must
+                                                      set it); else fp32 through the mode's regular epilogue              */
+  int mask_bf16;                                   /* MASK mode: `mask` holds bf16                                        */
 } sininn_conv_args;
 
 int sininn_conv(const sininn_conv_args* args, void* stream);
@@ -142,6 +156,8 @@ typedef struct sininn_wgrad_item {
   const float* in;   int in_stride;   int Cin;     /* conv input  [M][in_stride], Cin % 4 == 0                      */
   const float* dout; int dout_stride; int N;       /* output gradient [M][dout_stride], N % 4 == 0                  */
   float* gw; float* gb;                            /* OIHW weight gradient (+=), bias gradient (+=, may be NULL)    */
+  int in_bf16, dout_bf16;                          /* mixed-precision path: the operand is stored as bf16 (pointer cast,
+                                                      stride in elements); the gradient accumulates in fp32          */
 } sininn_wgrad_item;
 size_t sininn_wgrad_group_workspace_bytes(const sininn_wgrad_item* items, int n, int B, int H, int W, int ksize);
 int sininn_wgrad_group(const sininn_wgrad_item* items, int n, int B, int H, int W, int ksize,
@@ -205,6 +221,10 @@ typedef struct sininn_glow_args {
   const float* dout; const float* gld; float* dx;
   int skip_dx;                           /* backward: the caller does not need dx (first block of a pass): the last data-
                                             gradient conv is skipped; dx must still be a valid buffer (partly written) */
+  int dtype;                             /* 0: fp32 subnets (f32 MFMA, Winograd for 3x3).  1: mixed precision -- the conv
+                                            subnets run on bf16 MFMA with fp32 accumulation (packs from
+                                            sininn_pack_conv_weights_bf16, hidden tensors stored as bf16), the flow tensors,
+                                            the coupling arithmetic, log-det and all gradients w.r.t. parameters stay fp32 */
 } sininn_glow_args;
 
 /* Live timing for bench.py: between begin and end, every forward 3x3 coupling conv (conv2 + affine epilogue) of the

@@ -136,6 +136,10 @@ class SingleVideoINN(pl.LightningModule):
         self.save_hyperparameters()
         self.opt = opt
         self.inn = {'SRF': UncondSRFlow, 'IRN': InvRescaleNet}[opt.architecture](c, h, w, opt)
+        if getattr(opt, 'precision', 'fp32') != 'fp32':
+            if not hasattr(self.inn, 'set_precision'):
+                raise NotImplementedError(f'--precision {opt.precision} is implemented for the SRF architecture only')
+            self.inn.set_precision(opt.precision)
         n_params = sum(p.numel() for p in self.inn.parameters())
         logging.info(f'Created model with {n_params / 1e6:.2f}M parameters. Using GPUs {opt.gpu_ids}')
         self.tcr = TCR(opt.rotation, opt.translation)

@@ -52,6 +52,8 @@ _OPTIONS = [
     (('-t', '--temp',), dict(type=float, default=0.8, help='latent sampling temperature at test time')),
     (('--lr_dims',), dict(type=int, default=-1, help='internal: LR channels')),
     (('--z_dims',), dict(type=int, default=-1, help='internal: latent channels')),
+    (('--precision',), dict(choices=['fp32', 'bf16'], default='fp32',
+                            help='fp32: the reference arithmetic; bf16: conv subnets on bf16 MFMA (fp32 accumulate), fp32 flow')),
     (('--pixel_mode',), dict(choices=['clamp', 'wrap'], default='clamp',
                              help='test: float->uint8 conversion; wrap = the reference ToPILImage wrap-around')),
     (('--save_images',), dict(default=None, help='test: write PNG frames to this directory instead of the ffmpeg pipe')),

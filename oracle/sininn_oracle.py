@@ -73,6 +73,21 @@ def make_subnet(c_in, c_out, ksize):
                          nn.Conv2d(HIDDEN, c_out, ksize, padding=pad))
 
 
+def bf16_round(t):
+    """Round to bf16 (nearest even) and back, with a straight-through gradient: the checker's model of a bf16 operand."""
+    return t + (t.to(torch.bfloat16).to(t.dtype) - t).detach()
+
+
+def run_subnet(seq, x, emulate_bf16=False):
+    """The conv subnet (archs.py:11-17).  emulate_bf16 models the mixed-precision HIP path: inputs, weights and the
+    hidden tensor are rounded to bf16, every product is accumulated in fp32, bias / ReLU / output stay fp32."""
+    if not emulate_bf16:
+        return seq(x)
+    c1, c2 = seq[0], seq[2]
+    h = F.relu(F.conv2d(bf16_round(x), bf16_round(c1.weight), c1.bias, padding=c1.padding))
+    return F.conv2d(bf16_round(h), bf16_round(c2.weight), c2.bias, padding=c2.padding)
+
+
 # ----------------------------------------------------------------------------------------------
 # GLOW coupling block (FrEIA GLOWCouplingBlock, SURVEY Appendix A; called at archs.py:61-64)
 # ----------------------------------------------------------------------------------------------
@@ -90,23 +105,25 @@ class GlowBlock(nn.Module):
         self.s1 = make_subnet(self.l1, 2 * self.l2, ksize)
         self.s2 = make_subnet(self.l2, 2 * self.l1, ksize)
         self.last_jac = None
+        self.emulate_bf16 = False        # checker for the mixed-precision HIP path (not a reference feature)
 
     def forward(self, x, rev=False):
         x1, x2 = x[:, :self.l1], x[:, self.l1:]
+        bf = self.emulate_bf16
         if not rev:
-            r2 = self.s2(x2)
+            r2 = run_subnet(self.s2, x2, bf)
             s2, t2 = r2[:, :self.l1], r2[:, self.l1:]
             y1 = torch.exp(log_e(s2, self.clamp)) * x1 + t2
-            r1 = self.s1(y1)
+            r1 = run_subnet(self.s1, y1, bf)
             s1, t1 = r1[:, :self.l2], r1[:, self.l2:]
             y2 = torch.exp(log_e(s1, self.clamp)) * x2 + t1
             self.last_jac = (log_e(s1, self.clamp).sum(dim=(1, 2, 3))
                              + log_e(s2, self.clamp).sum(dim=(1, 2, 3)))
         else:
-            r1 = self.s1(x1)
+            r1 = run_subnet(self.s1, x1, bf)
             s1, t1 = r1[:, :self.l2], r1[:, self.l2:]
             y2 = (x2 - t1) / torch.exp(log_e(s1, self.clamp))
-            r2 = self.s2(y2)
+            r2 = run_subnet(self.s2, y2, bf)
             s2, t2 = r2[:, :self.l1], r2[:, self.l1:]
             y1 = (x1 - t2) / torch.exp(log_e(s2, self.clamp))
             self.last_jac = -(log_e(s1, self.clamp).sum(dim=(1, 2, 3))

@@ -33,6 +33,7 @@ class ConvArgs(C.Structure):
         ('mask', c_f), ('mask_stride', C.c_int),
         ('addend', c_f), ('addend_stride', C.c_int), ('addend_map', c_i),
         ('stamp', C.c_void_p),
+        ('w_bf16', C.c_int), ('in_bf16', C.c_int), ('out_bf16', C.c_int), ('mask_bf16', C.c_int),
     ]
 
 
@@ -49,13 +50,13 @@ class GlowArgs(C.Structure):
                 ('x', c_f), ('out', c_f), ('dst_map', c_i), ('logdet', c_f),
                 ('s1', SubnetArgs), ('s2', SubnetArgs),
                 ('saved', c_f), ('scratch', C.c_void_p), ('scratch_bytes', C.c_size_t),
-                ('dout', c_f), ('gld', c_f), ('dx', c_f), ('skip_dx', C.c_int)]
+                ('dout', c_f), ('gld', c_f), ('dx', c_f), ('skip_dx', C.c_int), ('dtype', C.c_int)]
 
 
 class WgradItem(C.Structure):
     """Mirror of sininn_wgrad_item."""
     _fields_ = [('inp', c_f), ('in_stride', C.c_int), ('Cin', C.c_int), ('dout', c_f), ('dout_stride', C.c_int),
-                ('N', C.c_int), ('gw', c_f), ('gb', c_f)]
+                ('N', C.c_int), ('gw', c_f), ('gb', c_f), ('in_bf16', C.c_int), ('dout_bf16', C.c_int)]
 
 
 class PackDesc(C.Structure):
@@ -71,6 +72,8 @@ _SIGS = {
     'sininn_version': (C.c_int, []),
     'sininn_last_error': (C.c_char_p, []),
     'sininn_pack_conv_weights': (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, c_i, C.c_int, c_f, c_f, C.c_int, c_f, C.c_void_p]),
+    'sininn_pack_conv_weights_bf16': (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, c_i, C.c_int, C.c_void_p, c_f, C.c_int,
+                                               C.c_void_p, C.c_void_p]),
     'sininn_pack_winograd': (C.c_int, [c_f, C.c_int, C.c_int, c_i, C.c_int, c_f, C.c_int, c_f, C.c_void_p]),
     'sininn_pack_work_items': (C.c_int, [C.POINTER(PackDesc)]),
     'sininn_pack_batch': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -150,7 +153,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(handle, name)          # AttributeError if the ABI lost a symbol
             fn.restype, fn.argtypes = res, args
-        if handle.sininn_version() != 1:
+        if handle.sininn_version() != 2:
             raise ImportError('libsininn.so ABI version mismatch')
         _lib = handle
     return _lib

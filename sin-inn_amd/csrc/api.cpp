@@ -65,6 +65,8 @@ int irn_coupling_bwd_launch(const float* dy, int dy_stride, const float* vy, int
                             hipStream_t st);
 int squeeze_rows_launch(const float* in, float* out, int B, int C, int H, int W, int levels, int inverse, const int* map,
                         hipStream_t st);
+int pack_bf16_launch(const float* w, const float* bias, int N, int Cin, int ksize, const int* colmap, int Np, void* wb_fwd,
+                     float* b_fwd, int Cdp, void* wb_dgrad, hipStream_t st);
 int frames_to_u8_launch(const float* in, const int64_t is[4], uint8_t* out, int B, int C, int H, int W, int wrap,
                         hipStream_t st);
 void profile_begin(int h, unsigned long long* stamps, int max_launches);
@@ -306,6 +308,11 @@ int sininn_wgrad_group(const sininn_wgrad_item* items, int n, int B, int H, int 
 int sininn_squeeze_rows(const float* in, float* out, int B, int C, int H, int W, int levels, int inverse,
                         const int* fine_map, void* stream) {
   return squeeze_rows_launch(in, out, B, C, H, W, levels, inverse, fine_map, ST(stream));
+}
+
+int sininn_pack_conv_weights_bf16(const float* w_oihw, const float* bias, int N, int Cin, int ksize, const int* colmap, int Np,
+                                  void* wb_fwd, float* b_fwd, int Cdp, void* wb_dgrad, void* stream) {
+  return pack_bf16_launch(w_oihw, bias, N, Cin, ksize, colmap, Np, wb_fwd, b_fwd, Cdp, wb_dgrad, ST(stream));
 }
 
 int sininn_frames_to_u8(const float* in, const int64_t in_strides[4], uint8_t* out, int B, int C, int H, int W, int wrap,

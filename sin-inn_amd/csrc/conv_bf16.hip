@@ -1,0 +1,382 @@
+// bf16 implicit-GEMM convolution on v_mfma_f32_32x32x16_bf16 (fp32 accumulation) for the mixed-precision path of
+// BASELINE configs[3] / [4]: the conv subnets (archs.py:11-17) compute in bf16, the invertible flow itself stays fp32.
+//
+//   * operands: the input is either fp32 (a half of the flow tensor / the coupling-tail gradient: converted to bf16
+//     with round-to-nearest-even while it is staged) or bf16 (the hidden tensor h / its gradient dh, which only the
+//     executor's own kernels touch and which therefore live in HBM as bf16: half the bytes of the 67..600 MB round
+//     trip); weights are packed bf16 [tap][column][K] once per optimiser step; accumulation and every epilogue
+//     (bias, ReLU, affine coupling + log-det, ReLU mask, skip-gradient add) run in fp32.
+//   * block = 8 x 16 output pixels x BN = 64 * NT columns, four waves as 2 (pixel rows) x 2 (columns); a wave owns
+//     2 x NT accumulator tiles of 32 x 32 (lane = column, 16 registers = pixel rows), i.e. 64 pixels x 32 NT columns.
+//   * K loop = channel chunk (CK = 32 or 16) x tap, like the fp32 direct kernel: the halo tile of a chunk is staged once
+//     and shifted LDS addresses serve the nine taps; weights of (chunk, tap) are double-buffered; one barrier per
+//     iteration.  All fragment reads are 16-byte ds_read_b128 of 8 consecutive k: pixel / column stride = 2 CK + 16
+//     bytes and an image-row pitch that is a multiple of 256 bytes make every hardware lane group of the read
+//     ({0-3,12-15,20-27}, ...: MI355X_MICROARCH.md, LDS table) hit 16 distinct 4-bank slots.
+//   * epilogue: accumulators -> fp32 LDS tile T[pixel][BN + 4] -> the shared float4 epilogue of the fp32 kernels
+//     (coupling / add / fused coupling backward), or the bf16-output epilogues here (ReLU -> h, mask -> dh).
+#include "conv_mfma_impl.h"
+
+namespace sininn {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvDevB {
+  ConvDev c;                 // fp32-side description (epilogue operands, shapes); c.in / c.w / c.out are unused when the
+  const void* in;            // typed pointers below replace them
+  const __bf16* w;           // [taps][Np][Kp] bf16
+  __bf16* out_b;             // bf16 output (RELU / LINEAR / MASK modes with out_bf16)
+  const __bf16* mask_b;      // bf16 ReLU mask source (MASK mode with out_bf16)
+  int Kp;                    // channels of the weight pack (Cin rounded up to a multiple of 16)
+  int in_bf16, out_bf16;
+};
+
+template <int CK> struct BfGeom {
+  static constexpr int PIXB = CK * 2 + 16;                               // bytes per staged pixel / weight column
+  static constexpr int pitch(int iw) { return (iw * PIXB + 255) / 256 * 256; }
+};
+
+// bf16-output epilogues: T[pixel][BN+4] fp32 -> 8 channels (16 bytes) per store
+template <int BN>
+__device__ __forceinline__ void epilogue_bf16(const ConvDevB& q, const float* T, int b, int y0, int x0, int n0, int tid) {
+  const ConvDev& p = q.c;
+  constexpr int TS = BN + 4, Q = BN / 8;
+  for (int idx = tid; idx < 128 * Q; idx += 256) {
+    const int pl = idx / Q, q8 = idx - pl * Q;
+    const int col = n0 + q8 * 8;
+    const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+    if (col < p.N && gy < p.H && gx < p.W) {               // N % 8 == 0 is checked on the host
+      const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
+      f32x4 a = *reinterpret_cast<const f32x4*>(T + pl * TS + q8 * 8);
+      f32x4 c = *reinterpret_cast<const f32x4*>(T + pl * TS + q8 * 8 + 4);
+      if (p.mode == SININN_CONV_RELU || p.mode == SININN_CONV_LINEAR) {
+        if (p.bias) {
+          a += *reinterpret_cast<const f32x4*>(p.bias + col);
+          c += *reinterpret_cast<const f32x4*>(p.bias + col + 4);
+        }
+        if (p.mode == SININN_CONV_RELU) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { a[j] = fmaxf(a[j], 0.f); c[j] = fmaxf(c[j], 0.f); }
+        }
+      } else {                                             // SININN_CONV_MASK: gradient through the ReLU of h
+        const bf16x8 mk = *reinterpret_cast<const bf16x8*>(q.mask_b + pix * p.mask_stride + col);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          a[j] = ((float)mk[j] > 0.f) ? a[j] : 0.f;
+          c[j] = ((float)mk[4 + j] > 0.f) ? c[j] : 0.f;
+        }
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { o[j] = (__bf16)a[j]; o[4 + j] = (__bf16)c[j]; }
+      *reinterpret_cast<bf16x8*>(q.out_b + pix * p.out_stride + col) = o;
+    }
+  }
+}
+
+template <int KS, int CK, int NT, int HT, bool IN_BF16>
+__global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvDevB q) {
+  const ConvDev& p = q.c;
+  constexpr int HALO = KS / 2, IW = 16 + 2 * HALO, IH = 8 + 2 * HALO, NPIX_IN = IH * IW, TAPS = KS * KS;
+  constexpr int BN = 64 * NT;
+  constexpr int PIXB = BfGeom<CK>::PIXB, PITCH = BfGeom<CK>::pitch(IW);
+  constexpr int IN_BYTES = IH * PITCH, W_BYTES = BN * PIXB;
+  // staging work items: input = (pixel, 4 fp32 channels -> 8 bytes) or (pixel, 8 bf16 channels -> 16 bytes)
+  constexpr int IN_PER_PIX = IN_BF16 ? CK / 8 : CK / 4;
+  constexpr int IN_ITEMS = (NPIX_IN * IN_PER_PIX + 255) / 256;
+  constexpr int W_PER_COL = CK / 8;                                      // 16-byte pieces per weight column
+  constexpr int W_ITEMS = (BN * W_PER_COL + 255) / 256;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+  unsigned char* const in_lds0 = smem_b;
+  unsigned char* const in_lds1 = smem_b + IN_BYTES;
+  unsigned char* const w_lds0 = smem_b + 2 * IN_BYTES;
+  unsigned char* const w_lds1 = w_lds0 + W_BYTES;
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  int bid = blockIdx.x;
+  const int tx = bid % p.tiles_x; bid /= p.tiles_x;
+  const int ty = bid % p.tiles_y;
+  const int b = bid / p.tiles_y;
+  const int y0 = ty * 8, x0 = tx * 16;
+  const int n0 = blockIdx.y * BN;
+
+  // ---- staging descriptors ---------------------------------------------------------------------------------------
+  int in_goff[IN_ITEMS], in_loff[IN_ITEMS];
+#pragma unroll
+  for (int i = 0; i < IN_ITEMS; ++i) {
+    const int f = tid + 256 * i;
+    const int pix = f / IN_PER_PIX, part = f - pix * IN_PER_PIX;
+    const int py = pix / IW, px = pix - py * IW;
+    const int gy = y0 + py - HALO, gx = x0 + px - HALO;
+    const bool inside = pix < NPIX_IN;
+    const bool inimg = inside && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    in_loff[i] = inside ? (py * PITCH + px * PIXB + part * (IN_BF16 ? 16 : 8)) : -1;
+    in_goff[i] = inimg ? (((b * p.H + gy) * p.W + gx) * p.in_stride + part * (IN_BF16 ? 8 : 4)) : -1;   // elements
+  }
+  int w_goff[W_ITEMS], w_loff[W_ITEMS];
+#pragma unroll
+  for (int i = 0; i < W_ITEMS; ++i) {
+    const int f = tid + 256 * i;
+    const int col = f / W_PER_COL, part = f - col * W_PER_COL;
+    const bool inside = col < BN;
+    w_loff[i] = inside ? (col * PIXB + part * 16) : -1;
+    w_goff[i] = (inside && (n0 + col) < p.Np) ? ((n0 + col) * q.Kp + part * 8) : -1;                    // elements
+  }
+  const int nchunks = q.Kp / CK;
+  const int nit = nchunks * TAPS;
+
+  typedef typename std::conditional<IN_BF16, bf16x8, f32x4>::type in_reg_t;
+  in_reg_t in_reg[IN_ITEMS];
+  bf16x8 w_reg[W_ITEMS];
+  auto load_in = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < IN_ITEMS; ++i) {
+      if constexpr (IN_BF16) {
+        bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int part = (tid + 256 * i) % IN_PER_PIX;
+        const bool live = in_goff[i] >= 0 && chunk * CK + part * 8 < p.Cin;     // Cin % 8 == 0 (host check)
+        in_reg[i] = live ? *reinterpret_cast<const bf16x8*>(static_cast<const __bf16*>(q.in) + in_goff[i] + chunk * CK) : z;
+      } else {
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const int part = (tid + 256 * i) % IN_PER_PIX;
+        const bool live = in_goff[i] >= 0 && chunk * CK + part * 4 < p.Cin;     // Cin % 4 == 0 (host check)
+        in_reg[i] = live ? *reinterpret_cast<const f32x4*>(static_cast<const float*>(q.in) + in_goff[i] + chunk * CK) : z;
+      }
+    }
+  };
+  auto store_in = [&](unsigned char* dst) {
+#pragma unroll
+    for (int i = 0; i < IN_ITEMS; ++i)
+      if (in_loff[i] >= 0) {
+        if constexpr (IN_BF16) {
+          *reinterpret_cast<bf16x8*>(dst + in_loff[i]) = in_reg[i];
+        } else {
+          bf16x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = (__bf16)in_reg[i][j];
+          *reinterpret_cast<bf16x4*>(dst + in_loff[i]) = v;
+        }
+      }
+  };
+  auto load_w = [&](int it) {
+    const int chunk = it / TAPS, tap = it - chunk * TAPS;
+#pragma unroll
+    for (int i = 0; i < W_ITEMS; ++i) {
+      bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      w_reg[i] = (w_goff[i] >= 0) ? *reinterpret_cast<const bf16x8*>(q.w + (size_t)tap * p.Np * q.Kp + w_goff[i] + chunk * CK) : z;
+    }
+  };
+  auto store_w = [&](unsigned char* dst) {
+#pragma unroll
+    for (int i = 0; i < W_ITEMS; ++i)
+      if (w_loff[i] >= 0) *reinterpret_cast<bf16x8*>(dst + w_loff[i]) = w_reg[i];
+  };
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+
+  // A fragment of lane (r, h) for row tile m: pixel (row 4 wm + 2 m + (r >> 4), column r & 15), channels 8 h .. 8 h + 7
+  int a_off[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) a_off[m] = (4 * wm + 2 * m + (r >> 4)) * PITCH + (r & 15) * PIXB + h * 16;
+  const int b_off = (wn * NT * 32 + r) * PIXB + h * 16;
+
+  load_in(0);
+  load_w(0);
+  store_in(in_lds0);
+  store_w(w_lds0);
+  if (nit > 1) load_w(1);
+  if (nchunks > 1) load_in(1);
+  __syncthreads();
+
+  for (int it = 0; it < nit; ++it) {
+    const int chunk = it / TAPS, tap = it - chunk * TAPS;
+    // stage the next iteration's weights (and, at the last tap of a chunk, the next chunk's halo tile) into the buffers
+    // nobody reads during this iteration; then put the loads after that in flight
+    if (it + 1 < nit) store_w(((it + 1) & 1) ? w_lds1 : w_lds0);
+    if (tap == TAPS - 1 && chunk + 1 < nchunks) store_in(((chunk + 1) & 1) ? in_lds1 : in_lds0);
+    if (it + 2 < nit) load_w(it + 2);
+    if (tap == TAPS - 1 && chunk + 2 < nchunks) load_in(chunk + 2);
+
+    const unsigned char* A = ((chunk & 1) ? in_lds1 : in_lds0) + (tap / KS) * PITCH + (tap % KS) * PIXB;
+    const unsigned char* B = (it & 1) ? w_lds1 : w_lds0;
+#pragma unroll
+    for (int ks = 0; ks < CK / 16; ++ks) {
+      bf16x8 af[2], bf[NT];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) af[m] = *reinterpret_cast<const bf16x8*>(A + a_off[m] + ks * 32);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const bf16x8*>(B + b_off + n * 32 * PIXB + ks * 32);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- accumulators -> T[pixel][BN + 4]; D layout: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) ----------
+  constexpr int TS = BN + 4;
+  float* const T = reinterpret_cast<float*>(smem_b);
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int pl = wm * 64 + m * 32 + row;
+        T[pl * TS + (wn * NT + n) * 32 + r] = acc[m][n][e];
+      }
+  __syncthreads();
+  if (q.out_bf16) {
+    epilogue_bf16<BN>(q, T, b, y0, x0, n0, tid);
+  } else {
+    __shared__ float red[4];
+    conv_epilogue_tile<8, BN, HT, 256>(p, T, b, y0, x0, n0, tid, red);
+  }
+}
+
+template <int KS, int CK, int NT, int HT, bool IN_BF16>
+static int launch_one(const ConvDevB& q, hipStream_t st) {
+  constexpr int HALO = KS / 2, IW = 16 + 2 * HALO, IH = 8 + 2 * HALO, BN = 64 * NT;
+  constexpr size_t lds_main = 2 * (size_t)IH * BfGeom<CK>::pitch(IW) + 2 * (size_t)BN * BfGeom<CK>::PIXB;
+  constexpr size_t lds_epi = (size_t)128 * (BN + 4) * sizeof(float);
+  constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  static_assert(lds <= 160 * 1024, "LDS tile too large");
+  auto k = conv_bf16_kernel<KS, CK, NT, HT, IN_BF16>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) { set_error("conv_bf16: cannot raise LDS limit to %zu", lds); return 1; }
+  dim3 grid(q.c.tiles_x * q.c.tiles_y * q.c.B, (q.c.Np + BN - 1) / BN);
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, q);
+  SININN_LAUNCH_CHECK("conv_bf16");
+  return 0;
+}
+
+template <int KS, int CK, int NT>
+static int launch_ht(const ConvDevB& q, hipStream_t st) {
+  const bool ht16 = q.c.col_tile == 32;            // coupling interleave half-width (irrelevant for the other modes)
+  if (q.in_bf16) return ht16 ? launch_one<KS, CK, NT, 16, true>(q, st) : launch_one<KS, CK, NT, 8, true>(q, st);
+  // fp32 inputs only feed the bf16-output convs of the path (cond -> h, dr -> dh): the coupling half-width is irrelevant
+  SININN_CHECK(q.out_bf16, "conv_bf16: an fp32-input conv must have a bf16 output");
+  return launch_one<KS, CK, NT, 8, false>(q, st);
+}
+
+template <int KS>
+static int launch_ks(const ConvDevB& q, hipStream_t st) {
+  const bool ck32 = q.Kp % 32 == 0;
+  const bool wide = q.c.Np > 64;                   // 128-column blocks unless the layer has at most 64 columns
+  if (ck32) return wide ? launch_ht<KS, 32, 2>(q, st) : launch_ht<KS, 32, 1>(q, st);
+  return wide ? launch_ht<KS, 16, 2>(q, st) : launch_ht<KS, 16, 1>(q, st);
+}
+
+// a->w: bf16 pack [taps][Np][Kp], Kp = Cin rounded up to 16; a->in: fp32 or (in_bf16) bf16; a->out: fp32 or (out_bf16) bf16
+int conv_bf16_launch(const sininn_conv_args* a, hipStream_t st) {
+  SININN_CHECK(a->ksize == 1 || a->ksize == 3, "conv_bf16: ksize %d not in {1,3}", a->ksize);
+  SININN_CHECK(a->Cin > 0 && a->Cin % 8 == 0, "conv_bf16: Cin=%d must be a positive multiple of 8", a->Cin);
+  SININN_CHECK(a->Np > 0 && a->Np % 16 == 0, "conv_bf16: Np=%d must be a positive multiple of 16", a->Np);
+  SININN_CHECK(a->B > 0 && a->H > 0 && a->W > 0, "conv_bf16: bad image shape");
+  SININN_CHECK((long)a->B * a->H * a->W * (long)(a->in_stride > a->out_stride ? a->in_stride : a->out_stride) < (1l << 31),
+               "conv_bf16: tensor too large for 32-bit pixel offsets");
+  SININN_CHECK(a->in && a->w && a->out && aligned16(a->in) && aligned16(a->w) && aligned16(a->out), "conv_bf16: null / unaligned tensor");
+  SININN_CHECK(a->in_stride >= a->Cin && a->in_stride % (a->in_bf16 ? 8 : 4) == 0, "conv_bf16: bad input stride %d", a->in_stride);
+  const bool couple = a->mode == SININN_CONV_COUPLE_FWD || a->mode == SININN_CONV_COUPLE_INV;
+  const bool cbwd = a->mode == SININN_CONV_ADD_CBWD_FWD || a->mode == SININN_CONV_ADD_CBWD_INV;
+  if (a->out_bf16) {
+    SININN_CHECK(a->mode == SININN_CONV_RELU || a->mode == SININN_CONV_LINEAR || a->mode == SININN_CONV_MASK,
+                 "conv_bf16: bf16 output supports RELU / LINEAR / MASK only");
+    SININN_CHECK(a->N > 0 && a->N % 8 == 0 && a->N <= a->Np && a->out_stride >= a->N && a->out_stride % 8 == 0, "conv_bf16: bad N / out_stride");
+    if (a->mode == SININN_CONV_MASK) SININN_CHECK(a->mask && a->mask_bf16 && a->mask_stride % 8 == 0 && aligned16(a->mask), "conv_bf16: MASK needs a bf16 mask");
+    if (a->mode == SININN_CONV_RELU) SININN_CHECK(a->bias != nullptr, "conv_bf16: RELU mode needs bias");
+  } else {
+    SININN_CHECK(couple || a->mode == SININN_CONV_ADD || cbwd || a->mode == SININN_CONV_LINEAR || a->mode == SININN_CONV_RELU,
+                 "conv_bf16: fp32 output supports COUPLE / ADD / ADD_CBWD / LINEAR / RELU");
+    SININN_CHECK(a->out_stride % 4 == 0, "conv_bf16: out_stride %% 4");
+    if (couple) {
+      SININN_CHECK(a->Co > 0 && a->Co % 8 == 0 && a->Np == 2 * a->Co && a->v && a->v_stride >= a->Co && a->clamp > 0.f && a->out_stride >= a->Co,
+                   "conv_bf16: coupling needs Np == 2*Co, v, clamp");
+      SININN_CHECK(aligned16(a->v) && a->v_stride % 4 == 0 && (!a->out2 || (aligned16(a->out2) && a->out2_stride % 4 == 0)) && (!a->sbuf || aligned16(a->sbuf)),
+                   "conv_bf16: coupling operands must be 16-byte aligned");
+      SININN_CHECK(a->col_tile == 16 || (a->col_tile == 32 && a->Co % 16 == 0), "conv_bf16: col_tile must be 16 or 32 (Co %% 16 == 0)");
+    } else {
+      SININN_CHECK(a->N > 0 && a->N % 4 == 0 && a->N <= a->Np && a->out_stride >= a->N, "conv_bf16: bad N");
+      if (a->mode == SININN_CONV_ADD || cbwd) SININN_CHECK(a->addend != nullptr, "conv_bf16: ADD mode needs addend");
+      if ((a->mode == SININN_CONV_ADD || cbwd) && !a->addend_map) SININN_CHECK(aligned16(a->addend) && a->addend_stride % 4 == 0, "conv_bf16: addend alignment");
+      if (cbwd) SININN_CHECK(a->v && a->sbuf && a->out2 && a->Co == a->N && a->out_stride >= 2 * a->Co && a->clamp > 0.f, "conv_bf16: ADD_CBWD needs v, sbuf, out2");
+    }
+  }
+  SININN_CHECK(!a->bias || aligned16(a->bias), "conv_bf16: bias must be 16-byte aligned");
+  ConvDevB q = {};
+  ConvDev& d = q.c;
+  d.in = nullptr; d.in_stride = a->in_stride; d.Cin = a->Cin;
+  d.w = nullptr; d.bias = a->bias; d.Np = a->Np;
+  d.B = a->B; d.H = a->H; d.W = a->W;
+  d.out = a->out_bf16 ? nullptr : a->out; d.out_stride = a->out_stride; d.N = a->N; d.out_map = a->out_map;
+  d.v = a->v; d.v_stride = a->v_stride; d.out2 = a->out2; d.out2_stride = a->out2_stride;
+  d.sbuf = a->sbuf; d.logdet = a->logdet; d.Co = a->Co; d.clamp = a->clamp;
+  d.mask = nullptr; d.mask_stride = a->mask_stride;
+  d.addend = a->addend; d.addend_stride = a->addend_stride; d.addend_map = a->addend_map;
+  d.mode = a->mode; d.col_tile = couple ? a->col_tile : 16; d.stamp = nullptr; d.ablate = 0; d.CK = 0;
+  d.tiles_x = (a->W + 15) / 16; d.tiles_y = (a->H + 7) / 8;
+  q.in = a->in; q.w = reinterpret_cast<const __bf16*>(a->w);
+  q.out_b = a->out_bf16 ? reinterpret_cast<__bf16*>(a->out) : nullptr;
+  q.mask_b = reinterpret_cast<const __bf16*>(a->mask);
+  q.Kp = (a->Cin + 15) / 16 * 16;
+  q.in_bf16 = a->in_bf16; q.out_bf16 = a->out_bf16;
+  return a->ksize == 3 ? launch_ks<3>(q, st) : launch_ks<1>(q, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 weight packs (one launch per conv):  wb_fwd [taps][Np][Kp]  (row q = output channel colmap[q], k = input channel,
+// zero beyond Cin), b_fwd [Np] fp32 packed bias, wb_dgrad [taps][Cdp][Kd] (row c = input channel of the conv, k = output
+// channel n, flipped taps: the B operand of the data-gradient conv; Kd = N rounded up to 16).
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_bf16_kernel(const float* __restrict__ w, const float* __restrict__ bias, int N, int Cin, int taps,
+                                 const int* __restrict__ colmap, int Np, int Kp, __bf16* __restrict__ wf,
+                                 float* __restrict__ bf, int Cdp, int Kd, __bf16* __restrict__ wd) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nf = wf ? taps * Np * Kp : 0;
+  const int nd = wd ? taps * Cdp * Kd : 0;
+  if (idx < nf) {
+    const int c = idx % Kp, qq = (idx / Kp) % Np, t = idx / (Kp * Np);
+    const int n = colmap ? colmap[qq] : qq;
+    wf[idx] = (__bf16)((n >= 0 && n < N && c < Cin) ? w[((size_t)n * Cin + c) * taps + t] : 0.f);
+  } else if (idx < nf + nd) {
+    const int k = idx - nf;
+    const int n = k % Kd, c = (k / Kd) % Cdp, t = k / (Kd * Cdp);
+    wd[k] = (__bf16)((c < Cin && n < N) ? w[((size_t)n * Cin + c) * taps + (taps - 1 - t)] : 0.f);
+  }
+  if (bf && idx < Np) {
+    const int n = colmap ? colmap[idx] : idx;
+    bf[idx] = (bias && n >= 0 && n < N) ? bias[n] : 0.f;
+  }
+}
+
+int pack_bf16_launch(const float* w, const float* bias, int N, int Cin, int ksize, const int* colmap, int Np, void* wb_fwd,
+                     float* b_fwd, int Cdp, void* wb_dgrad, hipStream_t st) {
+  SININN_CHECK(w != nullptr && N > 0 && Cin > 0 && (ksize == 1 || ksize == 3), "pack_bf16: bad arguments");
+  SININN_CHECK(!wb_fwd || Np >= 1, "pack_bf16: bad Np");
+  SININN_CHECK(!wb_dgrad || Cdp >= Cin, "pack_bf16: Cdp < Cin");
+  const int taps = ksize * ksize;
+  const int Kp = (Cin + 15) / 16 * 16, Kd = (N + 15) / 16 * 16;
+  int total = (wb_fwd ? taps * Np * Kp : 0) + (wb_dgrad ? taps * Cdp * Kd : 0);
+  if (total < Np) total = Np;
+  hipLaunchKernelGGL(pack_bf16_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, bias, N, Cin, taps, colmap, Np, Kp,
+                     static_cast<__bf16*>(wb_fwd), b_fwd, Cdp, Kd, static_cast<__bf16*>(wb_dgrad));
+  SININN_LAUNCH_CHECK("pack_bf16");
+  return 0;
+}
+
+}  // namespace sininn

@@ -15,8 +15,11 @@ static int g_force_cfg = 0;   // test hook: 0 auto, 1 force 8-row tiles, 2 force
 static int g_force_ck = 0;
 static int g_ablate = 0;     // diagnostic: see ConvDev::ablate (results are wrong when set)    // test hook: override the channel chunk
 
+int conv_bf16_launch(const sininn_conv_args* a, hipStream_t st);
+
 int conv_launch(const sininn_conv_args* a, hipStream_t st) {
   SININN_CHECK(a != nullptr, "conv: null args");
+  if (a->w_bf16) return conv_bf16_launch(a, st);
   SININN_CHECK(a->ksize == 1 || a->ksize == 3, "conv: ksize %d not in {1,3}", a->ksize);
   SININN_CHECK(a->Cin > 0 && a->Cin % 8 == 0, "conv: Cin=%d must be a positive multiple of 8", a->Cin);
   SININN_CHECK(a->Np > 0 && a->Np % 16 == 0, "conv: Np=%d must be a positive multiple of 16", a->Np);

@@ -194,6 +194,7 @@ int glow_forward(const sininn_glow_args* a, hipStream_t st) {
   halves_of(a, hv);
   Saved sv = saved_layout(a->saved, M, hv[0].co, hv[1].co);
   const int mode = a->rev ? SININN_CONV_COUPLE_INV : SININN_CONV_COUPLE_FWD;
+  const bool bf16 = a->dtype == 1;
   for (int i = 0; i < 2; ++i) {
     const Half& h = hv[i];
     float* hbuf = i == 0 ? sv.h_a : sv.h_b;
@@ -204,6 +205,7 @@ int glow_forward(const sininn_glow_args* a, hipStream_t st) {
     c1.w = h.net->w1; c1.bias = h.net->b1; c1.Np = SININN_HIDDEN; c1.winograd = (h.net->winograd & 1) && a->ksize == 3;
     c1.B = a->B; c1.H = a->H; c1.W = a->W; c1.ksize = a->ksize; c1.mode = SININN_CONV_RELU;
     c1.out = hbuf; c1.out_stride = SININN_HIDDEN; c1.N = SININN_HIDDEN;
+    if (bf16) { c1.winograd = 0; c1.w_bf16 = 1; c1.in_bf16 = 0; c1.out_bf16 = 1; }     // cond fp32 -> h bf16
     if (int rc = conv_launch(&c1, st)) return rc;
     sininn_conv_args c2 = {};
     c2.in = hbuf; c2.in_stride = SININN_HIDDEN; c2.Cin = SININN_HIDDEN;
@@ -215,6 +217,7 @@ int glow_forward(const sininn_glow_args* a, hipStream_t st) {
     c2.v = a->x + h.base; c2.v_stride = C;
     c2.out2 = (i == 0) ? sv.ybuf : nullptr; c2.out2_stride = h.co;
     c2.sbuf = sbuf; c2.logdet = a->logdet; c2.Co = h.co; c2.clamp = a->clamp; c2.col_tile = col_tile_of(h.co);
+    if (bf16) { c2.winograd = 0; c2.w_bf16 = 1; c2.in_bf16 = 1; }                       // h bf16 -> fp32 coupling epilogue
     hipEvent_t e0, e1;
     unsigned long long* stamp = nullptr;
     const bool timed = g_prof_h != 0 && a->ksize == 3 && a->H == g_prof_h && prof_pair(&e0, &e1, &stamp);
@@ -246,13 +249,16 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
   // first half's dh) has been queued; one launch pair on the weight-gradient stream instead of four
   // 3x3 blocks only: their grouped launch saves ~0.3 ms of kernel time per step (slab reduce 0.28 -> 0.09 ms, gradient
   // kernels -4 %); the 1x1 convs are faster on their own kernels (N = 48 runs a 48 x 64 tile there, 64 x ... padded here)
-  const bool grouped = wgrad_grouping_enabled() && k == 3;
+  const bool bf16 = a->dtype == 1;
+  const bool grouped = bf16 || (wgrad_grouping_enabled() && k == 3);      // the bf16-operand loads exist in the grouped kernels
   const bool per_half = wgrad_group_mode() == 2;
   sininn_wgrad_item items[4];
   int n_items = 0;
-  auto add_item = [&](const float* in, int in_stride, int cin, const float* dout, int dout_stride, int n, float* gw, float* gb) {
+  auto add_item = [&](const float* in, int in_stride, int cin, const float* dout, int dout_stride, int n, float* gw, float* gb,
+                      int in_b, int dout_b) {
     sininn_wgrad_item& it = items[n_items++];
     it.in = in; it.in_stride = in_stride; it.Cin = cin; it.dout = dout; it.dout_stride = dout_stride; it.N = n; it.gw = gw; it.gb = gb;
+    it.in_bf16 = in_b; it.dout_bf16 = dout_b;
   };
 
   // fuse: when set, the dgrad of this half's first conv also performs the coupling-tail backward of the OTHER
@@ -268,7 +274,7 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
       if (int rc = coupling_bwd_launch(dy, dy_stride, dy_map, vy, vy_stride, vy_map, sbuf, a->gld, B, HW, h.co, a->clamp, inv,
                                        dr, a->dx + h.base, C, st)) return rc;
     if (net->gw2) {
-      if (grouped) add_item(hbuf, SININN_HIDDEN, SININN_HIDDEN, dr, 2 * h.co, 2 * h.co, net->gw2, net->gb2);
+      if (grouped) add_item(hbuf, SININN_HIDDEN, SININN_HIDDEN, dr, 2 * h.co, 2 * h.co, net->gw2, net->gb2, bf16 ? 1 : 0, 0);
       else {
         if (int rc = order_after(wst, st)) return rc;
         if (int rc = wgrad_launch(hbuf, SININN_HIDDEN, SININN_HIDDEN, dr, 2 * h.co, 2 * h.co, B, H, W, k, net->gw2, net->gb2,
@@ -280,9 +286,10 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
     d2.winograd = (net->winograd & 8) && k == 3;
     d2.B = B; d2.H = H; d2.W = W; d2.ksize = k; d2.mode = SININN_CONV_MASK;
     d2.out = dh; d2.out_stride = SININN_HIDDEN; d2.N = SININN_HIDDEN; d2.mask = hbuf; d2.mask_stride = SININN_HIDDEN;
+    if (bf16) { d2.winograd = 0; d2.w_bf16 = 1; d2.in_bf16 = 0; d2.out_bf16 = 1; d2.mask_bf16 = 1; }   // dr fp32 -> dh bf16
     if (int rc = conv_launch(&d2, st)) return rc;
     if (net->gw1) {
-      if (grouped) add_item(cond, cond_stride, cond_cin, dh, SININN_HIDDEN, SININN_HIDDEN, net->gw1, net->gb1);
+      if (grouped) add_item(cond, cond_stride, cond_cin, dh, SININN_HIDDEN, SININN_HIDDEN, net->gw1, net->gb1, 0, bf16 ? 1 : 0);
       else {
         if (int rc = order_after(wst, st)) return rc;
         if (int rc = wgrad_launch(cond, cond_stride, cond_cin, dh, SININN_HIDDEN, SININN_HIDDEN, B, H, W, k, net->gw1, net->gb1,
@@ -298,6 +305,7 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
     sininn_conv_args d1 = {};
     d1.in = dh; d1.in_stride = SININN_HIDDEN; d1.Cin = SININN_HIDDEN; d1.w = net->w1_dgrad;
     d1.winograd = (net->winograd & 4) && k == 3;
+    if (bf16) { d1.winograd = 0; d1.w_bf16 = 1; d1.in_bf16 = 1; }                                       // dh bf16 -> fp32 epilogue
     d1.Np = d1.winograd ? (cond_cin + 31) / 32 * 32 : pad16i(cond_cin);
     d1.B = B; d1.H = H; d1.W = W; d1.ksize = k; d1.mode = SININN_CONV_ADD;
     d1.out = dcond; d1.out_stride = dcond_stride; d1.N = cond_cin;

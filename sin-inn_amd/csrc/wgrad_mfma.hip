@@ -21,7 +21,18 @@ struct WgradDev {
   float* partial;   // [S][taps][Nr][Cc]
   float* bpartial;  // [S][Nr]
   int Nr, Cc;
+  int in_bf16, dout_bf16;   // mixed-precision path: the operand lives in HBM as bf16 (strides in elements); converted to
+                            // fp32 while it is staged, the gradient itself accumulates on the f32 matrix pipe
 };
+
+typedef __bf16 wg_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 wg_load4(const float* base, size_t off, int is_bf16) {
+  if (is_bf16) {
+    const wg_bf16x4 v = *reinterpret_cast<const wg_bf16x4*>(reinterpret_cast<const __bf16*>(base) + off);
+    return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  }
+  return *reinterpret_cast<const f32x4*>(base + off);
+}
 
 constexpr int WG_TH = 8;   // pixel tile 8 x 16
 
@@ -81,7 +92,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradDev p) {
       const int n = n0 + n4 * 4;
       f32x4 val = {0.f, 0.f, 0.f, 0.f};
       if (pix < NPIX && gy < p.H && gx < p.W && n < p.N)   // N % 4 == 0 is checked on the host
-        val = *reinterpret_cast<const f32x4*>(p.dout + ((size_t)(b * p.H + gy) * p.W + gx) * p.dout_stride + n);
+        val = wg_load4(p.dout, ((size_t)(b * p.H + gy) * p.W + gx) * p.dout_stride + n, p.dout_bf16);
       d_reg[r] = val;
     }
 #pragma unroll
@@ -93,7 +104,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradDev p) {
       const int c = c0 + c4 * 4;
       f32x4 val = {0.f, 0.f, 0.f, 0.f};
       if (pix < NPIX_IN && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && c < p.Cin)
-        val = *reinterpret_cast<const f32x4*>(p.in + ((size_t)(b * p.H + gy) * p.W + gx) * p.in_stride + c);
+        val = wg_load4(p.in, ((size_t)(b * p.H + gy) * p.W + gx) * p.in_stride + c, p.in_bf16);
       i_reg[r] = val;
     }
   };
@@ -224,7 +235,7 @@ __device__ __forceinline__ void wgrad32_body(const WgradDev& p, const int split,
       const int n = n0 + n4 * 4;
       f32x4 val = {0.f, 0.f, 0.f, 0.f};
       if (pix < NPIX && gy < p.H && gx < p.W && n < p.N)
-        val = *reinterpret_cast<const f32x4*>(p.dout + ((size_t)(b * p.H + gy) * p.W + gx) * p.dout_stride + n);
+        val = wg_load4(p.dout, ((size_t)(b * p.H + gy) * p.W + gx) * p.dout_stride + n, p.dout_bf16);
       d_reg[r] = val;
     }
 #pragma unroll
@@ -236,7 +247,7 @@ __device__ __forceinline__ void wgrad32_body(const WgradDev& p, const int split,
       const int c = c0 + c4 * 4;
       f32x4 val = {0.f, 0.f, 0.f, 0.f};
       if (pix < NPIX_IN && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && c < p.Cin)
-        val = *reinterpret_cast<const f32x4*>(p.in + ((size_t)(b * p.H + gy) * p.W + gx) * p.in_stride + c);
+        val = wg_load4(p.in, ((size_t)(b * p.H + gy) * p.W + gx) * p.in_stride + c, p.in_bf16);
       i_reg[r] = val;
     }
   };
@@ -365,7 +376,7 @@ __device__ __forceinline__ void wgrad_wino_body(const WgradDev& p, const int spl
       const int n = n0 + n4 * 4;
       f32x4 val = {0.f, 0.f, 0.f, 0.f};
       if (pix < NPIX && gy < p.H && gx < p.W && n < p.N)
-        val = *reinterpret_cast<const f32x4*>(p.dout + ((size_t)(b * p.H + gy) * p.W + gx) * p.dout_stride + n);
+        val = wg_load4(p.dout, ((size_t)(b * p.H + gy) * p.W + gx) * p.dout_stride + n, p.dout_bf16);
       d_reg[r] = val;
     }
 #pragma unroll
@@ -377,7 +388,7 @@ __device__ __forceinline__ void wgrad_wino_body(const WgradDev& p, const int spl
       const int c = c0 + c4 * 4;
       f32x4 val = {0.f, 0.f, 0.f, 0.f};
       if (pix < NPIX_IN && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && c < p.Cin)
-        val = *reinterpret_cast<const f32x4*>(p.in + ((size_t)(b * p.H + gy) * p.W + gx) * p.in_stride + c);
+        val = wg_load4(p.in, ((size_t)(b * p.H + gy) * p.W + gx) * p.in_stride + c, p.in_bf16);
       i_reg[r] = val;
     }
   };
@@ -747,6 +758,7 @@ int wgrad_launch(const float* in, int in_stride, int Cin, const float* dout, int
   d.in = in; d.in_stride = in_stride; d.Cin = Cin; d.dout = dout; d.dout_stride = dout_stride; d.N = N;
   d.B = B; d.H = H; d.W = W; d.tiles_x = pl.tiles_x; d.tiles_y = pl.tiles_y; d.ntiles = pl.ntiles;
   d.tiles_per_split = pl.tiles_per_split; d.Nr = pl.Nr; d.Cc = pl.Cc;
+  d.in_bf16 = 0; d.dout_bf16 = 0;
   const int taps = ksize * ksize;
   d.partial = static_cast<float*>(ws);
   d.bpartial = d.partial + (size_t)pl.S * taps * pl.Nr * pl.Cc;
@@ -804,6 +816,7 @@ static int plan_group(const sininn_wgrad_item* items, int n, int B, int H, int W
     d.in = it.in; d.in_stride = it.in_stride; d.Cin = it.Cin; d.dout = it.dout; d.dout_stride = it.dout_stride; d.N = it.N;
     d.B = B; d.H = H; d.W = W; d.tiles_x = tiles_x; d.tiles_y = tiles_y; d.ntiles = ntiles; d.tiles_per_split = tps;
     d.Nr = q.nblk * bnw; d.Cc = q.cblk * bcw;
+    d.in_bf16 = it.in_bf16; d.dout_bf16 = it.dout_bf16;
     d.partial = ws ? ws + off : nullptr; off += (size_t)S * taps * d.Nr * d.Cc;
     d.bpartial = ws ? ws + off : nullptr; off += ((size_t)S * d.Nr + 3) / 4 * 4;
     q.gw = it.gw; q.gb = it.gb;
@@ -833,6 +846,7 @@ int wgrad_group_launch(const sininn_wgrad_item* items, int n, int B, int H, int 
     SININN_CHECK(it.in && it.dout && it.gw, "wgrad_group: null pointer in problem %d", i);
     SININN_CHECK(it.in_stride >= it.Cin && it.in_stride % 4 == 0 && aligned16(it.in), "wgrad_group: in must be 16-byte aligned, stride %% 4 == 0");
     SININN_CHECK(it.dout_stride >= it.N && it.dout_stride % 4 == 0 && aligned16(it.dout), "wgrad_group: dout must be 16-byte aligned, stride %% 4 == 0");
+    SININN_CHECK((it.in_bf16 == 0 || it.in_bf16 == 1) && (it.dout_bf16 == 0 || it.dout_bf16 == 1), "wgrad_group: dtype flags must be 0 / 1");
   }
   if (pl.wino) {
     hipLaunchKernelGGL((wgrad_wino_group_kernel<4, 2>), dim3(pl.grad_blocks), dim3(256), 0, st, pl.g);

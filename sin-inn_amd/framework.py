@@ -178,6 +178,14 @@ class ReversibleGraphNet(nn.Module):
                 pixel_major = True
         return cur.permute(0, 3, 1, 2) if pixel_major else cur
 
+    def set_precision(self, precision):
+        """'fp32' (default, the reference's arithmetic) or 'bf16' (mixed precision: bf16 conv subnets, fp32 flow)."""
+        assert precision in ('fp32', 'bf16')
+        for m in self.module_list:
+            if isinstance(m, GLOWCouplingBlock):
+                m.precision = precision
+        return self
+
     def prepare_packs(self):
         """Build (or refresh) every packed-weight buffer of the graph on the CURRENT stream.  Packs are otherwise built
         lazily by the first pass that misses the cache, on that pass's stream; with the forward and the reverse chain on

@@ -96,25 +96,30 @@ class _PackCache:
         self.store = {}
 
     @staticmethod
-    def _key(conv, want_dgrad, wino_fwd, wino_dgrad):
+    def _key(conv, want_dgrad, wino_fwd, wino_dgrad, bf16=False):
         return (conv.weight.data_ptr(), conv.weight._version, conv.bias._version, WEIGHTS_EPOCH[0], want_dgrad,
-                wino_fwd, wino_dgrad)
+                wino_fwd, wino_dgrad, bf16)
 
-    def get(self, conv, colmap, want_dgrad, wino_fwd=False, wino_dgrad=False):
-        key = self._key(conv, want_dgrad, wino_fwd, wino_dgrad)
-        hit = self.store.get(id(conv))
+    def get(self, conv, colmap, want_dgrad, wino_fwd=False, wino_dgrad=False, bf16=False):
+        key = self._key(conv, want_dgrad, wino_fwd, wino_dgrad, bf16)
+        hit = self.store.get((id(conv), bf16))
         if hit is None or hit.key != key:
             same_shape = hit is not None and hit.key[0] == key[0] and hit.key[4:] == key[4:]
-            packs = ops.pack_conv(conv.weight.detach(), conv.bias.detach(), colmap, want_dgrad, wino_fwd, wino_dgrad,
-                                  out=hit.packs if same_shape else None)
+            if bf16:
+                packs = ops.pack_conv_bf16(conv.weight.detach(), conv.bias.detach(), colmap, want_dgrad,
+                                           out=hit.packs if same_shape else None)
+            else:
+                packs = ops.pack_conv(conv.weight.detach(), conv.bias.detach(), colmap, want_dgrad, wino_fwd, wino_dgrad,
+                                      out=hit.packs if same_shape else None)
             if same_shape:
                 hit.key = key
             else:
-                if hit is not None:
+                if hit is not None and not bf16:
                     _PACK_REGISTRY.discard(hit)
                 hit = _PackEntry(conv, colmap, key, packs)
-                self.store[id(conv)] = hit
-                _PACK_REGISTRY.add(hit)
+                self.store[(id(conv), bf16)] = hit
+                if not bf16:            # the batched refresh of the optimiser step covers the fp32 packs; bf16 packs are
+                    _PACK_REGISTRY.add(hit)   # refreshed by the first (main-stream) prepare_packs() of the next step
         return hit.packs
 
 
@@ -199,17 +204,23 @@ def _pv(t, off=0):
     return None if t is None else t.data_ptr() + 4 * off
 
 
+def _pd(t):
+    """device pointer of a pack (fp32 or bf16)"""
+    return None if t is None else t.data_ptr()
+
+
 def _subnet_args(block, seq, co, dev, need_grad, with_grads):
     conv1, conv2, k = inspect_subnet(seq)
     cmap = ops.coupling_colmap(co, dev)
-    wino = USE_WINOGRAD[0] and k == 3
+    bf16 = block.precision == 'bf16'
+    wino = USE_WINOGRAD[0] and k == 3 and not bf16
     wino_w2 = wino                                  # conv2 forward: (s|t) interleave of either width
     # The data-gradient packs are built whenever the conv is trainable, not only when this call needs them: the cache key
     # then does not flip between no_grad (validation) and training passes, so an entry is never REPLACED mid-training --
     # a replacement would be packed lazily on whichever stream first misses (see ReversibleGraphNet.prepare_packs).
-    w1, b1, wd1 = block._packs.get(conv1, None, need_grad or conv1.weight.requires_grad, wino, wino)
-    w2, b2, wd2 = block._packs.get(conv2, cmap, need_grad or conv2.weight.requires_grad, wino_w2, wino)
-    a = SubnetArgs(w1=_pv(w1), b1=_pv(b1), w2=_pv(w2), b2=_pv(b2), w1_dgrad=_pv(wd1), w2_dgrad=_pv(wd2),
+    w1, b1, wd1 = block._packs.get(conv1, None, need_grad or conv1.weight.requires_grad, wino, wino, bf16)
+    w2, b2, wd2 = block._packs.get(conv2, cmap, need_grad or conv2.weight.requires_grad, wino_w2, wino, bf16)
+    a = SubnetArgs(w1=_pd(w1), b1=_pv(b1), w2=_pd(w2), b2=_pv(b2), w1_dgrad=_pd(wd1), w2_dgrad=_pd(wd2),
                    winograd=(1 if wino else 0) | (2 if wino_w2 else 0) | (12 if wino else 0))
     if with_grads:
         if conv1.weight.requires_grad:
@@ -243,7 +254,8 @@ class _GlowFn(torch.autograd.Function):
         s1, keep1 = _subnet_args(block, block.s1, block.split_len2, dev, need_grad, False)
         s2, keep2 = _subnet_args(block, block.s2, block.split_len1, dev, need_grad, False)
         a = GlowArgs(B=b, H=h, W=w, C=c, ksize=block.ksize, rev=1 if rev else 0, clamp=block.clamp, x=_pv(x),
-                     out=_pv(out), dst_map=_pv(dst), logdet=_pv(logdet), s1=s1, s2=s2, saved=_pv(saved))
+                     out=_pv(out), dst_map=_pv(dst), logdet=_pv(logdet), s1=s1, s2=s2, saved=_pv(saved),
+                     dtype=1 if block.precision == 'bf16' else 0)
         _lib.check(lib.sininn_glow_forward(C.byref(a), ops._stream()))
         if need_grad:
             ctx.block, ctx.rev, ctx.dst = block, rev, dst
@@ -271,7 +283,8 @@ class _GlowFn(torch.autograd.Function):
         a = GlowArgs(B=b, H=h, W=w, C=c, ksize=block.ksize, rev=1 if rev else 0, clamp=block.clamp, x=_pv(x),
                      out=_pv(out), dst_map=_pv(dst), s1=s1, s2=s2, saved=_pv(saved), scratch=_pv(scratch),
                      scratch_bytes=nbytes, dout=_pv(dout), gld=_pv(gld), dx=_pv(dx),
-                     skip_dx=0 if ctx.needs_input_grad[0] else 1)     # first block of a pass: nobody consumes dx
+                     skip_dx=0 if ctx.needs_input_grad[0] else 1,     # first block of a pass: nobody consumes dx
+                     dtype=1 if block.precision == 'bf16' else 0)
         main = torch.cuda.current_stream()
         side = _side_stream(dev) if USE_SIDE_STREAM[0] else main
         _lib.check(lib.sininn_glow_backward(C.byref(a), C.c_void_p(main.cuda_stream), C.c_void_p(side.cuda_stream)))
@@ -301,6 +314,9 @@ class GLOWCouplingBlock(nn.Module):
         assert inspect_subnet(self.s2)[2] == self.ksize
         self._packs = _PackCache()
         self.last_jac = None
+        # 'fp32': f32 MFMA everywhere (the reference's arithmetic).  'bf16': the conv subnets run on bf16 MFMA with fp32
+        # accumulation and bf16 hidden tensors; the flow tensors, the coupling arithmetic and the gradients stay fp32.
+        self.precision = 'fp32'
 
     def _params(self):
         return [p for s in (self.s1, self.s2) for p in s.parameters()]

@@ -97,6 +97,28 @@ def pack_conv(weight, bias, colmap=None, want_dgrad=True, wino_fwd=False, wino_d
     return w_fwd, b_fwd, w_dg
 
 
+def pack_conv_bf16(weight, bias, colmap=None, want_dgrad=True, out=None):
+    """OIHW conv weight -> bf16 packs for the mixed-precision convs: (wb_fwd [taps][Np][Kp] bf16, b_fwd [Np] fp32,
+    wb_dgrad [taps][pad16(Cin)][Kd] bf16); Kp / Kd = Cin / N rounded up to 16."""
+    _chk(weight)
+    n, cin, k, _ = weight.shape
+    assert weight.is_contiguous() and (bias is None or bias.is_contiguous())
+    dev = weight.device
+    npk = colmap.numel() if colmap is not None else pad16(n)
+    taps = k * k
+    kp, kd, cdp = pad16(cin), pad16(n), pad16(cin)
+    if out is not None:
+        w_fwd, b_fwd, w_dg = out
+    else:
+        b_fwd = torch.empty(npk, device=dev, dtype=torch.float32)
+        w_fwd = torch.empty(taps * npk * kp, device=dev, dtype=torch.bfloat16)
+        w_dg = torch.empty(taps * cdp * kd, device=dev, dtype=torch.bfloat16) if want_dgrad else None
+    check(_lib.lib().sininn_pack_conv_weights_bf16(ptr(weight), ptr(bias), n, cin, k, ptr(colmap, dtype=torch.int32), npk,
+                                                   ptr(w_fwd, dtype=torch.bfloat16), ptr(b_fwd), cdp,
+                                                   ptr(w_dg, dtype=torch.bfloat16), _stream()))
+    return w_fwd, b_fwd, w_dg
+
+
 def pack_desc(weight, bias, colmap, packs, wino_fwd, wino_dgrad):
     """sininn_pack_desc refreshing `packs` (a pack_conv result) from (weight, bias)."""
     n, cin, k, _ = weight.shape
@@ -134,7 +156,7 @@ def conv(**kw):
     """Launch sininn_conv; keyword names follow sininn_conv_args (tensors given as (tensor, offset) or c_void_p)."""
     a = ConvArgs()
     for k, v in kw.items():
-        setattr(a, 'inp' if k == 'in_' else k, v)
+        setattr(a, 'inp' if k == 'in_' else k, int(v) if isinstance(v, bool) else v)
     check(_lib.lib().sininn_conv(C.byref(a), _stream()))
 
 
@@ -149,14 +171,18 @@ def wgrad(in_t, in_off, in_stride, cin, dout, dout_stride, n, b, h, w, ksize, gw
 
 
 def wgrad_group(problems, b, h, w, ksize):
-    """problems: list of (in_t, in_off, in_stride, cin, dout, dout_off, dout_stride, n, gw, gb): all += in two launches."""
+    """problems: list of (in_t, in_off, in_stride, cin, dout, dout_off, dout_stride, n, gw, gb[, in_bf16, dout_bf16]): all +=
+    in two launches.  Operands flagged bf16 are torch.bfloat16 tensors (strides in elements)."""
     lib = _lib.lib()
     arr = (_lib.WgradItem * len(problems))()
-    for it, (in_t, in_off, in_stride, cin, dout, dout_off, dout_stride, n, gw, gb) in zip(arr, problems):
+    for it, prob in zip(arr, problems):
+        in_t, in_off, in_stride, cin, dout, dout_off, dout_stride, n, gw, gb = prob[:10]
+        in_b, dout_b = (bool(prob[10]), bool(prob[11])) if len(prob) > 10 else (False, False)
         assert gw.is_contiguous() and (gb is None or gb.is_contiguous())
-        it.inp, it.in_stride, it.Cin = ptr(in_t, in_off), in_stride, cin
-        it.dout, it.dout_stride, it.N = ptr(dout, dout_off), dout_stride, n
+        it.inp, it.in_stride, it.Cin = ptr(in_t, in_off, torch.bfloat16 if in_b else torch.float32), in_stride, cin
+        it.dout, it.dout_stride, it.N = ptr(dout, dout_off, torch.bfloat16 if dout_b else torch.float32), dout_stride, n
         it.gw, it.gb = ptr(gw), ptr(gb)
+        it.in_bf16, it.dout_bf16 = int(in_b), int(dout_b)
     nbytes = lib.sininn_wgrad_group_workspace_bytes(arr, len(problems), b, h, w, ksize)
     ws = torch.empty((nbytes + 3) // 4, device=problems[0][0].device, dtype=torch.float32)
     check(lib.sininn_wgrad_group(arr, len(problems), b, h, w, ksize, ptr(ws), nbytes, _stream()))

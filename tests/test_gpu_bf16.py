@@ -1,0 +1,196 @@
+"""GPU: the mixed-precision path (BASELINE configs[3] / [4]): conv subnets on v_mfma_f32_32x32x16_bf16 with fp32
+accumulation, hidden tensors stored as bf16, fp32 flow / coupling / log-det / parameter gradients.
+
+Tolerances (stated, separate from the fp32 path's 1e-4):
+  * a kernel whose operands are exactly representable in bf16 on both sides differs from torch only by fp32 accumulation
+    order: 1e-4 of the max-norm (fp32 outputs), one bf16 ulp = 2^-8 relative (bf16 outputs);
+  * the composed network against the oracle's bf16 EMULATION (operands rounded to bf16, fp32 accumulation, straight-through
+    gradients): outputs 2e-2 max-norm / 3e-3 L2 (a hidden value that sits on a bf16 rounding boundary lands on the other
+    side), gradients 5e-2 max-norm / 2e-2 L2 (the HIP path also rounds the coupling-tail gradient and dh to bf16);
+  * against the fp32 oracle: 5e-2 L2 on outputs -- the price of bf16 operands, stated so it is not mistaken for parity."""
+import os
+import sys
+import types
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+def relerr(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+@pytest.mark.parametrize('ksize', [3, 1])
+@pytest.mark.parametrize('cin,n,hw', [(24, 256, (16, 32)), (256, 48, (13, 21)), (96, 256, (9, 17)), (256, 192, (12, 20)),
+                                      (48, 256, (8, 16)), (192, 256, (5, 7))])
+def test_conv_bf16_kernel(ksize, cin, n, hw):
+    """every operand flavour of the bf16 conv engine against torch on the same bf16-rounded values."""
+    import sin_inn_amd
+    from sin_inn_amd import ops, _lib
+    torch.manual_seed(cin + n + ksize)
+    dev = torch.device('cuda')
+    b, (h, w) = 2, hw
+    conv = torch.nn.Conv2d(cin, n, ksize, padding=ksize // 2)
+    wq, bias = bf(conv.weight.detach()), conv.bias.detach()
+    x = torch.randn(b, cin, h, w)
+    wf, bfw, wd = ops.pack_conv_bf16(conv.weight.detach().cuda().contiguous(), bias.cuda().contiguous(), None, True)
+    npk = ops.pad16(n)
+    want = F.conv2d(bf(x), wq, bias, padding=ksize // 2)
+    # fp32 input (converted while staged) -> bf16 output, ReLU epilogue (conv1 of a subnet: cond -> h)
+    if n % 8 == 0:
+        out = torch.full((b, h, w, n), float('nan'), device=dev, dtype=torch.bfloat16)
+        ops.conv(in_=ops.ptr(nhwc(x)), in_stride=cin, Cin=cin, w=ops.ptr(wf, dtype=torch.bfloat16), bias=ops.ptr(bfw), Np=npk,
+                 B=b, H=h, W=w, ksize=ksize, mode=_lib.CONV_RELU, out=ops.ptr(out, dtype=torch.bfloat16), out_stride=n, N=n,
+                 w_bf16=1, in_bf16=0, out_bf16=1)
+        got = nchw(out.float())
+        ref = F.relu(want)
+        assert float((got - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max()) + 1e-6
+    # bf16 input -> fp32 output, LINEAR (accumulation order is the only difference)
+    xb = nhwc(x).to(torch.bfloat16)
+    out = torch.full((b, h, w, n), float('nan'), device=dev)
+    ops.conv(in_=ops.ptr(xb, dtype=torch.bfloat16), in_stride=cin, Cin=cin, w=ops.ptr(wf, dtype=torch.bfloat16), bias=ops.ptr(bfw),
+             Np=npk, B=b, H=h, W=w, ksize=ksize, mode=_lib.CONV_LINEAR, out=ops.ptr(out), out_stride=n, N=n, w_bf16=1, in_bf16=1)
+    assert relerr(nchw(out), want) < 1e-4
+    # data gradient: bf16 gradient in -> fp32 out + addend (conv1's dgrad: dh -> dcond)
+    g = torch.randn(b, n, h, w)
+    xin = bf(x).clone().requires_grad_(True)
+    F.conv2d(xin, wq, None, padding=ksize // 2).backward(bf(g))
+    add = torch.randn(b, h, w, cin, device=dev)
+    dx = torch.full((b, h, w, cin), float('nan'), device=dev)
+    gb16 = nhwc(g).to(torch.bfloat16)
+    ops.conv(in_=ops.ptr(gb16, dtype=torch.bfloat16), in_stride=n, Cin=n, w=ops.ptr(wd, dtype=torch.bfloat16), Np=ops.pad16(cin),
+             B=b, H=h, W=w, ksize=ksize, mode=_lib.CONV_ADD, out=ops.ptr(dx), out_stride=cin, N=cin, addend=ops.ptr(add),
+             addend_stride=cin, w_bf16=1, in_bf16=1)
+    assert relerr(nchw(dx), xin.grad + nchw(add)) < 1e-4
+    # data gradient through the ReLU: fp32 gradient in -> bf16 out, masked by a bf16 hidden tensor (conv2's dgrad: dr -> dh)
+    if cin % 8 == 0:
+        hid = torch.randn(b, h, w, cin, device=dev).to(torch.bfloat16)
+        dh = torch.full((b, h, w, cin), float('nan'), device=dev, dtype=torch.bfloat16)
+        ops.conv(in_=ops.ptr(nhwc(g)), in_stride=n, Cin=n, w=ops.ptr(wd, dtype=torch.bfloat16), Np=ops.pad16(cin), B=b, H=h, W=w,
+                 ksize=ksize, mode=_lib.CONV_MASK, out=ops.ptr(dh, dtype=torch.bfloat16), out_stride=cin, N=cin,
+                 mask=ops.ptr(hid, dtype=torch.bfloat16), mask_stride=cin, w_bf16=1, in_bf16=0, out_bf16=1, mask_bf16=1)
+        ref = xin.grad * (nchw(hid.float()) > 0)
+        got = nchw(dh.float())
+        assert float((got - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize('ksize', [3, 1])
+def test_wgrad_group_with_bf16_operands(ksize):
+    """weight gradients whose operands live in HBM as bf16 (h for conv2, dh for conv1): fp32 accumulation of the exact
+    bf16 values == torch autograd on the same values."""
+    import sin_inn_amd
+    from sin_inn_amd import ops
+    torch.manual_seed(5 + ksize)
+    b, h, w = 2, 13, 21
+    probs, wants = [], []
+    for cin, n, in_b, dout_b in ((256, 48, True, False), (24, 256, False, True), (256, 192, True, False), (96, 256, False, True)):
+        conv = torch.nn.Conv2d(cin, n, ksize, padding=ksize // 2)
+        x, g = torch.randn(b, cin, h, w), torch.randn(b, n, h, w)
+        xv, gv = (bf(x) if in_b else x), (bf(g) if dout_b else g)
+        conv(xv).backward(gv)
+        xg = nhwc(x).to(torch.bfloat16) if in_b else nhwc(x)
+        gg = nhwc(g).to(torch.bfloat16) if dout_b else nhwc(g)
+        gw, gbias = torch.zeros_like(conv.weight).cuda(), torch.zeros_like(conv.bias).cuda()
+        probs.append((xg, 0, cin, cin, gg, 0, n, n, gw, gbias, in_b, dout_b))
+        wants.append((conv.weight.grad, conv.bias.grad, gw, gbias))
+    ops.wgrad_group(probs, b, h, w, ksize)
+    for gw_ref, gb_ref, gw, gbias in wants:
+        assert relerr(gw, gw_ref) < 1e-4 and relerr(gbias, gb_ref) < 1e-4
+
+
+def _nets(size, num_coupling, lr_window=1, seed=0):
+    import archs
+    from oracle import sininn_oracle as O
+    from test_gpu_model import make_opt, copy_weights
+    torch.manual_seed(seed)
+    opt = make_opt(num_coupling=num_coupling, lr_window=lr_window)
+    net = archs.UncondSRFlow(3, size[0], size[1], opt)
+    ref = O.SRFlowOracle(3, size[0], size[1], scale=4, num_coupling=num_coupling)
+    copy_weights(ref, net)
+    emu = O.SRFlowOracle(3, size[0], size[1], scale=4, num_coupling=num_coupling)
+    copy_weights(emu, net)
+    for m in emu.modules():
+        if isinstance(m, O.GlowBlock):
+            m.emulate_bf16 = True
+    net.cuda().set_precision('bf16')
+    return net, ref, emu, opt
+
+
+@pytest.mark.parametrize('size,num_coupling', [((32, 48), 2), ((40, 56), 1)])
+def test_bf16_network_matches_emulating_oracle(size, num_coupling):
+    import sin_inn_amd
+    net, ref, emu, opt = _nets(size, num_coupling, seed=3)
+    x = torch.rand(2, 3, *size)
+    xg = x.cuda().requires_grad_(True); xe = x.clone().requires_grad_(True)
+    yg, ye = net(xg), emu(xe)
+    assert relerr(yg, ye) < 2e-2 and rel_l2(yg, ye) < 3e-3
+    assert relerr(net.log_jacobian(), emu.log_jacobian()) < 2e-2
+    with torch.no_grad():
+        assert rel_l2(yg, ref(x)) < 5e-2                     # distance to the fp32 reference arithmetic, for the record
+    wgt = torch.randn_like(ye)
+    (ye * wgt).sum().backward(); (yg * wgt.cuda()).sum().backward()
+    assert rel_l2(xg.grad, xe.grad) < 2e-2 and relerr(xg.grad, xe.grad) < 5e-2
+    sin_inn_amd.modules.join_side_streams()
+    for (n, pg), (_, pe) in zip(net.named_parameters(), emu.named_parameters()):
+        assert rel_l2(pg.grad, pe.grad) < 2e-2, n
+    # reverse direction + round trip: the inverse recomputes the same bf16 subnet outputs from (nearly) the same inputs
+    z = torch.randn(2, 192, size[0] // 8, size[1] // 8)
+    with torch.no_grad():
+        hg, he = net(z.cuda(), rev=True), emu(z, rev=True)
+        assert relerr(hg, he) < 2e-2 and rel_l2(hg, he) < 3e-3
+        back = net(net(x.cuda()), rev=True)
+        assert rel_l2(back, x) < 5e-3
+
+
+def test_bf16_training_step_runs_and_tracks_fp32():
+    """one training step in both precisions from the same weights / frames / latents: the losses agree to bf16 accuracy and
+    the parameter updates point the same way."""
+    import lit_wrapper
+    from data import FrameStore
+    from sin_inn_amd.functional import sample_windows
+    from test_gpu_model import make_opt
+    results = {}
+    for prec in ('fp32', 'bf16'):
+        torch.manual_seed(11)
+        opt = make_opt(num_coupling=2, lr_window=2, precision=prec)
+        model = lit_wrapper.SingleVideoINN(3, 64, 64, opt).cuda()
+        optim = model.attach_optimizer()
+        store = FrameStore.synthetic(12, 64, 64).to('cuda')
+        idx = torch.tensor([3, 4, 6, 8]).cuda()
+        hr, lr = sample_windows(store.hr, store.lr, idx, 2)
+        z = torch.randn(4, opt.z_dims, 8, 8, generator=torch.Generator().manual_seed(2))
+        real = lit_wrapper._latent
+        lit_wrapper._latent = lambda b, zd, h, w, device, temp=1.0: z.to(device)
+        try:
+            model.training_step([{'hr': hr, 'lr': lr}, {'hr': hr, 'lr': lr}], 0)
+        finally:
+            lit_wrapper._latent = real
+        results[prec] = (float(model._logged['train']), optim.flat_grads()[0].clone())
+    (l32, g32), (l16, g16) = results['fp32'], results['bf16']
+    assert abs(l16 / l32 - 1) < 2e-2
+    assert rel_l2(g16, g32) < 6e-2
+    cos = float((g16 * g32).sum() / (g16.norm() * g32.norm()))
+    assert cos > 0.998
