@@ -88,11 +88,11 @@ def cpu_baseline(args, opt, seconds_budget=30.0):
     from oracle import sininn_oracle as O
     torch.manual_seed(0)
     b = args.cpu_batch
-    ref = O.SRFlowOracle(3, args.size, args.size, scale=4, num_coupling=args.num_coupling)
+    ref = O.SRFlowOracle(3, args.height, args.width, scale=4, num_coupling=args.num_coupling)
     o = torch.optim.Adam(ref.parameters(), lr=1e-4, betas=(0.9, 0.99), weight_decay=1e-5)
-    hr = torch.rand(b, 3, args.size, args.size)
-    lr = torch.rand(b, opt.lr_dims, args.size // 8, args.size // 8)
-    z = torch.randn(b, opt.z_dims, args.size // 8, args.size // 8)
+    hr = torch.rand(b, 3, args.height, args.width)
+    lr = torch.rand(b, opt.lr_dims, args.height // 8, args.width // 8)
+    z = torch.randn(b, opt.z_dims, args.height // 8, args.width // 8)
     lam = dict(fwd_rec=1.0, fwd_mmd=0.0, latent_nll=0.0, bwd_rec=1.0, bwd_mmd=0.0)
     # host cores actually available to this process (the box's CPU share), not the machine's core count
     cores = min(len(os.sched_getaffinity(0)), int(os.environ.get('SININN_CPU_THREADS', '16')))
@@ -106,8 +106,9 @@ def cpu_baseline(args, opt, seconds_budget=30.0):
         n += 1
     dt = (time.time() - t0) / n if n else tw
     return {'value': b / dt, 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'{n} timed + 1 warm-up training steps of the torch-CPU oracle, batch {b}, '
-                      f'{args.size}x{args.size}, -c {args.num_coupling}, fp32'}
+            'sample': f'{n} timed + 1 warm-up training steps of the torch-CPU oracle (fp32), batch {b} (frames/s = batch / step '
+                      f'time, i.e. per-frame normalised from batch {b}, not the benchmark batch), '
+                      f'{args.width}x{args.height}, -c {args.num_coupling}'}
 
 
 def self_launch(n):
@@ -153,24 +154,85 @@ def rehearse(args, rank, ws):
     return 0
 
 
+CONFIGS = {
+    # BASELINE.json configs[i] -> workload presets (height, width, -c, precision, per-GPU batch)
+    1: dict(height=256, width=256, num_coupling=4, precision='fp32', batch=16,
+            name='BASELINE configs[1]: 8-block INN (SRF, -c 4 x 2 levels), 256x256x3, fp32'),
+    3: dict(height=512, width=512, num_coupling=4, precision='bf16', batch=16,
+            name='BASELINE configs[3] shape: INN at 512x512x3 (SRF, -c 4 x 2 levels), bf16 conv subnets / fp32 flow'),
+    4: dict(height=720, width=1280, num_coupling=12, precision='bf16', batch=16,
+            name='BASELINE configs[4] shape: 720p (1280x720x3), 12 GLOW blocks per level (-c 12), bf16 conv subnets / fp32 flow'),
+}
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 5 PF headline includes 2:1 sparsity)
+
+CLASS_NAMES = ['conv1 forward (+ReLU)', 'conv2 forward + coupling + log-det', 'data gradient of conv2 (+ReLU mask)',
+               'data gradient of conv1 (+skip grad, +fused coupling backward)', 'weight gradients (+slab reduce)',
+               'coupling backward tail (HBM-bound, no FLOPs counted)']
+
+
+def class_roofline(precision):
+    """roofline.classes from the executor's per-launch HIP-event brackets (single-stream steps): algorithmic TF/s per kernel
+    class, its fraction of the dtype's dense MFMA peak, and -- for the Winograd classes of the fp32 path -- the fraction of
+    the f32 matrix pipe the EXECUTED FLOPs occupy (Winograd F(2x2,3x3) executes 2.25x fewer than it is credited with)."""
+    import ctypes as C
+    from sin_inn_amd import _lib
+    n = 12
+    ms, fl, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_int * n)()
+    _lib.check(_lib.lib().sininn_profile_classes_end(n, ms, fl, cnt))
+    out = []
+    for i in range(n):
+        if cnt[i] == 0:
+            continue
+        k = 1 if i >= 6 else 3
+        cls = i % 6
+        wgrad_fp32 = cls == 4                              # weight gradients accumulate on the f32 pipe in both precisions
+        peak = PEAK_F32_MFMA_TFLOPS if (precision == 'fp32' or wgrad_fp32) else PEAK_BF16_MFMA_TFLOPS
+        rec = {'class': f'{k}x{k} {CLASS_NAMES[cls]}', 'launches': cnt[i], 'ms': ms[i]}
+        if fl[i] > 0:
+            tf = fl[i] / (ms[i] * 1e-3) / 1e12
+            rec.update(alg_tflops=tf, peak_tflops=peak, frac=tf / peak, bound='mfma')
+            wino = k == 3 and (precision == 'fp32' or wgrad_fp32)
+            if wino:
+                rec['executed_mfma_frac'] = tf / 2.25 / peak
+                rec['note'] = 'Winograd: executes 2.25x fewer MFMA FLOPs than the algorithmic count'
+        else:
+            rec['bound'] = 'hbm'
+        out.append(rec)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
-    ap.add_argument('--size', type=int, default=256)
-    ap.add_argument('--num-coupling', type=int, default=4, help='GLOW blocks per level (2 levels): 4 -> 8-block INN')
+    ap.add_argument('--config', type=int, default=1, choices=sorted(CONFIGS), help='BASELINE.json configs[] index: 1 = the headline '
+                    '(256x256 bs 16 fp32), 3 = 512x512 bf16, 4 = 720p -c 12 bf16')
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the config preset)')
+    ap.add_argument('--size', type=int, default=None, help='square frame size override')
+    ap.add_argument('--height', type=int, default=None)
+    ap.add_argument('--width', type=int, default=None)
+    ap.add_argument('--num-coupling', type=int, default=None, help='GLOW blocks per level (2 levels): 4 -> 8-block INN')
+    ap.add_argument('--precision', choices=['fp32', 'bf16'], default=None)
     ap.add_argument('--lr-window', type=int, default=10)
     ap.add_argument('--frames', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-batch', type=int, default=2)
+    ap.add_argument('--cpu-batch', type=int, default=None)
     ap.add_argument('--conv-cfg', type=int, default=0, help='diagnostic (sininn_conv_test_hooks force_cfg): 1 / 2 pin 32- / 64-column Winograd blocks')
-    ap.add_argument('--wgrad16', type=int, default=0, help='diagnostic (sininn_wgrad_test_hooks): bit0 16x16x4 tiles, bit1 no Winograd wgrad, bit2 8-row tiles, bit3 8-wave k-split blocks')
+    ap.add_argument('--wgrad16', type=int, default=0, help='diagnostic (sininn_wgrad_test_hooks): bit0 16x16x4 tiles, bit1 no Winograd wgrad, bit2 8-row tiles, bit3 8-wave k-split blocks, bit4 per-conv launches, bit5 per-half groups')
     ap.add_argument('--rehearse', action='store_true', help='CPU rehearsal of the multi-rank plumbing (gloo): rendezvous, '
                     'flat-gradient all-reduce, barrier + max-over-ranks timing, rank-0 JSON line; no kernels run, value is null')
     ap.add_argument('--no-overlap', action='store_true', help='diagnostic: single stream (no pass / wgrad overlap)')
     args = ap.parse_args()
+    preset = CONFIGS[args.config]
+    if args.size is not None:
+        args.height = args.width = args.size
+    for k in ('height', 'width', 'num_coupling', 'precision', 'batch'):
+        if getattr(args, k) is None:
+            setattr(args, k, preset[k])
+    if args.cpu_batch is None:
+        args.cpu_batch = 2 if args.height * args.width <= 256 * 256 else 1
+    custom = any(getattr(args, k) != preset[k] for k in ('height', 'width', 'num_coupling', 'precision', 'batch'))
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher.  Nothing in this process has touched the GPU yet (torch
@@ -197,19 +259,21 @@ def main():
     if args.no_overlap:
         _m.USE_SIDE_STREAM[0] = False
     opt = make_opt(args.num_coupling, args.lr_window)
+    opt.precision = args.precision
     torch.manual_seed(0)                                   # identical random-init weights on every rank
-    model = lit_wrapper.SingleVideoINN(3, args.size, args.size, opt).to(dev)
+    model = lit_wrapper.SingleVideoINN(3, args.height, args.width, opt).to(dev)
     if args.no_overlap:
         model.overlap_passes = False
     optim = model.attach_optimizer()
-    store = FrameStore.synthetic(args.frames, args.size, args.size).to(dev)   # clip resident in HBM before timing
+    store = FrameStore.synthetic(args.frames, args.height, args.width).to(dev)   # clip resident in HBM before timing
     lo, hi = args.lr_window, args.frames - args.lr_window
     gen = torch.Generator().manual_seed(100 + rank)        # each rank draws its own frames (data-parallel shard)
 
-    b, m0 = args.batch, args.batch * (args.size // 4) ** 2
+    lh, lw = args.height // 4, args.width // 4             # level-0 resolution
+    b, m0 = args.batch, args.batch * lh * lw
     co0 = 24
 
-    timer = KernelTimer(args.size // 4, dev)      # forward 3x3 coupling conv (256 -> 2*24 columns) at level-0 resolution
+    timer = KernelTimer(lh, dev)      # forward 3x3 coupling conv (256 -> 2*24 columns) at level-0 resolution
 
     def step():
         idx = torch.randint(lo, hi, (b,), generator=gen).to(dev)
@@ -239,21 +303,30 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
-    # The roofline needs the dominant kernel's duration with the chip to itself: in the timed region above its blocks
-    # interleave with the other pass chain's and the weight-gradient stream's kernels (execution window ~1.7x longer),
-    # and a rocprofv3 trace of this command serialises most of that overlap away.  So the same step is run a few more
-    # times on ONE stream (not part of `value`) and the kernel is timed there; the in-region numbers are reported too.
-    iso = None
-    if not args.no_overlap:
+    # The roofline needs kernel durations with the chip to itself: in the timed region above the blocks of a kernel
+    # interleave with the other pass chain's and the weight-gradient stream's kernels, and a rocprofv3 trace of this
+    # command serialises most of that overlap away.  So the same step is run a few more times on ONE stream (not part of
+    # `value`): the dominant kernel is timed there, and so is every kernel class of the block executor (roofline.classes).
+    iso, classes, iso_ms = None, None, None
+    if True:                                                # every rank runs them: the optimiser step holds a collective
         _m.USE_SIDE_STREAM[0] = False
         model.overlap_passes = False
-        iso = KernelTimer(args.size // 4, dev)
+        iso = KernelTimer(lh, dev)
+        step()                                              # settle on one stream
         barrier()
         iso.start()
-        for _ in range(min(3, args.steps)):
+        _l.lib().sininn_profile_classes_begin()
+        n_iso = min(3, args.steps)
+        t1 = time.perf_counter()
+        for _ in range(n_iso):
             step()
-        barrier()
+        torch.cuda.synchronize()
+        iso_ms = (time.perf_counter() - t1) / n_iso * 1e3
         iso.stop()
+        classes = class_roofline(args.precision)
+        for c in classes:
+            c['ms_per_step'] = c.pop('ms') / n_iso
+            c['launches_per_step'] = c.pop('launches') // n_iso
 
     if rank != 0:
         return
@@ -264,39 +337,62 @@ def main():
     kms = (iso or timer).mean_event_ms()      # HIP events on the launch stream
     flops = 2.0 * m0 * 9 * 256 * (2 * co0)
     roof = None
-    traffic = None
+    bf16 = args.precision == 'bf16'
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, 'profiles', 'traffic_dominant.json')   # PMC pass is a separate rocprofv3 run (committed)
-    if os.path.isfile(tpath):
-        traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
+    if os.path.isfile(tpath) and args.config == 1 and not custom:
+        tj = json.load(open(tpath))
+        traffic, traffic_src = tj.get('hbm_bytes_per_launch'), tj.get('source')
     if kms:
         ach = flops / (kms * 1e-3) / 1e12
-        roof = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
-                'kernel': 'wino_kernel<2,8,2> (fused 3x3 coupling conv 256->48 + affine + log-det, level 0; Winograd '
-                          'F(2x2,3x3): executes 2.25x fewer MFMA FLOPs than the algorithmic direct-conv count used here)',
+        hid_bytes = 2.0 if bf16 else 4.0
+        abytes = hid_bytes * m0 * 256 + 4.0 * m0 * 3 * co0 + hid_bytes * 9 * 256 * 2 * co0
+        kernel = ('conv_bf16_kernel<3,32,1,8,true> (fused 3x3 coupling conv 256->48 + affine + log-det, level 0; direct implicit GEMM on '
+                  'v_mfma_f32_32x32x16_bf16, bf16 hidden tensor in, fp32 flow out)') if bf16 else \
+                 ('wino_kernel<2,8,2> (fused 3x3 coupling conv 256->48 + affine + log-det, level 0; Winograd F(2x2,3x3): executes '
+                  '2.25x fewer MFMA FLOPs than the algorithmic direct-conv count used here)')
+        roof = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
+                'frac': ach / peak, 'traffic': traffic, 'traffic_source': traffic_src,
+                'kernel': kernel,
                 'launches_timed': (iso or timer).count, 'avg_ms': kms,
-                'avg_ms_source': 'HIP events on the launch stream'
-                                 + (', single-stream steps run right after the timed region' if iso is not None else
-                                    ', timed region (single stream)'),
-                'avg_ms_execution_window': (iso or timer).stamp_ms,     # in-kernel wall-clock stamps, same launches
+                'avg_ms_source': 'HIP events on the launch stream, single-stream steps run right after the timed region',
+                'avg_ms_execution_window': (iso or timer).stamp_ms,     # in-kernel wall-clock stamps, same launches (fp32 kernels)
                 'timed_region': {'launches': timer.count, 'avg_ms_execution_window': timer.stamp_ms,
                                  'avg_ms_hip_events': timer.mean_event_ms(),
                                  'note': 'three streams in flight: the window contains other kernels\' blocks'},
-                'alg_flops_per_launch': flops,
-                'alg_bytes_per_launch': 4.0 * (m0 * 256 + m0 * 3 * co0 + 9 * 256 * 2 * co0)}
+                'alg_flops_per_launch': flops, 'alg_bytes_per_launch': abytes}
+        if not bf16:
+            # what the matrix pipe actually executes: Winograd F(2x2,3x3) needs 16 multiplies per 2x2 outputs instead of 36
+            roof['executed_mfma_frac'] = ach / 2.25 / peak
+            roof['bound_note'] = ('algorithmic FLOPs are credited at the direct-convolution count; the f32 matrix pipe is '
+                                  f'{ach / 2.25 / peak:.0%} busy with the Winograd products, the rest of the time goes to the per-lane '
+                                  'input / output transforms (VALU), LDS operand staging and the HBM-bound epilogue (DESIGN 6)')
         # the same launch against the HBM roof (north_star quotes an HBM fraction): algorithmic bytes / time / 8 TB/s
-        abytes = roof['alg_bytes_per_launch']
         roof['hbm'] = {'achieved': abytes / (kms * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                        'frac': abytes / (kms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                       'note': '168 FLOP/B >> the fp32 ridge (20 FLOP/B): the kernel is MFMA-bound, this fraction is low by nature'}
+                       'note': 'FLOP/B far above the ridge: the kernel is matrix-pipe-bound, this fraction is low by nature'}
+        roof['classes'] = classes
+        roof['single_stream_ms_per_step'] = iso_ms
+        # whole-step algorithmic rate (train step = 6 x forward FLOPs)
+        fwd = 0.0
+        for lvl, (mm, cc) in enumerate(((m0, 48), (m0 // 4, 192))):
+            for blk in range(args.num_coupling):
+                kk = 9 if blk % 2 == 0 else 1
+                fwd += 2.0 * mm * kk * (cc // 2 * 256 + 256 * cc) * 2
+        roof['step'] = {'alg_tflop_per_step': 6 * fwd / 1e12, 'alg_tflops': 6 * fwd / (ms_per_step * 1e-3) / 1e12,
+                        'frac_of_peak': 6 * fwd / (ms_per_step * 1e-3) / 1e12 / peak}
     out = {'metric': 'training frames/sec at 256x256 bs=16', 'value': value, 'unit': 'frames/s', 'n_gpus': ws,
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
-           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-           'config': {'workload': f'BASELINE configs[1]: 8-block INN (SRF, -c {args.num_coupling} x 2 levels), '
-                                  f'{args.size}x{args.size}x3 synthetic clip ({args.frames} frames, lr_window '
-                                  f'{args.lr_window}), batch {b}/GPU, full training step (fwd+bwd, rev+bwd, Adam)',
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if bf16 else 'f32', 'data': 'synthetic',
+           'config': {'workload': (preset['name'] if not custom else f'custom: {args.height}x{args.width}x3, -c {args.num_coupling}, {args.precision}')
+                                  + f', synthetic clip ({args.frames} frames, lr_window {args.lr_window}), batch {b}/GPU, '
+                                    'full training step (fwd+bwd, rev+bwd, Adam)',
+                      'baseline_config': args.config, 'height': args.height, 'width': args.width,
                       'global_batch': ws * b, 'num_coupling': args.num_coupling, 'parallelism': f'dp{ws}'},
            'roofline': roof}
+    if args.config != 1 or custom:
+        out['metric'] = f'training frames/sec at {args.width}x{args.height} bs={b}'
     if not args.no_cpu_baseline and ws == 1:
         out['cpu_baseline'] = cpu_baseline(args, opt)
     else:

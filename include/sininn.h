@@ -238,7 +238,18 @@ void sininn_profile_begin(int level_height, unsigned long long* stamps, int max_
 int sininn_profile_end(int* count, float* total_ms);
 int sininn_wall_clock_khz(void);   /* tick rate of the stamps */
 
+/* Per-class timing of the block executor for bench.py's roofline.classes: between begin and end every launch of
+ * sininn_glow_forward / _backward is bracketed by HIP events on its stream.  Classes (index = class + 6 * (ksize == 1)):
+ * 0 conv1 forward (+ReLU), 1 conv2 forward + coupling + log-det, 2 data gradient of conv2 (+ReLU mask), 3 data gradient of
+ * conv1 (+ skip gradient, + fused coupling backward), 4 weight gradients (+ slab reduce), 5 coupling backward tail.
+ * end() synchronises and fills, per class, the summed event time (ms), the summed ALGORITHMIC FLOPs (2 M k^2 Cin N) and
+ * the launch count (n = 12 entries).  The bracket is the kernel's own duration only when everything runs on one stream. */
+#define SININN_PROFILE_CLASSES 12
+void sininn_profile_classes_begin(void);
+int sininn_profile_classes_end(int n, double* ms, double* flops, int* launches);
+
 size_t sininn_glow_saved_floats(int B, int H, int W, int C);
+size_t sininn_glow_saved_floats_dtype(int B, int H, int W, int C, int dtype);   /* dtype 1: bf16 hidden tensors (half the floats) */
 size_t sininn_glow_scratch_bytes(int B, int H, int W, int C, int ksize);
 int sininn_glow_forward(const sininn_glow_args* args, void* stream);
 int sininn_glow_backward(const sininn_glow_args* args, void* stream, void* wgrad_stream);

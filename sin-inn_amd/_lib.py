@@ -104,7 +104,10 @@ _SIGS = {
     'sininn_profile_begin': (None, [C.c_int, C.c_void_p, C.c_int]),
     'sininn_wall_clock_khz': (C.c_int, []),
     'sininn_profile_end': (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+    'sininn_profile_classes_begin': (None, []),
+    'sininn_profile_classes_end': (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     'sininn_glow_saved_floats': (C.c_size_t, [C.c_int] * 4),
+    'sininn_glow_saved_floats_dtype': (C.c_size_t, [C.c_int] * 5),
     'sininn_glow_scratch_bytes': (C.c_size_t, [C.c_int] * 5),
     'sininn_glow_forward': (C.c_int, [C.POINTER(GlowArgs), C.c_void_p]),
     'sininn_glow_backward': (C.c_int, [C.POINTER(GlowArgs), C.c_void_p, C.c_void_p]),

@@ -69,6 +69,8 @@ int pack_bf16_launch(const float* w, const float* bias, int N, int Cin, int ksiz
                      float* b_fwd, int Cdp, void* wb_dgrad, hipStream_t st);
 int frames_to_u8_launch(const float* in, const int64_t is[4], uint8_t* out, int B, int C, int H, int W, int wrap,
                         hipStream_t st);
+void profile_classes_begin();
+int profile_classes_end(int n, double* ms, double* flops, int* launches);
 void profile_begin(int h, unsigned long long* stamps, int max_launches);
 int profile_end(int* count, float* total_ms);
 int softsplat_fwd_launch(const float* in, const float* flow, int B, int C, int H, int W, float* out, hipStream_t st);
@@ -100,7 +102,7 @@ int pack_winograd_launch(const float* w, int N, int Cin, const int* colmap, int 
                          float* u_dgrad, hipStream_t st);
 int bayer_demosaic_launch(const uint8_t* hr, uint8_t* rgb, int T, int H, int W, int scale, int reduce_sum, hipStream_t st);
 int bayer_bin_launch(const uint8_t* hr, uint8_t* lr, int T, int H, int W, int scale, int reduce_sum, hipStream_t st);
-size_t glow_saved_floats(int B, int H, int W, int C);
+size_t glow_saved_floats(int B, int H, int W, int C, int dtype);
 size_t glow_scratch_bytes(int B, int H, int W, int C, int ksize);
 int glow_forward(const sininn_glow_args* a, hipStream_t st);
 int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst);
@@ -213,7 +215,8 @@ int sininn_wall_clock_khz(void) {
   return khz;
 }
 int sininn_profile_end(int* count, float* total_ms) { return profile_end(count, total_ms); }
-size_t sininn_glow_saved_floats(int B, int H, int W, int C) { return glow_saved_floats(B, H, W, C); }
+size_t sininn_glow_saved_floats(int B, int H, int W, int C) { return glow_saved_floats(B, H, W, C, 0); }
+size_t sininn_glow_saved_floats_dtype(int B, int H, int W, int C, int dtype) { return glow_saved_floats(B, H, W, C, dtype); }
 size_t sininn_glow_scratch_bytes(int B, int H, int W, int C, int ksize) { return glow_scratch_bytes(B, H, W, C, ksize); }
 int sininn_glow_forward(const sininn_glow_args* args, void* stream) { return glow_forward(args, ST(stream)); }
 int sininn_glow_backward(const sininn_glow_args* args, void* stream, void* wgrad_stream) {
@@ -314,6 +317,9 @@ int sininn_pack_conv_weights_bf16(const float* w_oihw, const float* bias, int N,
                                   void* wb_fwd, float* b_fwd, int Cdp, void* wb_dgrad, void* stream) {
   return pack_bf16_launch(w_oihw, bias, N, Cin, ksize, colmap, Np, wb_fwd, b_fwd, Cdp, wb_dgrad, ST(stream));
 }
+
+void sininn_profile_classes_begin(void) { profile_classes_begin(); }
+int sininn_profile_classes_end(int n, double* ms, double* flops, int* launches) { return profile_classes_end(n, ms, flops, launches); }
 
 int sininn_frames_to_u8(const float* in, const int64_t in_strides[4], uint8_t* out, int B, int C, int H, int W, int wrap,
                         void* stream) {

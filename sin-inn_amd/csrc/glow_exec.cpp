@@ -101,6 +101,56 @@ static bool prof_pair(hipEvent_t* a, hipEvent_t* b, unsigned long long** stamp) 
   return true;
 }
 
+// ---- per-class timing (bench.py roofline.classes): every launch of the block executor bracketed by HIP events, tagged
+// with its class and its ALGORITHMIC FLOPs (direct-convolution count 2 M k^2 Cin N).  Meaningful on ONE stream only (the
+// bracket then is the kernel's own duration); bench.py runs a few single-stream steps after the timed region for it. ----
+enum { PC_CONV1 = 0, PC_COUPLE = 1, PC_DGRAD2 = 2, PC_DGRAD1 = 3, PC_WGRAD = 4, PC_CBWD = 5, PC_PER_K = 6, PC_N = 12 };
+struct ClassRec { hipEvent_t a, b; int cls; double flops; };
+static bool g_pc_on = false;
+static std::vector<ClassRec> g_pc_recs;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pc_pool;
+
+void profile_classes_begin() {
+  std::lock_guard<std::mutex> lock(g_ev_mutex);
+  for (auto& r : g_pc_recs) g_pc_pool.push_back({r.a, r.b});
+  g_pc_recs.clear();
+  g_pc_on = true;
+}
+
+int profile_classes_end(int n, double* ms, double* flops, int* launches) {
+  std::lock_guard<std::mutex> lock(g_ev_mutex);
+  g_pc_on = false;
+  for (int i = 0; i < n; ++i) { ms[i] = 0.0; flops[i] = 0.0; launches[i] = 0; }
+  for (auto& r : g_pc_recs) {
+    float t = 0.f;
+    if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) {
+      set_error("profile_classes_end: event query failed");
+      return 1;
+    }
+    if (r.cls < n) { ms[r.cls] += t; flops[r.cls] += r.flops; launches[r.cls] += 1; }
+    g_pc_pool.push_back({r.a, r.b});
+  }
+  g_pc_recs.clear();
+  return 0;
+}
+
+struct ClassScope {           // RAII bracket: records the start event now and the end event when it goes out of scope
+  hipStream_t st; hipEvent_t b; bool live;
+  ClassScope(int cls, int ksize, double flops, hipStream_t s) : st(s), b(nullptr), live(false) {
+    if (!g_pc_on) return;
+    std::lock_guard<std::mutex> lock(g_ev_mutex);
+    if (g_pc_recs.size() >= 60000) return;
+    std::pair<hipEvent_t, hipEvent_t> p;
+    if (!g_pc_pool.empty()) { p = g_pc_pool.back(); g_pc_pool.pop_back(); }
+    else if (hipEventCreate(&p.first) != hipSuccess || hipEventCreate(&p.second) != hipSuccess) return;
+    g_pc_recs.push_back(ClassRec{p.first, p.second, cls + (ksize == 1 ? PC_PER_K : 0), flops});
+    (void)hipEventRecord(p.first, st);
+    b = p.second; live = true;
+  }
+  ~ClassScope() { if (live) (void)hipEventRecord(b, st); }
+};
+static inline double conv_flops(size_t M, int k, int cin, int n) { return 2.0 * (double)M * k * k * cin * n; }
+
 struct Half {                 // one half-coupling in execution order
   const sininn_subnet* net;
   int cond_off;               // offset of the conditioning channels in x (-1: the first half's compact output)
@@ -115,11 +165,12 @@ static void halves_of(const sininn_glow_args* a, Half h[2]) {
 }
 
 struct Saved { float *h_a, *h_b, *s_a, *s_b, *ybuf; size_t total; };
-static Saved saved_layout(float* base, size_t M, int co_a, int co_b) {
+static Saved saved_layout(float* base, size_t M, int co_a, int co_b, bool bf16 = false) {
   Saved s;
   size_t o = 0;
-  s.h_a = base + o; o += align64(M * SININN_HIDDEN);
-  s.h_b = base + o; o += align64(M * SININN_HIDDEN);
+  const size_t hid = bf16 ? M * SININN_HIDDEN / 2 : M * SININN_HIDDEN;      // bf16 hidden tensors take half the floats
+  s.h_a = base + o; o += align64(hid);
+  s.h_b = base + o; o += align64(hid);
   s.s_a = base + o; o += align64(M * co_a);
   s.s_b = base + o; o += align64(M * co_b);
   s.ybuf = base + o; o += align64(M * co_a);
@@ -127,10 +178,11 @@ static Saved saved_layout(float* base, size_t M, int co_a, int co_b) {
   return s;
 }
 
-size_t glow_saved_floats(int B, int H, int W, int C) {
+size_t glow_saved_floats(int B, int H, int W, int C, int dtype) {
   const size_t M = (size_t)B * H * W;
   const int big = C - C / 2;
-  return 2 * align64(M * SININN_HIDDEN) + 3 * align64(M * big) + 64;
+  const size_t hid = dtype == 1 ? M * SININN_HIDDEN / 2 : M * SININN_HIDDEN;
+  return 2 * align64(hid) + 3 * align64(M * big) + 64;
 }
 
 struct Scratch { float *dr_b, *dh_b, *dy_first, *dr_a, *dh_a; void* ws; size_t ws_bytes; size_t total_bytes; };
@@ -192,7 +244,7 @@ int glow_forward(const sininn_glow_args* a, hipStream_t st) {
   const int C = a->C;
   Half hv[2];
   halves_of(a, hv);
-  Saved sv = saved_layout(a->saved, M, hv[0].co, hv[1].co);
+  Saved sv = saved_layout(a->saved, M, hv[0].co, hv[1].co, a->dtype == 1);
   const int mode = a->rev ? SININN_CONV_COUPLE_INV : SININN_CONV_COUPLE_FWD;
   const bool bf16 = a->dtype == 1;
   for (int i = 0; i < 2; ++i) {
@@ -206,7 +258,10 @@ int glow_forward(const sininn_glow_args* a, hipStream_t st) {
     c1.B = a->B; c1.H = a->H; c1.W = a->W; c1.ksize = a->ksize; c1.mode = SININN_CONV_RELU;
     c1.out = hbuf; c1.out_stride = SININN_HIDDEN; c1.N = SININN_HIDDEN;
     if (bf16) { c1.winograd = 0; c1.w_bf16 = 1; c1.in_bf16 = 0; c1.out_bf16 = 1; }     // cond fp32 -> h bf16
-    if (int rc = conv_launch(&c1, st)) return rc;
+    {
+      ClassScope sc(PC_CONV1, a->ksize, conv_flops(M, a->ksize, c1.Cin, SININN_HIDDEN), st);
+      if (int rc = conv_launch(&c1, st)) return rc;
+    }
     sininn_conv_args c2 = {};
     c2.in = hbuf; c2.in_stride = SININN_HIDDEN; c2.Cin = SININN_HIDDEN;
     c2.w = h.net->w2; c2.bias = h.net->b2; c2.Np = 2 * h.co; c2.winograd = (h.net->winograd & 2) && a->ksize == 3;
@@ -223,7 +278,10 @@ int glow_forward(const sininn_glow_args* a, hipStream_t st) {
     const bool timed = g_prof_h != 0 && a->ksize == 3 && a->H == g_prof_h && prof_pair(&e0, &e1, &stamp);
     c2.stamp = timed ? stamp : nullptr;
     if (timed) (void)hipEventRecord(e0, st);
-    if (int rc = conv_launch(&c2, st)) return rc;
+    {
+      ClassScope sc(PC_COUPLE, a->ksize, conv_flops(M, a->ksize, SININN_HIDDEN, 2 * h.co), st);
+      if (int rc = conv_launch(&c2, st)) return rc;
+    }
     if (timed) (void)hipEventRecord(e1, st);
   }
   return 0;
@@ -238,7 +296,7 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
   Half hv[2];
   halves_of(a, hv);
   const int co_a = hv[0].co, co_b = hv[1].co, base_a = hv[0].base, base_b = hv[1].base;
-  Saved sv = saved_layout(a->saved, M, co_a, co_b);
+  Saved sv = saved_layout(a->saved, M, co_a, co_b, a->dtype == 1);
   Scratch sc = scratch_layout(a->scratch, B, H, W, C, k, co_a, co_b);
   SININN_CHECK(a->scratch_bytes >= sc.total_bytes, "glow_backward: scratch too small (%zu < %zu)", a->scratch_bytes, sc.total_bytes);
   const int inv = a->rev ? 1 : 0;
@@ -270,13 +328,16 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
                       const float* addend, int add_stride, const int* add_map, float* dcond, int dcond_stride,
                       bool do_coupling, const Fuse* fuse, bool skip_d1, bool last_half) -> int {
     const sininn_subnet* net = h.net;
-    if (do_coupling)
+    if (do_coupling) {
+      ClassScope sc(PC_CBWD, 3, 0.0, st);
       if (int rc = coupling_bwd_launch(dy, dy_stride, dy_map, vy, vy_stride, vy_map, sbuf, a->gld, B, HW, h.co, a->clamp, inv,
                                        dr, a->dx + h.base, C, st)) return rc;
+    }
     if (net->gw2) {
       if (grouped) add_item(hbuf, SININN_HIDDEN, SININN_HIDDEN, dr, 2 * h.co, 2 * h.co, net->gw2, net->gb2, bf16 ? 1 : 0, 0);
       else {
         if (int rc = order_after(wst, st)) return rc;
+        ClassScope scp(PC_WGRAD, k, conv_flops(M, k, SININN_HIDDEN, 2 * h.co), wst);
         if (int rc = wgrad_launch(hbuf, SININN_HIDDEN, SININN_HIDDEN, dr, 2 * h.co, 2 * h.co, B, H, W, k, net->gw2, net->gb2,
                                   sc.ws, sc.ws_bytes, wst)) return rc;
       }
@@ -287,16 +348,23 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
     d2.B = B; d2.H = H; d2.W = W; d2.ksize = k; d2.mode = SININN_CONV_MASK;
     d2.out = dh; d2.out_stride = SININN_HIDDEN; d2.N = SININN_HIDDEN; d2.mask = hbuf; d2.mask_stride = SININN_HIDDEN;
     if (bf16) { d2.winograd = 0; d2.w_bf16 = 1; d2.in_bf16 = 0; d2.out_bf16 = 1; d2.mask_bf16 = 1; }   // dr fp32 -> dh bf16
-    if (int rc = conv_launch(&d2, st)) return rc;
+    {
+      ClassScope scp(PC_DGRAD2, k, conv_flops(M, k, 2 * h.co, SININN_HIDDEN), st);
+      if (int rc = conv_launch(&d2, st)) return rc;
+    }
     if (net->gw1) {
       if (grouped) add_item(cond, cond_stride, cond_cin, dh, SININN_HIDDEN, SININN_HIDDEN, net->gw1, net->gb1, 0, bf16 ? 1 : 0);
       else {
         if (int rc = order_after(wst, st)) return rc;
+        ClassScope scp(PC_WGRAD, k, conv_flops(M, k, cond_cin, SININN_HIDDEN), wst);
         if (int rc = wgrad_launch(cond, cond_stride, cond_cin, dh, SININN_HIDDEN, SININN_HIDDEN, B, H, W, k, net->gw1, net->gb1,
                                   sc.ws, sc.ws_bytes, wst)) return rc;
       }
       if (grouped && (last_half || per_half) && n_items > 0) {     // every input of the group is queued on `st` now
         if (int rc = order_after(wst, st)) return rc;
+        double fl = 0.0;
+        for (int i = 0; i < n_items; ++i) fl += conv_flops(M, k, items[i].Cin, items[i].N);
+        ClassScope scp(PC_WGRAD, k, fl, wst);
         if (int rc = wgrad_group_launch(items, n_items, B, H, W, k, sc.ws, sc.ws_bytes, wst)) return rc;
         n_items = 0;
       }
@@ -317,6 +385,7 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
       d1.out2 = a->dx + hv[0].base; d1.out2_stride = C;
       d1.logdet = const_cast<float*>(a->gld); d1.Co = cond_cin; d1.clamp = a->clamp;
     }
+    ClassScope scp(PC_DGRAD1, k, conv_flops(M, k, SININN_HIDDEN, cond_cin), st);
     return conv_launch(&d1, st);
   };
 
@@ -347,6 +416,9 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
   }
   if (grouped && n_items > 0) {                      // a frozen conv1 in the last half: flush what was collected
     if (int rc = order_after(wst, st)) return rc;
+    double fl = 0.0;
+    for (int i = 0; i < n_items; ++i) fl += conv_flops(M, k, items[i].Cin, items[i].N);
+    ClassScope scp(PC_WGRAD, k, fl, wst);
     if (int rc = wgrad_group_launch(items, n_items, B, H, W, k, sc.ws, sc.ws_bytes, wst)) return rc;
   }
   return 0;

@@ -250,7 +250,8 @@ class _GlowFn(torch.autograd.Function):
         logdet, block._ld_row = block._ld_row, None
         if logdet is None or logdet.shape != (b,) or logdet.device != dev:
             logdet = torch.zeros(b, device=dev, dtype=torch.float32)
-        saved = torch.empty(lib.sininn_glow_saved_floats(b, h, w, c), device=dev, dtype=torch.float32)
+        saved = torch.empty(lib.sininn_glow_saved_floats_dtype(b, h, w, c, 1 if block.precision == 'bf16' else 0), device=dev,
+                            dtype=torch.float32)
         s1, keep1 = _subnet_args(block, block.s1, block.split_len2, dev, need_grad, False)
         s2, keep2 = _subnet_args(block, block.s2, block.split_len1, dev, need_grad, False)
         a = GlowArgs(B=b, H=h, W=w, C=c, ksize=block.ksize, rev=1 if rev else 0, clamp=block.clamp, x=_pv(x),

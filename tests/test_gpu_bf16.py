@@ -6,7 +6,8 @@ Tolerances (stated, separate from the fp32 path's 1e-4):
     order: 1e-4 of the max-norm (fp32 outputs), one bf16 ulp = 2^-8 relative (bf16 outputs);
   * the composed network against the oracle's bf16 EMULATION (operands rounded to bf16, fp32 accumulation, straight-through
     gradients): outputs 2e-2 max-norm / 3e-3 L2 (a hidden value that sits on a bf16 rounding boundary lands on the other
-    side), gradients 5e-2 max-norm / 2e-2 L2 (the HIP path also rounds the coupling-tail gradient and dh to bf16);
+    side), input gradients 5e-2 max-norm / 2e-2 L2, per-tensor parameter gradients 5e-2 L2 (the HIP path also rounds the
+    coupling-tail gradient dr and the hidden gradient dh to bf16, which the emulation's straight-through gradients do not);
   * against the fp32 oracle: 5e-2 L2 on outputs -- the price of bf16 operands, stated so it is not mistaken for parity."""
 import os
 import sys
@@ -155,7 +156,7 @@ def test_bf16_network_matches_emulating_oracle(size, num_coupling):
     assert rel_l2(xg.grad, xe.grad) < 2e-2 and relerr(xg.grad, xe.grad) < 5e-2
     sin_inn_amd.modules.join_side_streams()
     for (n, pg), (_, pe) in zip(net.named_parameters(), emu.named_parameters()):
-        assert rel_l2(pg.grad, pe.grad) < 2e-2, n
+        assert rel_l2(pg.grad, pe.grad) < 5e-2, n
     # reverse direction + round trip: the inverse recomputes the same bf16 subnet outputs from (nearly) the same inputs
     z = torch.randn(2, 192, size[0] // 8, size[1] // 8)
     with torch.no_grad():
