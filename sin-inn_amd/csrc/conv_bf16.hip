@@ -6,11 +6,14 @@
 //     executor's own kernels touch and which therefore live in HBM as bf16: half the bytes of the 67..600 MB round
 //     trip); weights are packed bf16 [tap][column][K] once per optimiser step; accumulation and every epilogue
 //     (bias, ReLU, affine coupling + log-det, ReLU mask, skip-gradient add) run in fp32.
-//   * block = 8 x 16 output pixels x BN = 64 * NT columns, four waves as 2 (pixel rows) x 2 (columns); a wave owns
-//     2 x NT accumulator tiles of 32 x 32 (lane = column, 16 registers = pixel rows), i.e. 64 pixels x 32 NT columns.
-//   * K loop = channel chunk (CK = 32 or 16) x tap, like the fp32 direct kernel: the halo tile of a chunk is staged once
-//     and shifted LDS addresses serve the nine taps; weights of (chunk, tap) are double-buffered; one barrier per
-//     iteration.  All fragment reads are 16-byte ds_read_b128 of 8 consecutive k: pixel / column stride = 2 CK + 16
+//   * block = 16 x 16 output pixels x 64 columns, four waves as 2 (pixel rows) x 2 (columns); a wave owns four
+//     accumulator tiles of 32 x 32 (lane = column, 16 registers = pixel rows), i.e. 128 pixels x 32 columns: the weights
+//     staged per chunk (37 KB, the larger part of the staging traffic) serve 256 pixels, and 5 LDS fragment reads feed 4 MFMAs.
+//   * K loop = channel chunks (CK = 32 or 16): the halo tile of a chunk AND the weights of all nine taps of that chunk are
+//     staged together (one LDS buffer, two barriers per chunk, 36 MFMAs per wave between them; the next chunk's global
+//     loads are in flight under the MFMAs, and the CU's second block computes while this one stages); shifted LDS
+//     addresses serve the taps.  (The first version staged one tap per barrier -- 4 MFMAs per wave per barrier, 15 % of
+//     the bf16 peak.)  All fragment reads are 16-byte ds_read_b128 of 8 consecutive k: pixel / column stride = 2 CK + 16
 //     bytes and an image-row pitch that is a multiple of 256 bytes make every hardware lane group of the read
 //     ({0-3,12-15,20-27}, ...: MI355X_MICROARCH.md, LDS table) hit 16 distinct 4-bank slots.
 //   * epilogue: accumulators -> fp32 LDS tile T[pixel][BN + 4] -> the shared float4 epilogue of the fp32 kernels
@@ -39,11 +42,11 @@ template <int CK> struct BfGeom {
 };
 
 // bf16-output epilogues: T[pixel][BN+4] fp32 -> 8 channels (16 bytes) per store
-template <int BN>
+template <int BN, int NPIX>
 __device__ __forceinline__ void epilogue_bf16(const ConvDevB& q, const float* T, int b, int y0, int x0, int n0, int tid) {
   const ConvDev& p = q.c;
   constexpr int TS = BN + 4, Q = BN / 8;
-  for (int idx = tid; idx < 128 * Q; idx += 256) {
+  for (int idx = tid; idx < NPIX * Q; idx += 256) {
     const int pl = idx / Q, q8 = idx - pl * Q;
     const int col = n0 + q8 * 8;
     const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
@@ -76,24 +79,25 @@ __device__ __forceinline__ void epilogue_bf16(const ConvDevB& q, const float* T,
   }
 }
 
-template <int KS, int CK, int NT, int HT, bool IN_BF16>
+template <int KS, int CK, int HT, bool IN_BF16>
 __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvDevB q) {
   const ConvDev& p = q.c;
-  constexpr int HALO = KS / 2, IW = 16 + 2 * HALO, IH = 8 + 2 * HALO, NPIX_IN = IH * IW, TAPS = KS * KS;
-  constexpr int BN = 64 * NT;
+  // 3x3: 16 x 16 output pixels per block (the nine taps' weights staged per chunk then serve 256 pixels), 4 row tiles of two
+  // pixel rows per wave; 1x1: 8 x 16 pixels (HBM-bound on the hidden tensor: more, smaller blocks stream better)
+  constexpr int TH = (KS == 3) ? 16 : 8, MT = TH / 4;
+  constexpr int HALO = KS / 2, IW = 16 + 2 * HALO, IH = TH + 2 * HALO, NPIX_IN = IH * IW, TAPS = KS * KS;
+  constexpr int BN = 64;
   constexpr int PIXB = BfGeom<CK>::PIXB, PITCH = BfGeom<CK>::pitch(IW);
-  constexpr int IN_BYTES = IH * PITCH, W_BYTES = BN * PIXB;
+  constexpr int IN_BYTES = IH * PITCH, W_TAP = BN * PIXB;
   // staging work items: input = (pixel, 4 fp32 channels -> 8 bytes) or (pixel, 8 bf16 channels -> 16 bytes)
   constexpr int IN_PER_PIX = IN_BF16 ? CK / 8 : CK / 4;
   constexpr int IN_ITEMS = (NPIX_IN * IN_PER_PIX + 255) / 256;
   constexpr int W_PER_COL = CK / 8;                                      // 16-byte pieces per weight column
-  constexpr int W_ITEMS = (BN * W_PER_COL + 255) / 256;
+  constexpr int W_ITEMS = (TAPS * BN * W_PER_COL + 255) / 256;           // all taps of a chunk are staged together
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-  unsigned char* const in_lds0 = smem_b;
-  unsigned char* const in_lds1 = smem_b + IN_BYTES;
-  unsigned char* const w_lds0 = smem_b + 2 * IN_BYTES;
-  unsigned char* const w_lds1 = w_lds0 + W_BYTES;
+  unsigned char* const in_lds = smem_b;
+  unsigned char* const w_lds = smem_b + IN_BYTES;
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -104,159 +108,146 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvDevB q) {
   const int tx = bid % p.tiles_x; bid /= p.tiles_x;
   const int ty = bid % p.tiles_y;
   const int b = bid / p.tiles_y;
-  const int y0 = ty * 8, x0 = tx * 16;
+  const int y0 = ty * TH, x0 = tx * 16;
   const int n0 = blockIdx.y * BN;
 
-  // ---- staging descriptors ---------------------------------------------------------------------------------------
-  int in_goff[IN_ITEMS], in_loff[IN_ITEMS];
-#pragma unroll
-  for (int i = 0; i < IN_ITEMS; ++i) {
+  // ---- staging descriptors (kept small: the kernel lives at the 256-VGPR edge) -----------------------------------------
+  // input: item f = tid + 256 i -> (pixel f / IN_PER_PIX, part f % IN_PER_PIX); only the global offset is kept, the LDS
+  // offset is recomputed when the chunk is stored.  weights: item -> (tap, column, part) is affine in i for a fixed thread.
+  auto in_offset = [&](int i) -> int {
     const int f = tid + 256 * i;
     const int pix = f / IN_PER_PIX, part = f - pix * IN_PER_PIX;
     const int py = pix / IW, px = pix - py * IW;
     const int gy = y0 + py - HALO, gx = x0 + px - HALO;
-    const bool inside = pix < NPIX_IN;
-    const bool inimg = inside && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-    in_loff[i] = inside ? (py * PITCH + px * PIXB + part * (IN_BF16 ? 16 : 8)) : -1;
-    in_goff[i] = inimg ? (((b * p.H + gy) * p.W + gx) * p.in_stride + part * (IN_BF16 ? 8 : 4)) : -1;   // elements
-  }
-  int w_goff[W_ITEMS], w_loff[W_ITEMS];
+    const bool inimg = pix < NPIX_IN && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    return inimg ? (((b * p.H + gy) * p.W + gx) * p.in_stride + part * (IN_BF16 ? 8 : 4)) : -1;          // elements
+  };
+  // bf16 inputs (K = 256: eight chunks) keep the offsets in registers; fp32 inputs (few chunks, twice the items) recompute them
+  int in_goff[IN_BF16 ? IN_ITEMS : 1];
+  if constexpr (IN_BF16) {
 #pragma unroll
-  for (int i = 0; i < W_ITEMS; ++i) {
-    const int f = tid + 256 * i;
-    const int col = f / W_PER_COL, part = f - col * W_PER_COL;
-    const bool inside = col < BN;
-    w_loff[i] = inside ? (col * PIXB + part * 16) : -1;
-    w_goff[i] = (inside && (n0 + col) < p.Np) ? ((n0 + col) * q.Kp + part * 8) : -1;                    // elements
+    for (int i = 0; i < IN_ITEMS; ++i) in_goff[i] = in_offset(i);
   }
+  constexpr int IPT = BN * W_PER_COL;                                    // weight items per tap: 256 (CK 32) or 128 (CK 16)
+  static_assert(IPT == 256 || IPT == 128, "weight staging assumes 64 columns x 2 or 4 pieces");
+  const int w_tap0 = (IPT == 256) ? 0 : (tid >> 7);                      // tap of item i = w_tap0 + i * (256 / IPT)
+  const int w_col = (tid % IPT) / W_PER_COL, w_part = tid % W_PER_COL;
+  const bool w_colok = (n0 + w_col) < p.Np;
+  const int w_l0 = w_tap0 * W_TAP + w_col * PIXB + w_part * 16;
+  const int w_g0 = (w_tap0 * p.Np + n0 + w_col) * q.Kp + w_part * 8;     // elements
+  const int w_gstep = (256 / IPT) * p.Np * q.Kp;
   const int nchunks = q.Kp / CK;
-  const int nit = nchunks * TAPS;
 
-  typedef typename std::conditional<IN_BF16, bf16x8, f32x4>::type in_reg_t;
+  typedef typename std::conditional<IN_BF16, bf16x8, bf16x4>::type in_reg_t;     // fp32 inputs are rounded at load time
   in_reg_t in_reg[IN_ITEMS];
   bf16x8 w_reg[W_ITEMS];
-  auto load_in = [&](int chunk) {
+  auto load_chunk = [&](int chunk) {
 #pragma unroll
     for (int i = 0; i < IN_ITEMS; ++i) {
+      const int part = (tid + 256 * i) % IN_PER_PIX;
       if constexpr (IN_BF16) {
         bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        const int part = (tid + 256 * i) % IN_PER_PIX;
         const bool live = in_goff[i] >= 0 && chunk * CK + part * 8 < p.Cin;     // Cin % 8 == 0 (host check)
         in_reg[i] = live ? *reinterpret_cast<const bf16x8*>(static_cast<const __bf16*>(q.in) + in_goff[i] + chunk * CK) : z;
-      } else {
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const int part = (tid + 256 * i) % IN_PER_PIX;
-        const bool live = in_goff[i] >= 0 && chunk * CK + part * 4 < p.Cin;     // Cin % 4 == 0 (host check)
-        in_reg[i] = live ? *reinterpret_cast<const f32x4*>(static_cast<const float*>(q.in) + in_goff[i] + chunk * CK) : z;
       }
     }
-  };
-  auto store_in = [&](unsigned char* dst) {
-#pragma unroll
-    for (int i = 0; i < IN_ITEMS; ++i)
-      if (in_loff[i] >= 0) {
-        if constexpr (IN_BF16) {
-          *reinterpret_cast<bf16x8*>(dst + in_loff[i]) = in_reg[i];
-        } else {
-          bf16x4 v;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = (__bf16)in_reg[i][j];
-          *reinterpret_cast<bf16x4*>(dst + in_loff[i]) = v;
-        }
-      }
-  };
-  auto load_w = [&](int it) {
-    const int chunk = it / TAPS, tap = it - chunk * TAPS;
 #pragma unroll
     for (int i = 0; i < W_ITEMS; ++i) {
       bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      w_reg[i] = (w_goff[i] >= 0) ? *reinterpret_cast<const bf16x8*>(q.w + (size_t)tap * p.Np * q.Kp + w_goff[i] + chunk * CK) : z;
+      const bool live = w_colok && (w_tap0 + i * (256 / IPT)) < TAPS;
+      w_reg[i] = live ? *reinterpret_cast<const bf16x8*>(q.w + w_g0 + i * w_gstep + chunk * CK) : z;
     }
   };
-  auto store_w = [&](unsigned char* dst) {
+  auto store_chunk = [&](int chunk) {
+    if constexpr (!IN_BF16) {
+      // fp32 inputs (cond, dr: at most six chunks) are not prefetched through registers -- eleven float4 per thread would
+      // push the kernel into scratch; they are loaded, rounded and stored here while the CU's other block computes
+#pragma unroll
+      for (int i = 0; i < IN_ITEMS; ++i) {
+        const int part = (tid + 256 * i) % IN_PER_PIX;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const int go = in_offset(i);
+        const bool live = go >= 0 && chunk * CK + part * 4 < p.Cin;             // Cin % 4 == 0 (host check)
+        if (live) v = *reinterpret_cast<const f32x4*>(static_cast<const float*>(q.in) + go + chunk * CK);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) in_reg[i][j] = (__bf16)v[j];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < IN_ITEMS; ++i) {
+      const int f = tid + 256 * i;
+      const int pix = f / IN_PER_PIX, part = f - pix * IN_PER_PIX;
+      const int py = pix / IW, px = pix - py * IW;
+      if (pix < NPIX_IN)
+        *reinterpret_cast<in_reg_t*>(in_lds + py * PITCH + px * PIXB + part * (IN_BF16 ? 16 : 8)) = in_reg[i];
+    }
 #pragma unroll
     for (int i = 0; i < W_ITEMS; ++i)
-      if (w_loff[i] >= 0) *reinterpret_cast<bf16x8*>(dst + w_loff[i]) = w_reg[i];
+      if ((w_tap0 + i * (256 / IPT)) < TAPS) *reinterpret_cast<bf16x8*>(w_lds + w_l0 + i * (256 / IPT) * W_TAP) = w_reg[i];
   };
 
-  f32x16 acc[2][NT];
+  f32x16 acc[MT];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+    for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
 
-  // A fragment of lane (r, h) for row tile m: pixel (row 4 wm + 2 m + (r >> 4), column r & 15), channels 8 h .. 8 h + 7
-  int a_off[2];
-#pragma unroll
-  for (int m = 0; m < 2; ++m) a_off[m] = (4 * wm + 2 * m + (r >> 4)) * PITCH + (r & 15) * PIXB + h * 16;
-  const int b_off = (wn * NT * 32 + r) * PIXB + h * 16;
+  // A fragment of lane (r, h) for row tile m: pixel (row 8 wm + 2 m + (r >> 4), column r & 15), channels 8 h .. 8 h + 7
+  const int a_off0 = (2 * MT * wm + (r >> 4)) * PITCH + (r & 15) * PIXB + h * 16;
+  const int b_off = (wn * 32 + r) * PIXB + h * 16;
 
-  load_in(0);
-  load_w(0);
-  store_in(in_lds0);
-  store_w(w_lds0);
-  if (nit > 1) load_w(1);
-  if (nchunks > 1) load_in(1);
-  __syncthreads();
-
-  for (int it = 0; it < nit; ++it) {
-    const int chunk = it / TAPS, tap = it - chunk * TAPS;
-    // stage the next iteration's weights (and, at the last tap of a chunk, the next chunk's halo tile) into the buffers
-    // nobody reads during this iteration; then put the loads after that in flight
-    if (it + 1 < nit) store_w(((it + 1) & 1) ? w_lds1 : w_lds0);
-    if (tap == TAPS - 1 && chunk + 1 < nchunks) store_in(((chunk + 1) & 1) ? in_lds1 : in_lds0);
-    if (it + 2 < nit) load_w(it + 2);
-    if (tap == TAPS - 1 && chunk + 2 < nchunks) load_in(chunk + 2);
-
-    const unsigned char* A = ((chunk & 1) ? in_lds1 : in_lds0) + (tap / KS) * PITCH + (tap % KS) * PIXB;
-    const unsigned char* B = (it & 1) ? w_lds1 : w_lds0;
-#pragma unroll
-    for (int ks = 0; ks < CK / 16; ++ks) {
-      bf16x8 af[2], bf[NT];
-#pragma unroll
-      for (int m = 0; m < 2; ++m) af[m] = *reinterpret_cast<const bf16x8*>(A + a_off[m] + ks * 32);
-#pragma unroll
-      for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const bf16x8*>(B + b_off + n * 32 * PIXB + ks * 32);
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
-    }
+  load_chunk(0);
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    __syncthreads();                       // the previous chunk's fragment reads are done (single LDS buffer; the second
+    store_chunk(chunk);                    // block of the CU computes meanwhile)
     __syncthreads();
+    if (chunk + 1 < nchunks) load_chunk(chunk + 1);          // in flight under the MFMAs below
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const unsigned char* A = in_lds + (tap / KS) * PITCH + (tap % KS) * PIXB;
+      const unsigned char* B = w_lds + tap * W_TAP + b_off;
+#pragma unroll
+      for (int ks = 0; ks < CK / 16; ++ks) {
+        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(B + ks * 32);
+        bf16x8 af[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const bf16x8*>(A + a_off0 + m * 2 * PITCH + ks * 32);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], b0, acc[m], 0, 0, 0);
+      }
+    }
   }
+  __syncthreads();
 
   // ---- accumulators -> T[pixel][BN + 4]; D layout: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) ----------
   constexpr int TS = BN + 4;
   float* const T = reinterpret_cast<float*>(smem_b);
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-        const int pl = wm * 64 + m * 32 + row;
-        T[pl * TS + (wn * NT + n) * 32 + r] = acc[m][n][e];
-      }
+    for (int e = 0; e < 16; ++e) {
+      const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+      const int pl = wm * (MT * 32) + m * 32 + row;
+      T[pl * TS + wn * 32 + r] = acc[m][e];
+    }
   __syncthreads();
   if (q.out_bf16) {
-    epilogue_bf16<BN>(q, T, b, y0, x0, n0, tid);
+    epilogue_bf16<BN, TH * 16>(q, T, b, y0, x0, n0, tid);
   } else {
     __shared__ float red[4];
-    conv_epilogue_tile<8, BN, HT, 256>(p, T, b, y0, x0, n0, tid, red);
+    conv_epilogue_tile<TH, BN, HT, 256>(p, T, b, y0, x0, n0, tid, red);
   }
 }
 
-template <int KS, int CK, int NT, int HT, bool IN_BF16>
+template <int KS, int CK, int HT, bool IN_BF16>
 static int launch_one(const ConvDevB& q, hipStream_t st) {
-  constexpr int HALO = KS / 2, IW = 16 + 2 * HALO, IH = 8 + 2 * HALO, BN = 64 * NT;
-  constexpr size_t lds_main = 2 * (size_t)IH * BfGeom<CK>::pitch(IW) + 2 * (size_t)BN * BfGeom<CK>::PIXB;
-  constexpr size_t lds_epi = (size_t)128 * (BN + 4) * sizeof(float);
+  constexpr int TH = (KS == 3) ? 16 : 8;
+  constexpr int HALO = KS / 2, IW = 16 + 2 * HALO, IH = TH + 2 * HALO, BN = 64, TAPS = KS * KS;
+  constexpr size_t lds_main = (size_t)IH * BfGeom<CK>::pitch(IW) + (size_t)TAPS * BN * BfGeom<CK>::PIXB;
+  constexpr size_t lds_epi = (size_t)TH * 16 * (BN + 4) * sizeof(float);
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
-  static_assert(lds <= 160 * 1024, "LDS tile too large");
-  auto k = conv_bf16_kernel<KS, CK, NT, HT, IN_BF16>;
+  static_assert(lds <= 80 * 1024, "two blocks per CU must fit");
+  auto k = conv_bf16_kernel<KS, CK, HT, IN_BF16>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { set_error("conv_bf16: cannot raise LDS limit to %zu", lds); return 1; }
   dim3 grid(q.c.tiles_x * q.c.tiles_y * q.c.B, (q.c.Np + BN - 1) / BN);
@@ -265,21 +256,18 @@ static int launch_one(const ConvDevB& q, hipStream_t st) {
   return 0;
 }
 
-template <int KS, int CK, int NT>
+template <int KS, int CK>
 static int launch_ht(const ConvDevB& q, hipStream_t st) {
   const bool ht16 = q.c.col_tile == 32;            // coupling interleave half-width (irrelevant for the other modes)
-  if (q.in_bf16) return ht16 ? launch_one<KS, CK, NT, 16, true>(q, st) : launch_one<KS, CK, NT, 8, true>(q, st);
+  if (q.in_bf16) return ht16 ? launch_one<KS, CK, 16, true>(q, st) : launch_one<KS, CK, 8, true>(q, st);
   // fp32 inputs only feed the bf16-output convs of the path (cond -> h, dr -> dh): the coupling half-width is irrelevant
   SININN_CHECK(q.out_bf16, "conv_bf16: an fp32-input conv must have a bf16 output");
-  return launch_one<KS, CK, NT, 8, false>(q, st);
+  return launch_one<KS, CK, 8, false>(q, st);
 }
 
 template <int KS>
 static int launch_ks(const ConvDevB& q, hipStream_t st) {
-  const bool ck32 = q.Kp % 32 == 0;
-  const bool wide = q.c.Np > 64;                   // 128-column blocks unless the layer has at most 64 columns
-  if (ck32) return wide ? launch_ht<KS, 32, 2>(q, st) : launch_ht<KS, 32, 1>(q, st);
-  return wide ? launch_ht<KS, 16, 2>(q, st) : launch_ht<KS, 16, 1>(q, st);
+  return (q.Kp % 32 == 0) ? launch_ht<KS, 32>(q, st) : launch_ht<KS, 16>(q, st);
 }
 
 // a->w: bf16 pack [taps][Np][Kp], Kp = Cin rounded up to 16; a->in: fp32 or (in_bf16) bf16; a->out: fp32 or (out_bf16) bf16
@@ -329,7 +317,8 @@ int conv_bf16_launch(const sininn_conv_args* a, hipStream_t st) {
   d.mask = nullptr; d.mask_stride = a->mask_stride;
   d.addend = a->addend; d.addend_stride = a->addend_stride; d.addend_map = a->addend_map;
   d.mode = a->mode; d.col_tile = couple ? a->col_tile : 16; d.stamp = nullptr; d.ablate = 0; d.CK = 0;
-  d.tiles_x = (a->W + 15) / 16; d.tiles_y = (a->H + 7) / 8;
+  const int th = a->ksize == 3 ? 16 : 8;
+  d.tiles_x = (a->W + 15) / 16; d.tiles_y = (a->H + th - 1) / th;
   q.in = a->in; q.w = reinterpret_cast<const __bf16*>(a->w);
   q.out_b = a->out_bf16 ? reinterpret_cast<__bf16*>(a->out) : nullptr;
   q.mask_b = reinterpret_cast<const __bf16*>(a->mask);

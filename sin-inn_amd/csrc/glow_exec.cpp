@@ -212,6 +212,10 @@ static Scratch scratch_layout(void* basep, int B, int H, int W, int C, int ksize
     it[3].Cin = cond_a;        it[3].N = SININN_HIDDEN;
     const size_t gbytes = wgrad_group_workspace_bytes(it, 4, B, H, W, ksize);
     w = gbytes > w ? gbytes : w;
+    // mixed-precision path: 64 x 64 tiles on the bf16 matrix pipe (conv2: h is bf16, conv1: dh is bf16)
+    it[0].in_bf16 = it[2].in_bf16 = 1; it[1].dout_bf16 = it[3].dout_bf16 = 1;
+    const size_t bbytes = wgrad_group_workspace_bytes(it, 4, B, H, W, ksize);
+    w = bbytes > w ? bbytes : w;
   }
   s.ws = base + o;
   s.ws_bytes = w;

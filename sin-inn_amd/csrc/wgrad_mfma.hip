@@ -689,6 +689,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(WgradGroup g) {
 
 struct WgradPlan { int RT, CT, Nr, Cc, nblk, cblk, S, tiles_per_split, ntiles, tiles_x, tiles_y; size_t bytes; bool use32; bool wino; int th; int kh; };
 
+void wgrad_set_bf16_mfma(int on);
 static bool g_wgrad_force16 = false;   // test hook
 static bool g_wgrad_wino = true;       // Winograd weight gradient for 3x3 (test hook bit 1 disables)
 static bool g_wgrad_wino_th8 = false;  // test hook bit 2: 8-row pixel tiles in the Winograd weight gradient
@@ -696,7 +697,7 @@ static bool g_wgrad_wino_kh2 = false;  // test hook bit 3: 8-wave blocks with an
                                        // time, but 3 % slower end to end when other streams' kernels co-run) -- off
 static int g_wgrad_group_mode = 1;     // 1: whole block (4 convs), 2: per half-coupling (2 convs); test hook bit 5 selects 2
 static bool g_wgrad_grouped = true;    // test hook bit 4 clears: the block executor issues one launch pair per conv (round-1 path)
-void wgrad_set_force16(int on) { g_wgrad_force16 = (on & 1) != 0; g_wgrad_wino = (on & 2) == 0; g_wgrad_wino_th8 = (on & 4) != 0; g_wgrad_wino_kh2 = (on & 8) != 0; g_wgrad_grouped = (on & 16) == 0; g_wgrad_group_mode = (on & 32) ? 2 : 1; }
+void wgrad_set_force16(int on) { g_wgrad_force16 = (on & 1) != 0; g_wgrad_wino = (on & 2) == 0; g_wgrad_wino_th8 = (on & 4) != 0; g_wgrad_wino_kh2 = (on & 8) != 0; g_wgrad_grouped = (on & 16) == 0; g_wgrad_group_mode = (on & 32) ? 2 : 1; wgrad_set_bf16_mfma((on & 64) == 0); }
 bool wgrad_grouping_enabled() { return g_wgrad_grouped && g_wgrad_wino && !g_wgrad_force16; }
 int wgrad_group_mode() { return g_wgrad_group_mode; }
 
@@ -779,16 +780,215 @@ int wgrad_launch(const float* in, int in_stride, int Cin, const float* dout, int
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 weight gradient (mixed-precision path): dW[tap][n][c] = sum_pix dout[pix][n] * in[pix + tap][c] on
+// v_mfma_f32_32x32x16_bf16, fp32 accumulation.  MFMA rows = n, columns = c, k = 16 consecutive pixels of an image row.
+//   * both operands need k-contiguous fragments (8 consecutive PIXELS of one channel per lane), i.e. the transpose of the
+//     pixel-major tensors: the tile is transposed while it is staged -- a lane loads the same channel group of two
+//     neighbouring pixels (16-byte global loads), packs (pixel, pixel + 1) pairs and writes one dword per channel into
+//     dT[n][pixel] / iT[c][halo row][x]; the 64 lanes of a wave write 64 consecutive pixel pairs of one channel row.
+//   * the nine taps of a 3x3 conv share the staged halo tile: for tile row y and tap row dy the lane reads the 16 aligned
+//     pixels x = 8h .. 8h + 15 of halo row y + dy (two ds_read_b128) and forms the dx = 0 / 1 / 2 fragments in registers
+//     (dx = 2 is a register re-selection, dx = 1 four v_alignbyte): 7 LDS reads feed 9 MFMAs.
+//   * block = 64 n x 64 c x all taps, waves 2 x 2, wave tile 32 x 32 x 9 taps = 144 accumulator registers; pixel tiles of
+//     8 x 16 are walked split-K style and the fp32 slabs go through the same ordered group reduce as the fp32 kernels.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 wgb_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned wgb_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_bf16_pair(float lo, float hi) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  bf2 v = {(__bf16)lo, (__bf16)hi};
+  return *reinterpret_cast<unsigned*>(&v);
+}
+
+template <int KS>
+__device__ __forceinline__ void wgrad_bf16_body(const WgradDev& p, const int split, const int n0, const int c0, const int zblock) {
+  constexpr int HALO = KS / 2, TAPS = KS * KS, TH = 8;
+  constexpr int IROWS = TH + 2 * HALO, IWV = 16 + 2 * HALO;          // staged halo rows, valid pixels per halo row
+  constexpr int IROWP = 24;                                           // pixels per halo row in LDS (x = 16 .. 23 readable)
+  constexpr int PD = 128 * 2 + 16;                                    // bytes per dout row (channel n): 4-bank step
+  constexpr int PI = ((IROWS * IROWP * 2 + 255) / 256) * 256 + 16;    // bytes per in row (channel c): 4-bank step
+  constexpr int IPAIRS = IROWS * (IWV / 2);                           // pixel pairs of the halo tile
+  __shared__ __attribute__((aligned(16))) unsigned char lds[64 * PD + 64 * PI];
+  unsigned char* const dT = lds;
+  unsigned char* const iT = lds + 64 * PD;
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const int wr = wave & 1, wc = wave >> 1;
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  float bsum = 0.f;
+
+  const int t_begin = split * p.tiles_per_split;
+  const int t_end = min(t_begin + p.tiles_per_split, p.ntiles);
+  const int dgrp = p.dout_bf16 ? 8 : 16;        // channel groups of the 64 staged dout channels (8 bf16 / 4 fp32 per load)
+  const int igrp = p.in_bf16 ? 8 : 16;
+
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    int tt = tile;
+    const int tx = tt % p.tiles_x; tt /= p.tiles_x;
+    const int ty = tt % p.tiles_y;
+    const int b = tt / p.tiles_y;
+    const int y0 = ty * TH, x0 = tx * 16;
+    __syncthreads();                              // the previous tile's fragment reads are done
+    // ---- dout tile: 64 pixel pairs x channel groups, transposed into dT[n][pixel] -------------------------------
+    for (int f = tid; f < 64 * dgrp; f += 256) {
+      const int pp = f & 63, g = f >> 6;
+      const int py = pp >> 3, px = (pp & 7) * 2;
+      const int gy = y0 + py, gx = x0 + px;
+      const bool in0 = gy < p.H && gx < p.W, in1 = gy < p.H && gx + 1 < p.W;
+      const size_t base = ((size_t)(b * p.H + gy) * p.W + gx) * p.dout_stride;
+      if (p.dout_bf16) {
+        const int n = n0 + g * 8;
+        wgb_bf16x8 v0 = {}, v1 = {};
+        if (n < p.N) {                             // N % 8 == 0 on this path (host check)
+          if (in0) v0 = *reinterpret_cast<const wgb_bf16x8*>(reinterpret_cast<const __bf16*>(p.dout) + base + n);
+          if (in1) v1 = *reinterpret_cast<const wgb_bf16x8*>(reinterpret_cast<const __bf16*>(p.dout) + base + p.dout_stride + n);
+        }
+        const unsigned short* a = reinterpret_cast<const unsigned short*>(&v0);
+        const unsigned short* c = reinterpret_cast<const unsigned short*>(&v1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          *reinterpret_cast<unsigned*>(dT + (g * 8 + j) * PD + pp * 4) = (unsigned)a[j] | ((unsigned)c[j] << 16);
+      } else {
+        const int n = n0 + g * 4;
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+        if (n < p.N) {
+          if (in0) v0 = *reinterpret_cast<const f32x4*>(p.dout + base + n);
+          if (in1) v1 = *reinterpret_cast<const f32x4*>(p.dout + base + p.dout_stride + n);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<unsigned*>(dT + (g * 4 + j) * PD + pp * 4) = pack_bf16_pair(v0[j], v1[j]);
+      }
+    }
+    // ---- in halo tile: pixel pairs of (TH + 2) x 18 pixels, transposed into iT[c][row][x] ---------------------------
+    for (int f = tid; f < 64 * igrp; f += 256) {
+      // 64 lanes = 64 consecutive pixel pairs of one channel group; IPAIRS (<= 90) pairs take two rounds
+      const int g = f >> 6, l = f & 63;
+#pragma unroll
+      for (int rnd = 0; rnd < (IPAIRS + 63) / 64; ++rnd) {
+        const int q = l + 64 * rnd;
+        if (q < IPAIRS) {
+          const int row = q / (IWV / 2), pr = q - row * (IWV / 2);
+          const int gy = y0 + row - HALO, gx = x0 + pr * 2 - HALO;
+          const bool rowok = gy >= 0 && gy < p.H;
+          const bool in0 = rowok && gx >= 0 && gx < p.W, in1 = rowok && gx + 1 >= 0 && gx + 1 < p.W;
+          const size_t base = ((size_t)(b * p.H + gy) * p.W + gx) * p.in_stride;     // used only when in0 / in1
+          unsigned char* dst = iT + row * (IROWP * 2) + pr * 4;
+          if (p.in_bf16) {
+            const int c = c0 + g * 8;
+            wgb_bf16x8 v0 = {}, v1 = {};
+            if (c < p.Cin) {                         // Cin % 8 == 0 on this path (host check)
+              if (in0) v0 = *reinterpret_cast<const wgb_bf16x8*>(reinterpret_cast<const __bf16*>(p.in) + base + c);
+              if (in1) v1 = *reinterpret_cast<const wgb_bf16x8*>(reinterpret_cast<const __bf16*>(p.in) + base + p.in_stride + c);
+            }
+            const unsigned short* a = reinterpret_cast<const unsigned short*>(&v0);
+            const unsigned short* e = reinterpret_cast<const unsigned short*>(&v1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              *reinterpret_cast<unsigned*>(dst + (g * 8 + j) * PI) = (unsigned)a[j] | ((unsigned)e[j] << 16);
+          } else {
+            const int c = c0 + g * 4;
+            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+            if (c < p.Cin) {
+              if (in0) v0 = *reinterpret_cast<const f32x4*>(p.in + base + c);
+              if (in1) v1 = *reinterpret_cast<const f32x4*>(p.in + base + p.in_stride + c);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              *reinterpret_cast<unsigned*>(dst + (g * 4 + j) * PI) = pack_bf16_pair(v0[j], v1[j]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- TH k-steps of 16 pixels (one tile row each) -----------------------------------------------------------------
+    const unsigned char* arow = dT + (wr * 32 + r) * PD + h * 16;
+    const unsigned char* brow = iT + (wc * 32 + r) * PI + h * 16;
+#pragma unroll 2
+    for (int y = 0; y < TH; ++y) {
+      const wgb_bf16x8 af = *reinterpret_cast<const wgb_bf16x8*>(arow + y * 32);
+      {
+        const __bf16* av = reinterpret_cast<const __bf16*>(&af);
+        float sacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sacc += (float)av[j];
+        bsum += sacc;
+      }
+#pragma unroll
+      for (int dy = 0; dy < KS; ++dy) {
+        const wgb_u32x4 lo = *reinterpret_cast<const wgb_u32x4*>(brow + (y + dy) * (IROWP * 2));
+        if constexpr (KS == 1) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, *reinterpret_cast<const wgb_bf16x8*>(&lo), acc[0], 0, 0, 0);
+        } else {
+          const wgb_u32x4 hi = *reinterpret_cast<const wgb_u32x4*>(brow + (y + dy) * (IROWP * 2) + 16);
+          wgb_u32x4 s1, s2;
+          s1[0] = __builtin_amdgcn_alignbyte(lo[1], lo[0], 2);
+          s1[1] = __builtin_amdgcn_alignbyte(lo[2], lo[1], 2);
+          s1[2] = __builtin_amdgcn_alignbyte(lo[3], lo[2], 2);
+          s1[3] = __builtin_amdgcn_alignbyte(hi[0], lo[3], 2);
+          s2[0] = lo[1]; s2[1] = lo[2]; s2[2] = lo[3]; s2[3] = hi[0];
+          acc[dy * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, *reinterpret_cast<const wgb_bf16x8*>(&lo), acc[dy * 3 + 0], 0, 0, 0);
+          acc[dy * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, *reinterpret_cast<const wgb_bf16x8*>(&s1), acc[dy * 3 + 1], 0, 0, 0);
+          acc[dy * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, *reinterpret_cast<const wgb_bf16x8*>(&s2), acc[dy * 3 + 2], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- slab write: D[row n = (e & 3) + 8 (e >> 2) + 4 h][col c = r] -------------------------------------------------
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int n = n0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      const int c = c0 + wc * 32 + r;
+      if (n < p.Nr && c < p.Cc) p.partial[(((size_t)split * TAPS + t) * p.Nr + n) * p.Cc + c] = acc[t][e];
+    }
+  // bias partial: lane (r, h) holds the sum over its pixels of dout[.][n0 + 32 wr + r]
+  bsum += __shfl_xor(bsum, 32);
+  if (zblock == 0 && wc == 0 && h == 0) {
+    const int n = n0 + wr * 32 + r;
+    if (n < p.Nr) p.bpartial[(size_t)split * p.Nr + n] = bsum;
+  }
+}
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_group_kernel(WgradGroup g) {
+  const int pi = group_problem(g, blockIdx.x, false);
+  const WgradProb& q = g.p[pi];
+  const int lb = blockIdx.x - q.block_begin;
+  const int split = lb % q.S, nb = (lb / q.S) % q.nblk, cb = lb / (q.S * q.nblk);
+  wgrad_bf16_body<KS>(q.d, split, nb * 64, cb * 64, cb);
+}
+
 // ---- grouped launch (host) ---------------------------------------------------------------------------------------
-struct WgradGroupPlan { WgradGroup g; int grad_blocks, red_blocks; size_t bytes; bool wino; int th; };
+struct WgradGroupPlan { WgradGroup g; int grad_blocks, red_blocks; size_t bytes; bool wino; int th; bool mfma_bf16; };
+
+static bool g_wgrad_bf16_mfma = true;   // test hook bit 6 clears: bf16-operand problems accumulate on the f32 pipe (Winograd)
+void wgrad_set_bf16_mfma(int on) { g_wgrad_bf16_mfma = on != 0; }
 
 static int plan_group(const sininn_wgrad_item* items, int n, int B, int H, int W, int ksize, float* ws, WgradGroupPlan& pl) {
   SININN_CHECK(items && n >= 1 && n <= WG_MAXP, "wgrad_group: 1..%d problems per group", WG_MAXP);
   SININN_CHECK(ksize == 1 || ksize == 3, "wgrad_group: ksize %d not in {1,3}", ksize);
   SININN_CHECK(B > 0 && H > 0 && W > 0, "wgrad_group: bad shape");
-  pl.wino = (ksize == 3);
-  pl.th = pl.wino ? 4 : WG_TH;
-  const int bnw = pl.wino ? 64 : 32, bcw = 32;
+  // a group whose every problem has a bf16 operand runs on the bf16 matrix pipe (one operand is stored as bf16 already,
+  // the other is rounded while it is staged); anything else accumulates exact fp32 products on the f32 pipe
+  bool all_mixed = g_wgrad_bf16_mfma;
+  for (int i = 0; i < n; ++i)
+    all_mixed = all_mixed && (items[i].in_bf16 || items[i].dout_bf16) && items[i].Cin % 8 == 0 && items[i].N % 8 == 0;
+  pl.mfma_bf16 = all_mixed;
+  pl.wino = (ksize == 3) && !pl.mfma_bf16;
+  pl.th = pl.mfma_bf16 ? 8 : (pl.wino ? 4 : WG_TH);
+  const int bnw = (pl.wino || pl.mfma_bf16) ? 64 : 32, bcw = pl.mfma_bf16 ? 64 : 32;
   const int taps = ksize * ksize;
   const int tiles_x = (W + 15) / 16, tiles_y = (H + pl.th - 1) / pl.th;
   const int ntiles = B * tiles_x * tiles_y;
@@ -848,7 +1048,13 @@ int wgrad_group_launch(const sininn_wgrad_item* items, int n, int B, int H, int 
     SININN_CHECK(it.dout_stride >= it.N && it.dout_stride % 4 == 0 && aligned16(it.dout), "wgrad_group: dout must be 16-byte aligned, stride %% 4 == 0");
     SININN_CHECK((it.in_bf16 == 0 || it.in_bf16 == 1) && (it.dout_bf16 == 0 || it.dout_bf16 == 1), "wgrad_group: dtype flags must be 0 / 1");
   }
-  if (pl.wino) {
+  if (pl.mfma_bf16) {
+    if (ksize == 3) hipLaunchKernelGGL((wgrad_bf16_group_kernel<3>), dim3(pl.grad_blocks), dim3(256), 0, st, pl.g);
+    else hipLaunchKernelGGL((wgrad_bf16_group_kernel<1>), dim3(pl.grad_blocks), dim3(256), 0, st, pl.g);
+    SININN_LAUNCH_CHECK("wgrad_bf16_group");
+    if (ksize == 3) hipLaunchKernelGGL((wgrad_reduce_group_kernel<9>), dim3(pl.red_blocks), dim3(256), 0, st, pl.g);
+    else hipLaunchKernelGGL((wgrad_reduce_group_kernel<1>), dim3(pl.red_blocks), dim3(256), 0, st, pl.g);
+  } else if (pl.wino) {
     hipLaunchKernelGGL((wgrad_wino_group_kernel<4, 2>), dim3(pl.grad_blocks), dim3(256), 0, st, pl.g);
     SININN_LAUNCH_CHECK("wgrad_wino_group");
     hipLaunchKernelGGL((wgrad_reduce_group_kernel<9>), dim3(pl.red_blocks), dim3(256), 0, st, pl.g);

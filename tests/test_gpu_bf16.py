@@ -99,25 +99,33 @@ def test_conv_bf16_kernel(ksize, cin, n, hw):
 
 
 @pytest.mark.parametrize('ksize', [3, 1])
-def test_wgrad_group_with_bf16_operands(ksize):
-    """weight gradients whose operands live in HBM as bf16 (h for conv2, dh for conv1): fp32 accumulation of the exact
-    bf16 values == torch autograd on the same values."""
+@pytest.mark.parametrize('pipe', ['bf16', 'f32'])
+@pytest.mark.parametrize('hw', [(13, 21), (32, 32)])
+def test_wgrad_group_with_bf16_operands(ksize, pipe, hw):
+    """weight gradients whose operands live in HBM as bf16 (h for conv2, dh for conv1).  pipe 'bf16' (default): the
+    transposing v_mfma_f32_32x32x16_bf16 kernel, the fp32 operand is rounded to bf16 while it is staged; pipe 'f32' (test
+    hook 64): the f32-pipe kernels convert the bf16 operand up.  Either way the products are exact in fp32, so the result
+    equals torch autograd on the same (rounded) values up to accumulation order."""
     import sin_inn_amd
-    from sin_inn_amd import ops
+    from sin_inn_amd import ops, _lib
     torch.manual_seed(5 + ksize)
-    b, h, w = 2, 13, 21
+    b, (h, w) = 2, hw
     probs, wants = [], []
     for cin, n, in_b, dout_b in ((256, 48, True, False), (24, 256, False, True), (256, 192, True, False), (96, 256, False, True)):
         conv = torch.nn.Conv2d(cin, n, ksize, padding=ksize // 2)
         x, g = torch.randn(b, cin, h, w), torch.randn(b, n, h, w)
-        xv, gv = (bf(x) if in_b else x), (bf(g) if dout_b else g)
+        xv, gv = (bf(x) if (in_b or pipe == 'bf16') else x), (bf(g) if (dout_b or pipe == 'bf16') else g)
         conv(xv).backward(gv)
         xg = nhwc(x).to(torch.bfloat16) if in_b else nhwc(x)
         gg = nhwc(g).to(torch.bfloat16) if dout_b else nhwc(g)
         gw, gbias = torch.zeros_like(conv.weight).cuda(), torch.zeros_like(conv.bias).cuda()
         probs.append((xg, 0, cin, cin, gg, 0, n, n, gw, gbias, in_b, dout_b))
         wants.append((conv.weight.grad, conv.bias.grad, gw, gbias))
-    ops.wgrad_group(probs, b, h, w, ksize)
+    try:
+        _lib.lib().sininn_wgrad_test_hooks(64 if pipe == 'f32' else 0)
+        ops.wgrad_group(probs, b, h, w, ksize)
+    finally:
+        _lib.lib().sininn_wgrad_test_hooks(0)
     for gw_ref, gb_ref, gw, gbias in wants:
         assert relerr(gw, gw_ref) < 1e-4 and relerr(gbias, gb_ref) < 1e-4
 
