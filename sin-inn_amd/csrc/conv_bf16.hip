@@ -46,25 +46,44 @@ template <int BN, int NPIX>
 __device__ __forceinline__ void epilogue_bf16(const ConvDevB& q, const float* T, int b, int y0, int x0, int n0, int tid) {
   const ConvDev& p = q.c;
   constexpr int TS = BN + 4, Q = BN / 8;
-  for (int idx = tid; idx < NPIX * Q; idx += 256) {
-    const int pl = idx / Q, q8 = idx - pl * Q;
-    const int col = n0 + q8 * 8;
+  static_assert(256 % Q == 0, "a thread keeps its column group over the pixel loop");
+  constexpr int ITERS = (NPIX * Q + 255) / 256;
+  const int q8 = tid % Q;
+  const int col = n0 + q8 * 8;
+  if (col >= p.N) return;                                    // N % 8 == 0 is checked on the host
+  const bool masked = p.mode == SININN_CONV_MASK;
+  // loop invariants (bias) hoisted, the per-pixel mask requested one iteration ahead: no global-load latency per iteration
+  f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+  if (!masked && p.bias) {
+    b0 = *reinterpret_cast<const f32x4*>(p.bias + col);
+    b1 = *reinterpret_cast<const f32x4*>(p.bias + col + 4);
+  }
+  auto load_mask = [&](int it) -> bf16x8 {
+    bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (!masked) return z;
+    const int pl = (tid + it * 256) / Q;
     const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
-    if (col < p.N && gy < p.H && gx < p.W) {               // N % 8 == 0 is checked on the host
+    if (!(pl < NPIX && gy < p.H && gx < p.W)) return z;
+    return *reinterpret_cast<const bf16x8*>(q.mask_b + ((size_t)(b * p.H + gy) * p.W + gx) * p.mask_stride + col);
+  };
+  bf16x8 mk_next = load_mask(0);
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const bf16x8 mk = mk_next;
+    if (it + 1 < ITERS) mk_next = load_mask(it + 1);
+    const int pl = (tid + it * 256) / Q;
+    const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+    if (pl < NPIX && gy < p.H && gx < p.W) {
       const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
       f32x4 a = *reinterpret_cast<const f32x4*>(T + pl * TS + q8 * 8);
       f32x4 c = *reinterpret_cast<const f32x4*>(T + pl * TS + q8 * 8 + 4);
-      if (p.mode == SININN_CONV_RELU || p.mode == SININN_CONV_LINEAR) {
-        if (p.bias) {
-          a += *reinterpret_cast<const f32x4*>(p.bias + col);
-          c += *reinterpret_cast<const f32x4*>(p.bias + col + 4);
-        }
+      if (!masked) {
+        a += b0; c += b1;
         if (p.mode == SININN_CONV_RELU) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) { a[j] = fmaxf(a[j], 0.f); c[j] = fmaxf(c[j], 0.f); }
         }
-      } else {                                             // SININN_CONV_MASK: gradient through the ReLU of h
-        const bf16x8 mk = *reinterpret_cast<const bf16x8*>(q.mask_b + pix * p.mask_stride + col);
+      } else {                                             // gradient through the ReLU of h
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           a[j] = ((float)mk[j] > 0.f) ? a[j] : 0.f;
@@ -94,6 +113,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvDevB q) {
   constexpr int IN_ITEMS = (NPIX_IN * IN_PER_PIX + 255) / 256;
   constexpr int W_PER_COL = CK / 8;                                      // 16-byte pieces per weight column
   constexpr int W_ITEMS = (TAPS * BN * W_PER_COL + 255) / 256;           // all taps of a chunk are staged together
+  constexpr bool W_PREFETCH = (KS == 1);                                 // register prefetch of the next chunk's weights
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
   unsigned char* const in_lds = smem_b;
@@ -128,14 +148,20 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvDevB q) {
 #pragma unroll
     for (int i = 0; i < IN_ITEMS; ++i) in_goff[i] = in_offset(i);
   }
-  constexpr int IPT = BN * W_PER_COL;                                    // weight items per tap: 256 (CK 32) or 128 (CK 16)
-  static_assert(IPT == 256 || IPT == 128, "weight staging assumes 64 columns x 2 or 4 pieces");
-  const int w_tap0 = (IPT == 256) ? 0 : (tid >> 7);                      // tap of item i = w_tap0 + i * (256 / IPT)
-  const int w_col = (tid % IPT) / W_PER_COL, w_part = tid % W_PER_COL;
-  const bool w_colok = (n0 + w_col) < p.Np;
-  const int w_l0 = w_tap0 * W_TAP + w_col * PIXB + w_part * 16;
-  const int w_g0 = (w_tap0 * p.Np + n0 + w_col) * q.Kp + w_part * 8;     // elements
-  const int w_gstep = (256 / IPT) * p.Np * q.Kp;
+  // weight items: (tap, column, 16-byte part) flattened as ct = tap * BN + column; item i of a thread is ct0 + i * CT_STEP
+  constexpr int CT_STEP = 256 / W_PER_COL;                               // 128 (CK 16), 64 (CK 32), 16 (CK 128)
+  static_assert(CT_STEP % BN == 0 || (TAPS == 1 && BN % CT_STEP == 0), "weight staging: affine item -> (tap, column)");
+  const int w_ct0 = tid / W_PER_COL, w_part = tid % W_PER_COL;
+  const int w_tap0 = w_ct0 / BN, w_col0 = w_ct0 % BN;
+  constexpr int W_TAP_STEP = (CT_STEP >= BN) ? CT_STEP / BN : 0;         // taps advanced per item
+  constexpr int W_COL_STEP = (CT_STEP >= BN) ? 0 : CT_STEP;              // columns advanced per item (1x1 only)
+  const int w_l0 = w_tap0 * W_TAP + w_col0 * PIXB + w_part * 16;
+  const int w_g0 = (w_tap0 * p.Np + n0 + w_col0) * q.Kp + w_part * 8;   // elements
+  const int w_gstep = (W_TAP_STEP * p.Np + W_COL_STEP) * q.Kp;
+  constexpr int W_LSTEP = W_TAP_STEP * W_TAP + W_COL_STEP * PIXB;
+  auto w_live = [&](int i) -> bool {
+    return (w_tap0 + i * W_TAP_STEP) < TAPS && (w_col0 + i * W_COL_STEP) < BN && (n0 + w_col0 + i * W_COL_STEP) < p.Np;
+  };
   const int nchunks = q.Kp / CK;
 
   typedef typename std::conditional<IN_BF16, bf16x8, bf16x4>::type in_reg_t;     // fp32 inputs are rounded at load time
@@ -151,11 +177,12 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvDevB q) {
         in_reg[i] = live ? *reinterpret_cast<const bf16x8*>(static_cast<const __bf16*>(q.in) + in_goff[i] + chunk * CK) : z;
       }
     }
+    if constexpr (W_PREFETCH) {
 #pragma unroll
-    for (int i = 0; i < W_ITEMS; ++i) {
-      bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      const bool live = w_colok && (w_tap0 + i * (256 / IPT)) < TAPS;
-      w_reg[i] = live ? *reinterpret_cast<const bf16x8*>(q.w + w_g0 + i * w_gstep + chunk * CK) : z;
+      for (int i = 0; i < W_ITEMS; ++i) {
+        bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        w_reg[i] = w_live(i) ? *reinterpret_cast<const bf16x8*>(q.w + w_g0 + i * w_gstep + chunk * CK) : z;
+      }
     }
   };
   auto store_chunk = [&](int chunk) {
@@ -181,9 +208,20 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvDevB q) {
       if (pix < NPIX_IN)
         *reinterpret_cast<in_reg_t*>(in_lds + py * PITCH + px * PIXB + part * (IN_BF16 ? 16 : 8)) = in_reg[i];
     }
+    if constexpr (!W_PREFETCH) {
+      // 3x3: the nine taps' weights (36 VGPRs per thread) are NOT held across the MFMA loop -- with them the kernel sat at
+      // 254 VGPRs and the compiler serialised every fragment read behind its MFMA (ds_read -> lgkmcnt(0) -> v_mfma chains).
+      // They are L2-resident; the load latency is covered by the CU's second block.
+#pragma unroll
+      for (int i = 0; i < W_ITEMS; ++i) {
+        bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        w_reg[i] = w_live(i) ? *reinterpret_cast<const bf16x8*>(q.w + w_g0 + i * w_gstep + chunk * CK) : z;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < W_ITEMS; ++i)
-      if ((w_tap0 + i * (256 / IPT)) < TAPS) *reinterpret_cast<bf16x8*>(w_lds + w_l0 + i * (256 / IPT) * W_TAP) = w_reg[i];
+      if ((w_tap0 + i * W_TAP_STEP) < TAPS && (w_col0 + i * W_COL_STEP) < BN)
+        *reinterpret_cast<bf16x8*>(w_lds + w_l0 + i * W_LSTEP) = w_reg[i];
   };
 
   f32x16 acc[MT];
@@ -196,12 +234,27 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvDevB q) {
   const int a_off0 = (2 * MT * wm + (r >> 4)) * PITCH + (r & 15) * PIXB + h * 16;
   const int b_off = (wn * 32 + r) * PIXB + h * 16;
 
+  // phase stamps (diagnostic, sininn_conv_args.stamp -> 8 words: barrier A, staging, barrier B, load issue, MFMA loop,
+  // epilogue, total, blocks): wave 0 / lane 0 of every block adds its shader-clock deltas
+  const bool stamping = p.stamp != nullptr && tid == 0;
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = stamping ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long tstart = tprev;
+  auto mark = [&](int k) {
+    if (stamping) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph[k] += t - tprev; tprev = t; }
+  };
+
   load_chunk(0);
   for (int chunk = 0; chunk < nchunks; ++chunk) {
+    mark(3);
     __syncthreads();                       // the previous chunk's fragment reads are done (single LDS buffer; the second
+    mark(0);
     store_chunk(chunk);                    // block of the CU computes meanwhile)
+    mark(1);
     __syncthreads();
+    mark(2);
     if (chunk + 1 < nchunks) load_chunk(chunk + 1);          // in flight under the MFMAs below
+    mark(3);
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const unsigned char* A = in_lds + (tap / KS) * PITCH + (tap % KS) * PIXB;
@@ -216,6 +269,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvDevB q) {
         for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], b0, acc[m], 0, 0, 0);
       }
     }
+    mark(4);
   }
   __syncthreads();
 
@@ -237,6 +291,13 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvDevB q) {
     __shared__ float red[4];
     conv_epilogue_tile<TH, BN, HT, 256>(p, T, b, y0, x0, n0, tid, red);
   }
+  if (stamping) {
+    mark(5);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) atomicAdd(p.stamp + k, ph[k]);
+    atomicAdd(p.stamp + 6, tprev - tstart);
+    atomicAdd(p.stamp + 7, 1ull);
+  }
 }
 
 template <int KS, int CK, int HT, bool IN_BF16>
@@ -247,6 +308,7 @@ static int launch_one(const ConvDevB& q, hipStream_t st) {
   constexpr size_t lds_epi = (size_t)TH * 16 * (BN + 4) * sizeof(float);
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   static_assert(lds <= 80 * 1024, "two blocks per CU must fit");
+  static_assert(CK != 16 || KS != 3 || lds_main <= 53 * 1024, "CK 16: three blocks per CU by the main-loop footprint");
   auto k = conv_bf16_kernel<KS, CK, HT, IN_BF16>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { set_error("conv_bf16: cannot raise LDS limit to %zu", lds); return 1; }
@@ -265,9 +327,17 @@ static int launch_ht(const ConvDevB& q, hipStream_t st) {
   return launch_one<KS, CK, 8, false>(q, st);
 }
 
+int g_bf16_force_ck16 = 0;     // diagnostic (SININN_BF16_CK16=1): 16-channel chunks everywhere (3 blocks per CU instead of 2)
+
 template <int KS>
 static int launch_ks(const ConvDevB& q, hipStream_t st) {
-  return (q.Kp % 32 == 0) ? launch_ht<KS, 32>(q, st) : launch_ht<KS, 16>(q, st);
+  static const bool env16 = getenv("SININN_BF16_CK16") != nullptr;
+  if constexpr (KS == 1) {
+    // 1x1 convs are HBM-bound on the hidden tensor: 128-channel chunks (two for K = 256) keep 35 KB of loads in flight
+    // per block and 16 MFMAs per wave between barriers instead of 4
+    if (q.Kp % 128 == 0 && !env16) return launch_ht<1, 128>(q, st);
+  }
+  return (q.Kp % 32 == 0 && !env16 && !g_bf16_force_ck16) ? launch_ht<KS, 32>(q, st) : launch_ht<KS, 16>(q, st);
 }
 
 // a->w: bf16 pack [taps][Np][Kp], Kp = Cin rounded up to 16; a->in: fp32 or (in_bf16) bf16; a->out: fp32 or (out_bf16) bf16
@@ -316,7 +386,7 @@ int conv_bf16_launch(const sininn_conv_args* a, hipStream_t st) {
   d.sbuf = a->sbuf; d.logdet = a->logdet; d.Co = a->Co; d.clamp = a->clamp;
   d.mask = nullptr; d.mask_stride = a->mask_stride;
   d.addend = a->addend; d.addend_stride = a->addend_stride; d.addend_map = a->addend_map;
-  d.mode = a->mode; d.col_tile = couple ? a->col_tile : 16; d.stamp = nullptr; d.ablate = 0; d.CK = 0;
+  d.mode = a->mode; d.col_tile = couple ? a->col_tile : 16; d.stamp = a->stamp; d.ablate = 0; d.CK = 0;
   const int th = a->ksize == 3 ? 16 : 8;
   d.tiles_x = (a->W + 15) / 16; d.tiles_y = (a->H + th - 1) / th;
   q.in = a->in; q.w = reinterpret_cast<const __bf16*>(a->w);
@@ -324,6 +394,7 @@ int conv_bf16_launch(const sininn_conv_args* a, hipStream_t st) {
   q.mask_b = reinterpret_cast<const __bf16*>(a->mask);
   q.Kp = (a->Cin + 15) / 16 * 16;
   q.in_bf16 = a->in_bf16; q.out_bf16 = a->out_bf16;
+
   return a->ksize == 3 ? launch_ks<3>(q, st) : launch_ks<1>(q, st);
 }
 

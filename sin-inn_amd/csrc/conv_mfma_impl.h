@@ -66,6 +66,62 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvDev& p, const float
     constexpr int Q = CB / 4;                        // channel quads per pixel
     const int c_block0 = n0 / 2;
     float ld_acc = 0.f;
+    if constexpr (NTHR % Q == 0) {
+      // a thread's channel quad is the same in every iteration: channel offsets and the packed bias are loop invariants,
+      // and the only per-pixel global input (v) is requested one iteration ahead, so the loop no longer pays a
+      // global-load latency per iteration (it was a third of the bf16 kernel's block time)
+      const int q4 = tid % Q;
+      const int cl = q4 * 4;                         // block-local channel
+      const int c = c_block0 + cl;
+      const bool cok = c < p.Co;
+      const int tcol = (cl / HT) * (2 * HT) + (cl % HT);
+      f32x4 bs = {0.f, 0.f, 0.f, 0.f}, bt = bs;
+      if (p.bias && cok) {
+        bs = *reinterpret_cast<const f32x4*>(p.bias + n0 + tcol);
+        bt = *reinterpret_cast<const f32x4*>(p.bias + n0 + tcol + HT);
+      }
+      constexpr int ITERS = (NPIX * Q + NTHR - 1) / NTHR;
+      auto load_v = [&](int it) -> f32x4 {
+        const int pl = (tid + it * NTHR) / Q;
+        const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        if (!(cok && pl < NPIX && gy < p.H && gx < p.W)) return z;
+        return *reinterpret_cast<const f32x4*>(p.v + ((size_t)(b * p.H + gy) * p.W + gx) * p.v_stride + c);
+      };
+      f32x4 v_next = load_v(0);
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const f32x4 v4 = v_next;
+        if (it + 1 < ITERS) v_next = load_v(it + 1);
+        const int pl = (tid + it * NTHR) / Q;
+        const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+        if (cok && pl < NPIX && gy < p.H && gx < p.W) {
+          f32x4 s4 = *reinterpret_cast<const f32x4*>(T + pl * TS + tcol) + bs;
+          f32x4 t4 = *reinterpret_cast<const f32x4*>(T + pl * TS + tcol + HT) + bt;
+          if (T2) {
+            s4 += *reinterpret_cast<const f32x4*>(T2 + pl * TS + tcol);
+            t4 += *reinterpret_cast<const f32x4*>(T2 + pl * TS + tcol + HT);
+          }
+          const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
+          f32x4 y4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float L = glow_log_e(s4[j], p.clamp);
+            const float e = expf(L);
+            if (MODE == SININN_CONV_COUPLE_FWD) { y4[j] = e * v4[j] + t4[j]; ld_acc += L; }
+            else { y4[j] = (v4[j] - t4[j]) / e; ld_acc -= L; }
+          }
+          if (p.out_map) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p.out[pix * p.out_stride + p.out_map[c + j]] = y4[j];
+          } else {
+            *reinterpret_cast<f32x4*>(p.out + pix * p.out_stride + c) = y4;
+          }
+          if (p.out2) *reinterpret_cast<f32x4*>(p.out2 + pix * p.out2_stride + c) = y4;
+          if (p.sbuf) *reinterpret_cast<f32x4*>(p.sbuf + pix * p.Co + c) = s4;
+        }
+      }
+    } else
     for (int idx = tid; idx < NPIX * Q; idx += NTHR) {
       const int pl = idx / Q, q4 = idx - pl * Q;
       const int cl = q4 * 4;                         // block-local channel
@@ -116,6 +172,59 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvDev& p, const float
     }
   } else {
     constexpr int Q = BN / 4;
+    if constexpr (NTHR % Q == 0) {
+      constexpr int ITERS = (NPIX * Q + NTHR - 1) / NTHR;
+      const bool act = MODE == SININN_CONV_RELU || MODE == SININN_CONV_LINEAR || MODE == SININN_CONV_LRELU;
+      const bool plain_add = MODE == SININN_CONV_ADD && p.addend_map == nullptr;
+      const int colq = n0 + (tid % Q) * 4;           // this thread's column quad in every iteration
+      if ((act || MODE == SININN_CONV_MASK || plain_add) && colq + 3 < p.N) {
+        // hot modes, full quads: the bias is a loop invariant; the per-pixel side input (mask / addend) is requested one
+        // iteration ahead.  Partial quads and the other modes take the general loop below.
+        f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && (act || plain_add)) bq = *reinterpret_cast<const f32x4*>(p.bias + colq);
+        auto side = [&](int it) -> f32x4 {
+          f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          if (act) return z;
+          const int pl = (tid + it * NTHR) / Q;
+          const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+          if (!(pl < NPIX && gy < p.H && gx < p.W)) return z;
+          const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
+          return (MODE == SININN_CONV_MASK) ? *reinterpret_cast<const f32x4*>(p.mask + pix * p.mask_stride + colq)
+                                            : *reinterpret_cast<const f32x4*>(p.addend + pix * p.addend_stride + colq);
+        };
+        f32x4 side_next = side(0);
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+          const f32x4 sd = side_next;
+          if (it + 1 < ITERS) side_next = side(it + 1);
+          const int pl = (tid + it * NTHR) / Q;
+          const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+          if (pl < NPIX && gy < p.H && gx < p.W) {
+            const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
+            f32x4 val = *reinterpret_cast<const f32x4*>(T + pl * TS + (tid % Q) * 4);
+            if (T2) val += *reinterpret_cast<const f32x4*>(T2 + pl * TS + (tid % Q) * 4);
+            if (act) {
+              val += bq;
+              if (MODE == SININN_CONV_RELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) val[j] = fmaxf(val[j], 0.f);
+              } else if (MODE == SININN_CONV_LRELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) val[j] = val[j] > 0.f ? val[j] : val[j] * p.clamp;
+              }
+            } else if (MODE == SININN_CONV_MASK) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) val[j] = (sd[j] > 0.f) ? val[j] : 0.f;
+            } else {
+              val += bq;
+              val += sd;
+            }
+            *reinterpret_cast<f32x4*>(p.out + pix * p.out_stride + colq) = val;
+          }
+        }
+        return;
+      }
+    }
     for (int idx = tid; idx < NPIX * Q; idx += NTHR) {
       const int pl = idx / Q, q4 = idx - pl * Q;
       const int col = n0 + q4 * 4;

@@ -88,3 +88,22 @@ def test_infer_writes_frames(tmp_path):
     assert len(outs) == 1 and outs[0].shape == (len(data), 3, 32, 32) and torch.isfinite(outs[0]).all()
     model.infer(get_loader(data, 40), opt, save_images=str(tmp_path / 'frames'))
     assert len(os.listdir(tmp_path / 'frames')) == len(data)
+
+
+def test_cli_training_under_two_ranks(tmp_path):
+    """`main.py train` launched with torch.distributed.run, 2 ranks (gloo: they share the test box's single GPU): rank shards of
+    unequal natural length (3 training frames over 2 ranks) still run the same number of steps, rank 0 writes the checkpoint."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0', SININN_DIST_BACKEND='gloo',
+               SININN_FORCE_DEVICE='0')
+    wd = str(tmp_path / 'exp')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29741', os.path.join(ROOT, 'main.py'), 'train', '--synthetic', '52', '32', '32', '--fps', '10',
+           '--lr_window', '1', '-c', '1', '-b', '1', '-e', '2', '--save_iter', '2', '-p', '1', '-w', wd, '--suffix', 'dp']
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    import glob
+    ckpts = glob.glob(os.path.join(wd, 'train', '*', 'checkpoints', 'epoch=1.ckpt'))
+    assert len(ckpts) == 1
+    ck = torch.load(ckpts[0], map_location='cpu')
+    # 52 frames, fps 10 -> train frames [11, 23, 35]: 3 positions over 2 ranks -> padded to 4 -> 2 steps per rank per epoch
+    assert ck['global_step'] == 4
