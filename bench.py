@@ -223,6 +223,9 @@ def main():
     ap.add_argument('--rehearse', action='store_true', help='CPU rehearsal of the multi-rank plumbing (gloo): rendezvous, '
                     'flat-gradient all-reduce, barrier + max-over-ranks timing, rank-0 JSON line; no kernels run, value is null')
     ap.add_argument('--no-overlap', action='store_true', help='diagnostic: single stream (no pass / wgrad overlap)')
+    ap.add_argument('--overlap', choices=['auto', 'full', 'wgrad', 'none'], default='auto',
+                    help='full: forward / reverse pass chains on two streams + weight gradients on a third (default below 2 M level-0 '
+                         'pixels per batch); wgrad: one chain + the weight-gradient stream; none == --no-overlap')
     args = ap.parse_args()
     preset = CONFIGS[args.config]
     if args.size is not None:
@@ -262,8 +265,14 @@ def main():
     opt.precision = args.precision
     torch.manual_seed(0)                                   # identical random-init weights on every rank
     model = lit_wrapper.SingleVideoINN(3, args.height, args.width, opt).to(dev)
-    if args.no_overlap:
+    if args.no_overlap or args.overlap == 'none':
+        args.no_overlap = True
+        _m.USE_SIDE_STREAM[0] = False
         model.overlap_passes = False
+    elif args.overlap == 'wgrad':
+        model.overlap_passes = False
+    elif args.overlap == 'full':
+        model.overlap_passes = True
     optim = model.attach_optimizer()
     store = FrameStore.synthetic(args.frames, args.height, args.width).to(dev)   # clip resident in HBM before timing
     lo, hi = args.lr_window, args.frames - args.lr_window

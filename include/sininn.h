@@ -134,6 +134,8 @@ typedef struct sininn_conv_args {
   int out_bf16;                                    /* `out` holds bf16 (RELU / LINEAR / MASK modes; an fp32-input conv must
                                                       set it); else fp32 through the mode's regular epilogue              */
   int mask_bf16;                                   /* MASK mode: `mask` holds bf16                                        */
+  int in_group_stride;                             /* experimental, Winograd kernels: > 0 = the input is channel-group-major
+                                                      [Cin/8][B*H*W][8] with this many floats between groups (in_stride == 8) */
 } sininn_conv_args;
 
 int sininn_conv(const sininn_conv_args* args, void* stream);

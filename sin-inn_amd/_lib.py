@@ -33,7 +33,7 @@ class ConvArgs(C.Structure):
         ('mask', c_f), ('mask_stride', C.c_int),
         ('addend', c_f), ('addend_stride', C.c_int), ('addend_map', c_i),
         ('stamp', C.c_void_p),
-        ('w_bf16', C.c_int), ('in_bf16', C.c_int), ('out_bf16', C.c_int), ('mask_bf16', C.c_int),
+        ('w_bf16', C.c_int), ('in_bf16', C.c_int), ('out_bf16', C.c_int), ('mask_bf16', C.c_int), ('in_group_stride', C.c_int),
     ]
 
 

@@ -27,7 +27,7 @@ int conv_launch(const sininn_conv_args* a, hipStream_t st) {
   SININN_CHECK((long)a->B * a->H * a->W * (long)(a->in_stride > a->out_stride ? a->in_stride : a->out_stride) < (1l << 31),
                "conv: tensor too large for 32-bit pixel offsets");
   SININN_CHECK(a->in && a->w && a->out, "conv: null tensor pointer");
-  SININN_CHECK(a->in_stride >= a->Cin && a->in_stride % 4 == 0 && aligned16(a->in),
+  SININN_CHECK((a->in_stride >= a->Cin || a->in_group_stride > 0) && a->in_stride % 4 == 0 && aligned16(a->in),
                "conv: input must be 16-byte aligned with stride %% 4 == 0 (stride=%d)", a->in_stride);
   SININN_CHECK(aligned16(a->w), "conv: packed weights must be 16-byte aligned");
   const bool couple = a->mode == SININN_CONV_COUPLE_FWD || a->mode == SININN_CONV_COUPLE_INV;
@@ -71,6 +71,8 @@ int conv_launch(const sininn_conv_args* a, hipStream_t st) {
   d.col_tile = a->col_tile;
   d.stamp = a->stamp;
   d.ablate = g_ablate;
+  d.in_chunk = a->in_group_stride > 0 ? a->in_group_stride : 8;
+  if (a->in_group_stride > 0) SININN_CHECK(a->winograd && a->in_stride == 8, "conv: the channel-group-major input layout needs the Winograd kernels and in_stride == 8");
   SININN_CHECK(a->mode >= 0 && a->mode <= SININN_CONV_ADD_CBWD_INV, "conv: unknown mode %d", a->mode);
   // channel chunk: the largest of 32/24/16/8 that divides Cin
   int ck = 8;

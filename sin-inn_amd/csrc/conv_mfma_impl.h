@@ -34,6 +34,8 @@ struct ConvDev {
   int mode;
   int col_tile;   // coupling (s|t) interleave width of the packed weights (16 or 32)
   unsigned long long* stamp;   // optional {start, end} wall-clock words (sininn_conv_args.stamp)
+  int in_chunk;   // floats between consecutive 8-channel groups of one input pixel: 8 for pixel-major tensors; B*H*W*8 for
+                  // the channel-group-major layout [C/8][pixel][8] (then in_stride == 8) -- Winograd kernels only
   int ablate;   // diagnostic only (tools/bench_kernels.py --ablate): 1 skip staging, 2 skip loop barrier, 4 skip LDS reads
 };
 

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256 * CG, 2 / CG) void wino32_kernel(ConvDev p) {
 #pragma unroll
     for (int r = 0; r < IN_F4; ++r) {
       f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      in_reg[r] = (in_goff[r] >= 0) ? *reinterpret_cast<const f32x4*>(p.in + in_goff[r] + chunk * CK) : z;
+      in_reg[r] = (in_goff[r] >= 0) ? *reinterpret_cast<const f32x4*>(p.in + in_goff[r] + (size_t)chunk * p.in_chunk) : z;
     }
 #pragma unroll
     for (int r = 0; r < U_F4; ++r) {

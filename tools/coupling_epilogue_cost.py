@@ -33,3 +33,20 @@ for name, use_map, use_out2, use_s in (('plain stores', 0, 0, 0), ('+ out_map (f
     for _ in range(20): ops.conv(**kw)
     t1.record(); torch.cuda.synchronize()
     print(f'{name:36s} {t0.elapsed_time(t1) / 20 * 1e3:7.1f} us')
+
+# channel-group-major hidden tensor [C/8][pixel][8]: every halo row of a chunk is one contiguous run
+m = b * h * w
+hid_g = hid.reshape(m, cin // 8, 8).permute(1, 0, 2).contiguous()
+out_a, out_b = torch.empty_like(x), torch.empty_like(x)
+base = dict(w=ops.ptr(wf), bias=ops.ptr(bfw), Np=2 * co, winograd=1, B=b, H=h, W=w, ksize=3, mode=_lib.CONV_COUPLE_FWD, out_stride=48,
+            v=ops.ptr(x), v_stride=48, Co=co, clamp=1.2, col_tile=ops.coupling_tile(co), Cin=cin)
+for name, kw in (('pixel-major input', dict(in_=ops.ptr(hid), in_stride=cin, out=ops.ptr(out_a))),
+                 ('group-major input', dict(in_=ops.ptr(hid_g), in_stride=8, in_group_stride=m * 8, out=ops.ptr(out_b)))):
+    kw = dict(base, **kw)
+    for _ in range(3): ops.conv(**kw)
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(20): ops.conv(**kw)
+    t1.record(); torch.cuda.synchronize()
+    print(f'{name:36s} {t0.elapsed_time(t1) / 20 * 1e3:7.1f} us')
+print('same result:', bool(torch.equal(out_a[..., :co], out_b[..., :co])), 'max abs diff', float((out_a[..., :co] - out_b[..., :co]).abs().max()))
