@@ -203,3 +203,40 @@ def test_bf16_training_step_runs_and_tracks_fp32():
     assert rel_l2(g16, g32) < 6e-2
     cos = float((g16 * g32).sum() / (g16.norm() * g32.norm()))
     assert cos > 0.998
+
+
+@pytest.mark.parametrize('shape,num_coupling,with_grads', [((512, 512), 4, True), ((720, 1280), 12, False)])
+def test_bf16_at_baseline_config_shapes(shape, num_coupling, with_grads):
+    """BASELINE configs[3] (512x512, -c 4) and configs[4] (1280x720, -c 12) at their own shapes, batch 1, bf16 path against
+    the oracle's bf16 emulation: forward values and log-det (both configs), the reverse direction and gradients (config 3;
+    the 24-block 720p backward is minutes of CPU oracle time), plus the HIP round trip."""
+    import sin_inn_amd
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    net, ref, emu, opt = _nets(shape, num_coupling, lr_window=10, seed=5)
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(1, 3, *shape, generator=g)
+    xg = x.cuda().requires_grad_(with_grads)
+    xe = x.clone().requires_grad_(with_grads)
+    if with_grads:
+        yg, ye = net(xg), emu(xe)
+    else:
+        with torch.no_grad():
+            yg, ye = net(xg), emu(xe)
+    assert yg.shape == (1, 192, shape[0] // 8, shape[1] // 8)
+    # 16 / 48 subnets deep: a hidden value on a bf16 rounding boundary lands on the other side in a few places
+    assert rel_l2(yg, ye) < 1e-2 and relerr(yg, ye) < 1e-1
+    assert relerr(net.log_jacobian(), emu.log_jacobian()) < 2e-2
+    with torch.no_grad():
+        back = net(yg.detach(), rev=True)
+        assert rel_l2(back, x) < 1e-2
+    if with_grads:
+        wgt = torch.randn(ye.shape, generator=g)
+        (ye * wgt).sum().backward(); (yg * wgt.cuda()).sum().backward()
+        assert rel_l2(xg.grad, xe.grad) < 5e-2
+        sin_inn_amd.modules.join_side_streams()
+        flat_g = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu()
+        flat_e = torch.cat([p.grad.reshape(-1) for p in emu.parameters()])
+        assert rel_l2(flat_g, flat_e) < 5e-2
+        z = torch.randn(1, 192, shape[0] // 8, shape[1] // 8, generator=g)
+        with torch.no_grad():
+            assert rel_l2(net(z.cuda(), rev=True), emu(z, rev=True)) < 1e-2

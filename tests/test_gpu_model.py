@@ -312,6 +312,32 @@ def test_bigger_configs_properties():
         torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize('shape,num_coupling', [((512, 512), 4), ((720, 1280), 12)])
+def test_fp32_forward_parity_at_bigger_config_shapes(shape, num_coupling):
+    """The fp32 path against the oracle at the SHAPES of BASELINE configs[3] / [4] (512x512 -c 4; 1280x720 -c 12), batch 1:
+    forward values, log-det and the inverse direction at the path's 1e-4 (their bf16 arithmetic is covered by
+    tests/test_gpu_bf16.py::test_bf16_at_baseline_config_shapes)."""
+    import archs
+    from oracle import sininn_oracle as O
+    torch.set_num_threads(min(16, len(__import__('os').sched_getaffinity(0))))
+    torch.manual_seed(13)
+    opt = make_opt(num_coupling=num_coupling, lr_window=10)
+    net = archs.UncondSRFlow(3, shape[0], shape[1], opt)
+    ref = O.SRFlowOracle(3, shape[0], shape[1], scale=4, num_coupling=num_coupling)
+    copy_weights(ref, net)
+    net.cuda()
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(1, 3, *shape, generator=g)
+    with torch.no_grad():
+        yg, yc = net(x.cuda()), ref(x)
+        assert relerr(yg, yc) < RTOL
+        assert relerr(net.log_jacobian(), ref.log_jacobian()) < RTOL
+        # inverse direction on the ORACLE's forward output (a latent that belongs to an image: a random z through 24 random
+        # blocks is ill-conditioned -- two correct fp32 evaluations of it differ by 8e-3 -- and says nothing about the kernels)
+        assert relerr(net(yc.cuda(), rev=True), x) < RTOL
+        assert relerr(net.log_jacobian(), -ref.log_jacobian()) < RTOL
+
+
 @pytest.mark.parametrize('arch', ['SRF', 'IRN'])
 def test_training_is_bitwise_reproducible(arch):
     """Two identical runs (same seed, frames, latents) give bitwise identical weights after 3 steps: the forward / reverse
