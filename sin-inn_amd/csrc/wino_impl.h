@@ -116,6 +116,10 @@ __global__ __launch_bounds__(256 * CG, 2 / CG) void wino_kernel(ConvDev p) {
   for (int q = 0; q < 16; ++q)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[q][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // a wave whose second column tile lies entirely beyond the packed columns (Np = 48 in a 64-column block: the level-0
+  // coupling conv) skips that tile's MFMAs: its SIMD partner of the other column group then has the matrix pipe to itself
+  // for a quarter of the time (wave-uniform branch; the U fragments are still read so the counted waits stay valid)
+  const bool tile1_live = (n0 + grp * BG + 16) < p.Np;
 
   load_chunk(0);
   store_chunk(in_lds0, u_lds0);
@@ -165,26 +169,29 @@ __global__ __launch_bounds__(256 * CG, 2 / CG) void wino_kernel(ConvDev p) {
     constexpr int PF = 2;
     static_assert(NT == 2, "the wait counts below assume two column tiles per wave");
     f32x2 bf[PF + 1][NT];
-    static_for<0, PF>([&](auto qq) {
-      constexpr int q = decltype(qq)::value;
-      bf[q][0] = lds_read_b64<((q * BN) * SU) * 4>(Uc);
-      bf[q][1] = lds_read_b64<((q * BN + 16) * SU) * 4>(Uc);
-    });
-    static_for<0, 16>([&](auto qq) {
-      constexpr int q = decltype(qq)::value;
-      if constexpr (q + PF < 16) {
-        bf[(q + PF) % (PF + 1)][0] = lds_read_b64<(((q + PF) * BN) * SU) * 4>(Uc);
-        bf[(q + PF) % (PF + 1)][1] = lds_read_b64<(((q + PF) * BN + 16) * SU) * 4>(Uc);
-      }
-      constexpr int newer = (q + PF < 16 ? PF : 15 - q) * NT;     // reads issued after this position's
-      lds_wait<newer>(bf[q % (PF + 1)][0], bf[q % (PF + 1)][1]);
-#pragma unroll
-      for (int n = 0; n < NT; ++n)
-        acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q >> 2][q & 3].x, bf[q % (PF + 1)][n].x, acc[q][n], 0, 0, 0);
-#pragma unroll
-      for (int n = 0; n < NT; ++n)
-        acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q >> 2][q & 3].y, bf[q % (PF + 1)][n].y, acc[q][n], 0, 0, 0);
-    });
+    auto positions = [&](auto live1_tag) {
+      constexpr bool LIVE1 = decltype(live1_tag)::value;
+      static_for<0, PF>([&](auto qq) {
+        constexpr int q = decltype(qq)::value;
+        bf[q][0] = lds_read_b64<((q * BN) * SU) * 4>(Uc);
+        if constexpr (LIVE1) bf[q][1] = lds_read_b64<((q * BN + 16) * SU) * 4>(Uc);
+      });
+      static_for<0, 16>([&](auto qq) {
+        constexpr int q = decltype(qq)::value;
+        if constexpr (q + PF < 16) {
+          bf[(q + PF) % (PF + 1)][0] = lds_read_b64<(((q + PF) * BN) * SU) * 4>(Uc);
+          if constexpr (LIVE1) bf[(q + PF) % (PF + 1)][1] = lds_read_b64<(((q + PF) * BN + 16) * SU) * 4>(Uc);
+        }
+        constexpr int newer = (q + PF < 16 ? PF : 15 - q) * (LIVE1 ? 2 : 1);     // reads issued after this position's
+        if constexpr (LIVE1) lds_wait<newer>(bf[q % (PF + 1)][0], bf[q % (PF + 1)][1]);
+        else lds_wait<newer>(bf[q % (PF + 1)][0]);
+        acc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q >> 2][q & 3].x, bf[q % (PF + 1)][0].x, acc[q][0], 0, 0, 0);
+        if constexpr (LIVE1) acc[q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q >> 2][q & 3].x, bf[q % (PF + 1)][1].x, acc[q][1], 0, 0, 0);
+        acc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q >> 2][q & 3].y, bf[q % (PF + 1)][0].y, acc[q][0], 0, 0, 0);
+        if constexpr (LIVE1) acc[q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q >> 2][q & 3].y, bf[q % (PF + 1)][1].y, acc[q][1], 0, 0, 0);
+      });
+    };
+    if (tile1_live) positions(std::true_type{}); else positions(std::false_type{});
     if (!(p.ablate & 2)) __syncthreads();
   }
 
