@@ -357,6 +357,7 @@ __device__ __forceinline__ void wgrad_wino_body(const WgradDev& p, const int spl
 #pragma unroll
   for (int q = 0; q < 16; ++q) { acc[q][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[q][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
   float bsum[2] = {0.f, 0.f};
+  const bool a1_live = (n0 + 32 * wr + 16) < p.N;       // wave-uniform
 
   const int t_begin = split * p.tiles_per_split;
   const int t_end = min(t_begin + p.tiles_per_split, p.ntiles);
@@ -439,6 +440,7 @@ __device__ __forceinline__ void wgrad_wino_body(const WgradDev& p, const int spl
       // ---- W = A dY A^T for (output channel n = 32*wr + 16*a + li, tile t), a = 0, 1 ---------------
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
+        if (a == 1 && !a1_live) continue;     // row tile entirely beyond N (N = 48 in the 64-row block): no transform, no MFMAs
         const float* dp = d_lds + (ty2 * 16 + tx2) * SD + 32 * wr + 16 * a + li;
         const float y00 = dp[0], y01 = dp[SD], y10 = dp[16 * SD], y11 = dp[17 * SD];
         bsum[a] += (y00 + y01) + (y10 + y11);
