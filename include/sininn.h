@@ -134,8 +134,12 @@ typedef struct sininn_conv_args {
   int out_bf16;                                    /* `out` holds bf16 (RELU / LINEAR / MASK modes; an fp32-input conv must
                                                       set it); else fp32 through the mode's regular epilogue              */
   int mask_bf16;                                   /* MASK mode: `mask` holds bf16                                        */
-  int in_group_stride;                             /* experimental, Winograd kernels: > 0 = the input is channel-group-major
-                                                      [Cin/8][B*H*W][8] with this many floats between groups (in_stride == 8) */
+  /* channel-group-major tensors [C/8][B*H*W][8] (Winograd kernels; the hidden tensors h / dh of a 3x3 GLOW block, which only
+   * the block executor's kernels touch): every halo row of an 8-channel chunk is then one contiguous run.  A value > 0 is the
+   * number of floats between channel groups (= B*H*W*8) and selects the layout for that operand: */
+  int in_group_stride;                             /* `in` (then in_stride must be 8)                                     */
+  int out_group_stride;                            /* `out` (RELU / MASK modes, N == Np, N % 64 == 0)                      */
+  int mask_group_stride;                           /* `mask` (MASK mode)                                                  */
 } sininn_conv_args;
 
 int sininn_conv(const sininn_conv_args* args, void* stream);
@@ -160,6 +164,8 @@ typedef struct sininn_wgrad_item {
   float* gw; float* gb;                            /* OIHW weight gradient (+=), bias gradient (+=, may be NULL)    */
   int in_bf16, dout_bf16;                          /* mixed-precision path: the operand is stored as bf16 (pointer cast,
                                                       stride in elements); the gradient accumulates in fp32          */
+  int in_group_stride, dout_group_stride;          /* > 0: the operand is channel-group-major [C/8][B*H*W][8] (fp32, 3x3
+                                                      Winograd kernels); value = floats between channel groups         */
 } sininn_wgrad_item;
 size_t sininn_wgrad_group_workspace_bytes(const sininn_wgrad_item* items, int n, int B, int H, int W, int ksize);
 int sininn_wgrad_group(const sininn_wgrad_item* items, int n, int B, int H, int W, int ksize,

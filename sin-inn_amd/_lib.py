@@ -34,6 +34,7 @@ class ConvArgs(C.Structure):
         ('addend', c_f), ('addend_stride', C.c_int), ('addend_map', c_i),
         ('stamp', C.c_void_p),
         ('w_bf16', C.c_int), ('in_bf16', C.c_int), ('out_bf16', C.c_int), ('mask_bf16', C.c_int), ('in_group_stride', C.c_int),
+        ('out_group_stride', C.c_int), ('mask_group_stride', C.c_int),
     ]
 
 
@@ -56,7 +57,8 @@ class GlowArgs(C.Structure):
 class WgradItem(C.Structure):
     """Mirror of sininn_wgrad_item."""
     _fields_ = [('inp', c_f), ('in_stride', C.c_int), ('Cin', C.c_int), ('dout', c_f), ('dout_stride', C.c_int),
-                ('N', C.c_int), ('gw', c_f), ('gb', c_f), ('in_bf16', C.c_int), ('dout_bf16', C.c_int)]
+                ('N', C.c_int), ('gw', c_f), ('gb', c_f), ('in_bf16', C.c_int), ('dout_bf16', C.c_int),
+                ('in_group_stride', C.c_int), ('dout_group_stride', C.c_int)]
 
 
 class PackDesc(C.Structure):

@@ -386,7 +386,7 @@ int conv_bf16_launch(const sininn_conv_args* a, hipStream_t st) {
   d.sbuf = a->sbuf; d.logdet = a->logdet; d.Co = a->Co; d.clamp = a->clamp;
   d.mask = nullptr; d.mask_stride = a->mask_stride;
   d.addend = a->addend; d.addend_stride = a->addend_stride; d.addend_map = a->addend_map;
-  d.mode = a->mode; d.col_tile = couple ? a->col_tile : 16; d.stamp = a->stamp; d.ablate = 0; d.CK = 0; d.in_chunk = 8;
+  d.mode = a->mode; d.col_tile = couple ? a->col_tile : 16; d.stamp = a->stamp; d.ablate = 0; d.CK = 0; d.in_chunk = 8; d.out_gs = 0; d.mask_gs = 0;
   const int th = a->ksize == 3 ? 16 : 8;
   d.tiles_x = (a->W + 15) / 16; d.tiles_y = (a->H + th - 1) / th;
   q.in = a->in; q.w = reinterpret_cast<const __bf16*>(a->w);

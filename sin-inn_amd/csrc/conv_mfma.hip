@@ -37,9 +37,9 @@ int conv_launch(const sininn_conv_args* a, hipStream_t st) {
     SININN_CHECK(a->clamp > 0.f, "conv: clamp must be > 0");
     SININN_CHECK(a->out_stride >= a->Co, "conv: out_stride < Co");
   } else {
-    SININN_CHECK(a->N > 0 && a->N <= a->Np && a->out_stride >= a->N, "conv: bad N=%d (Np=%d, out_stride=%d)", a->N, a->Np, a->out_stride);
+    SININN_CHECK(a->N > 0 && a->N <= a->Np && (a->out_stride >= a->N || a->out_group_stride > 0), "conv: bad N=%d (Np=%d, out_stride=%d)", a->N, a->Np, a->out_stride);
     if (a->mode == SININN_CONV_RELU) SININN_CHECK(a->bias != nullptr, "conv: RELU mode needs bias");
-    if (a->mode == SININN_CONV_MASK) SININN_CHECK(a->mask != nullptr && a->mask_stride >= a->N, "conv: MASK mode needs mask");
+    if (a->mode == SININN_CONV_MASK) SININN_CHECK(a->mask != nullptr && (a->mask_stride >= a->N || a->mask_group_stride > 0), "conv: MASK mode needs mask");
     const bool cbwd = a->mode == SININN_CONV_ADD_CBWD_FWD || a->mode == SININN_CONV_ADD_CBWD_INV;
     if (a->mode == SININN_CONV_ADD || cbwd) SININN_CHECK(a->addend != nullptr, "conv: ADD mode needs addend");
     if (cbwd) SININN_CHECK(a->v && a->sbuf && a->out2 && a->Co == a->N && a->out_stride >= 2 * a->Co && a->clamp > 0.f, "conv: ADD_CBWD needs v, sbuf, out2, Co == N, out_stride >= 2*Co");
@@ -72,6 +72,14 @@ int conv_launch(const sininn_conv_args* a, hipStream_t st) {
   d.stamp = a->stamp;
   d.ablate = g_ablate;
   d.in_chunk = a->in_group_stride > 0 ? a->in_group_stride : 8;
+  d.out_gs = a->out_group_stride > 0 ? (size_t)a->out_group_stride : 0;
+  d.mask_gs = a->mask_group_stride > 0 ? (size_t)a->mask_group_stride : 0;
+  if (d.out_gs || d.mask_gs) {
+    // group-major hidden tensors go through the epilogue's full-quad fast path only
+    SININN_CHECK(a->winograd && (a->mode == SININN_CONV_RELU || a->mode == SININN_CONV_MASK) && a->N % 64 == 0 && a->N == a->Np,
+                 "conv: channel-group-major out / mask needs a Winograd RELU / MASK conv with N == Np, N %% 64 == 0");
+    SININN_CHECK(!d.mask_gs || a->mode == SININN_CONV_MASK, "conv: mask_group_stride without MASK mode");
+  }
   if (a->in_group_stride > 0) SININN_CHECK(a->winograd && a->in_stride == 8, "conv: the channel-group-major input layout needs the Winograd kernels and in_stride == 8");
   SININN_CHECK(a->mode >= 0 && a->mode <= SININN_CONV_ADD_CBWD_INV, "conv: unknown mode %d", a->mode);
   // channel chunk: the largest of 32/24/16/8 that divides Cin

@@ -34,6 +34,8 @@ struct ConvDev {
   int mode;
   int col_tile;   // coupling (s|t) interleave width of the packed weights (16 or 32)
   unsigned long long* stamp;   // optional {start, end} wall-clock words (sininn_conv_args.stamp)
+  size_t out_gs, mask_gs;   // > 0: `out` / `mask` are channel-group-major [N/8][pixel][8] with this many floats between groups
+                            // (RELU / MASK modes of the Winograd kernels: the hidden tensors h / dh of a 3x3 GLOW block)
   int in_chunk;   // floats between consecutive 8-channel groups of one input pixel: 8 for pixel-major tensors; B*H*W*8 for
                   // the channel-group-major layout [C/8][pixel][8] (then in_stride == 8) -- Winograd kernels only
   int ablate;   // diagnostic only (tools/bench_kernels.py --ablate): 1 skip staging, 2 skip loop barrier, 4 skip LDS reads
@@ -191,8 +193,10 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvDev& p, const float
           const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
           if (!(pl < NPIX && gy < p.H && gx < p.W)) return z;
           const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
-          return (MODE == SININN_CONV_MASK) ? *reinterpret_cast<const f32x4*>(p.mask + pix * p.mask_stride + colq)
-                                            : *reinterpret_cast<const f32x4*>(p.addend + pix * p.addend_stride + colq);
+          if (MODE == SININN_CONV_MASK)
+            return p.mask_gs ? *reinterpret_cast<const f32x4*>(p.mask + (size_t)(colq >> 3) * p.mask_gs + pix * 8 + (colq & 7))
+                             : *reinterpret_cast<const f32x4*>(p.mask + pix * p.mask_stride + colq);
+          return *reinterpret_cast<const f32x4*>(p.addend + pix * p.addend_stride + colq);
         };
         f32x4 side_next = side(0);
 #pragma unroll
@@ -221,7 +225,8 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvDev& p, const float
               val += bq;
               val += sd;
             }
-            *reinterpret_cast<f32x4*>(p.out + pix * p.out_stride + colq) = val;
+            if (p.out_gs) *reinterpret_cast<f32x4*>(p.out + (size_t)(colq >> 3) * p.out_gs + pix * 8 + (colq & 7)) = val;
+            else *reinterpret_cast<f32x4*>(p.out + pix * p.out_stride + colq) = val;
           }
         }
         return;

@@ -3,6 +3,7 @@
 // costs one ctypes call per block pass instead of one per kernel (the training step is ~450 launches; issued from
 // Python they made the host the bottleneck).  Weight-gradient kernels go to a second stream (they depend on dr / dh
 // only) so they overlap the data-gradient chain.
+#include <stdlib.h>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -151,6 +152,15 @@ struct ClassScope {           // RAII bracket: records the start event now and t
 };
 static inline double conv_flops(size_t M, int k, int cin, int n) { return 2.0 * (double)M * k * k * cin * n; }
 
+static const bool g_group_major = getenv("SININN_GROUP_MAJOR") == nullptr || atoi(getenv("SININN_GROUP_MAJOR")) != 0;   // A/B switch
+
+// h / dh of this subnet are channel-group-major: fp32, 3x3, every conv of the subnet on the Winograd kernels, and the
+// tensor small enough for the int group stride
+static bool group_major_hidden(const sininn_glow_args* a, const sininn_subnet* net) {
+  const size_t M = (size_t)a->B * a->H * a->W;
+  return g_group_major && a->dtype == 0 && a->ksize == 3 && (net->winograd & 15) == 15 && M * 8 < (1u << 30) && wgrad_grouping_enabled();
+}
+
 struct Half {                 // one half-coupling in execution order
   const sininn_subnet* net;
   int cond_off;               // offset of the conditioning channels in x (-1: the first half's compact output)
@@ -262,6 +272,10 @@ int glow_forward(const sininn_glow_args* a, hipStream_t st) {
     c1.B = a->B; c1.H = a->H; c1.W = a->W; c1.ksize = a->ksize; c1.mode = SININN_CONV_RELU;
     c1.out = hbuf; c1.out_stride = SININN_HIDDEN; c1.N = SININN_HIDDEN;
     if (bf16) { c1.winograd = 0; c1.w_bf16 = 1; c1.in_bf16 = 0; c1.out_bf16 = 1; }     // cond fp32 -> h bf16
+    // fp32 3x3 blocks on the Winograd kernels keep h / dh channel-group-major [256/8][M][8]: the halo rows of an 8-channel
+    // chunk are then contiguous runs for the K = 256 convs that read them (dominant kernel -10 %)
+    const bool gm = group_major_hidden(a, h.net);
+    if (gm) c1.out_group_stride = (int)(M * 8);
     {
       ClassScope sc(PC_CONV1, a->ksize, conv_flops(M, a->ksize, c1.Cin, SININN_HIDDEN), st);
       if (int rc = conv_launch(&c1, st)) return rc;
@@ -277,6 +291,7 @@ int glow_forward(const sininn_glow_args* a, hipStream_t st) {
     c2.out2 = (i == 0) ? sv.ybuf : nullptr; c2.out2_stride = h.co;
     c2.sbuf = sbuf; c2.logdet = a->logdet; c2.Co = h.co; c2.clamp = a->clamp; c2.col_tile = col_tile_of(h.co);
     if (bf16) { c2.winograd = 0; c2.w_bf16 = 1; c2.in_bf16 = 1; }                       // h bf16 -> fp32 coupling epilogue
+    if (gm) { c2.in_stride = 8; c2.in_group_stride = (int)(M * 8); }
     hipEvent_t e0, e1;
     unsigned long long* stamp = nullptr;
     const bool timed = g_prof_h != 0 && a->ksize == 3 && a->H == g_prof_h && prof_pair(&e0, &e1, &stamp);
@@ -317,10 +332,10 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
   sininn_wgrad_item items[4];
   int n_items = 0;
   auto add_item = [&](const float* in, int in_stride, int cin, const float* dout, int dout_stride, int n, float* gw, float* gb,
-                      int in_b, int dout_b) {
+                      int in_b, int dout_b, int in_gs, int dout_gs) {
     sininn_wgrad_item& it = items[n_items++];
     it.in = in; it.in_stride = in_stride; it.Cin = cin; it.dout = dout; it.dout_stride = dout_stride; it.N = n; it.gw = gw; it.gb = gb;
-    it.in_bf16 = in_b; it.dout_bf16 = dout_b;
+    it.in_bf16 = in_b; it.dout_bf16 = dout_b; it.in_group_stride = in_gs; it.dout_group_stride = dout_gs;
   };
 
   // fuse: when set, the dgrad of this half's first conv also performs the coupling-tail backward of the OTHER
@@ -337,8 +352,10 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
       if (int rc = coupling_bwd_launch(dy, dy_stride, dy_map, vy, vy_stride, vy_map, sbuf, a->gld, B, HW, h.co, a->clamp, inv,
                                        dr, a->dx + h.base, C, st)) return rc;
     }
+    const bool gm = group_major_hidden(a, net);
+    const int gs = gm ? (int)(M * 8) : 0;
     if (net->gw2) {
-      if (grouped) add_item(hbuf, SININN_HIDDEN, SININN_HIDDEN, dr, 2 * h.co, 2 * h.co, net->gw2, net->gb2, bf16 ? 1 : 0, 0);
+      if (grouped) add_item(hbuf, SININN_HIDDEN, SININN_HIDDEN, dr, 2 * h.co, 2 * h.co, net->gw2, net->gb2, bf16 ? 1 : 0, 0, gs, 0);
       else {
         if (int rc = order_after(wst, st)) return rc;
         ClassScope scp(PC_WGRAD, k, conv_flops(M, k, SININN_HIDDEN, 2 * h.co), wst);
@@ -352,12 +369,13 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
     d2.B = B; d2.H = H; d2.W = W; d2.ksize = k; d2.mode = SININN_CONV_MASK;
     d2.out = dh; d2.out_stride = SININN_HIDDEN; d2.N = SININN_HIDDEN; d2.mask = hbuf; d2.mask_stride = SININN_HIDDEN;
     if (bf16) { d2.winograd = 0; d2.w_bf16 = 1; d2.in_bf16 = 0; d2.out_bf16 = 1; d2.mask_bf16 = 1; }   // dr fp32 -> dh bf16
+    if (gm) { d2.out_group_stride = gs; d2.mask_group_stride = gs; }
     {
       ClassScope scp(PC_DGRAD2, k, conv_flops(M, k, 2 * h.co, SININN_HIDDEN), st);
       if (int rc = conv_launch(&d2, st)) return rc;
     }
     if (net->gw1) {
-      if (grouped) add_item(cond, cond_stride, cond_cin, dh, SININN_HIDDEN, SININN_HIDDEN, net->gw1, net->gb1, 0, bf16 ? 1 : 0);
+      if (grouped) add_item(cond, cond_stride, cond_cin, dh, SININN_HIDDEN, SININN_HIDDEN, net->gw1, net->gb1, 0, bf16 ? 1 : 0, 0, gs);
       else {
         if (int rc = order_after(wst, st)) return rc;
         ClassScope scp(PC_WGRAD, k, conv_flops(M, k, cond_cin, SININN_HIDDEN), wst);
@@ -378,6 +396,7 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
     d1.in = dh; d1.in_stride = SININN_HIDDEN; d1.Cin = SININN_HIDDEN; d1.w = net->w1_dgrad;
     d1.winograd = (net->winograd & 4) && k == 3;
     if (bf16) { d1.winograd = 0; d1.w_bf16 = 1; d1.in_bf16 = 1; }                                       // dh bf16 -> fp32 epilogue
+    if (gm) { d1.in_stride = 8; d1.in_group_stride = gs; }
     d1.Np = d1.winograd ? (cond_cin + 31) / 32 * 32 : pad16i(cond_cin);
     d1.B = B; d1.H = H; d1.W = W; d1.ksize = k; d1.mode = SININN_CONV_ADD;
     d1.out = dcond; d1.out_stride = dcond_stride; d1.N = cond_cin;

@@ -21,6 +21,7 @@ struct WgradDev {
   float* partial;   // [S][taps][Nr][Cc]
   float* bpartial;  // [S][Nr]
   int Nr, Cc;
+  size_t in_gs, dout_gs;    // > 0: channel-group-major fp32 operand [C/8][pixel][8], floats between groups (Winograd kernels)
   int in_bf16, dout_bf16;   // mixed-precision path: the operand lives in HBM as bf16 (strides in elements); converted to
                             // fp32 while it is staged, the gradient itself accumulates on the f32 matrix pipe
 };
@@ -377,7 +378,11 @@ __device__ __forceinline__ void wgrad_wino_body(const WgradDev& p, const int spl
       const int n = n0 + n4 * 4;
       f32x4 val = {0.f, 0.f, 0.f, 0.f};
       if (pix < NPIX && gy < p.H && gx < p.W && n < p.N)
-        val = wg_load4(p.dout, ((size_t)(b * p.H + gy) * p.W + gx) * p.dout_stride + n, p.dout_bf16);
+        {
+          const size_t pixi = (size_t)(b * p.H + gy) * p.W + gx;
+          val = p.dout_gs ? *reinterpret_cast<const f32x4*>(p.dout + (size_t)(n >> 3) * p.dout_gs + pixi * 8 + (n & 7))
+                          : wg_load4(p.dout, pixi * p.dout_stride + n, p.dout_bf16);
+        }
       d_reg[r] = val;
     }
 #pragma unroll
@@ -389,7 +394,11 @@ __device__ __forceinline__ void wgrad_wino_body(const WgradDev& p, const int spl
       const int c = c0 + c4 * 4;
       f32x4 val = {0.f, 0.f, 0.f, 0.f};
       if (pix < NPIX_IN && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && c < p.Cin)
-        val = wg_load4(p.in, ((size_t)(b * p.H + gy) * p.W + gx) * p.in_stride + c, p.in_bf16);
+        {
+          const size_t pixi = (size_t)(b * p.H + gy) * p.W + gx;
+          val = p.in_gs ? *reinterpret_cast<const f32x4*>(p.in + (size_t)(c >> 3) * p.in_gs + pixi * 8 + (c & 7))
+                        : wg_load4(p.in, pixi * p.in_stride + c, p.in_bf16);
+        }
       i_reg[r] = val;
     }
   };
@@ -761,7 +770,7 @@ int wgrad_launch(const float* in, int in_stride, int Cin, const float* dout, int
   d.in = in; d.in_stride = in_stride; d.Cin = Cin; d.dout = dout; d.dout_stride = dout_stride; d.N = N;
   d.B = B; d.H = H; d.W = W; d.tiles_x = pl.tiles_x; d.tiles_y = pl.tiles_y; d.ntiles = pl.ntiles;
   d.tiles_per_split = pl.tiles_per_split; d.Nr = pl.Nr; d.Cc = pl.Cc;
-  d.in_bf16 = 0; d.dout_bf16 = 0;
+  d.in_bf16 = 0; d.dout_bf16 = 0; d.in_gs = 0; d.dout_gs = 0;
   const int taps = ksize * ksize;
   d.partial = static_cast<float*>(ws);
   d.bpartial = d.partial + (size_t)pl.S * taps * pl.Nr * pl.Cc;
@@ -1019,6 +1028,8 @@ static int plan_group(const sininn_wgrad_item* items, int n, int B, int H, int W
     d.B = B; d.H = H; d.W = W; d.tiles_x = tiles_x; d.tiles_y = tiles_y; d.ntiles = ntiles; d.tiles_per_split = tps;
     d.Nr = q.nblk * bnw; d.Cc = q.cblk * bcw;
     d.in_bf16 = it.in_bf16; d.dout_bf16 = it.dout_bf16;
+    d.in_gs = it.in_group_stride > 0 ? (size_t)it.in_group_stride : 0;
+    d.dout_gs = it.dout_group_stride > 0 ? (size_t)it.dout_group_stride : 0;
     d.partial = ws ? ws + off : nullptr; off += (size_t)S * taps * d.Nr * d.Cc;
     d.bpartial = ws ? ws + off : nullptr; off += ((size_t)S * d.Nr + 3) / 4 * 4;
     q.gw = it.gw; q.gb = it.gb;
@@ -1046,8 +1057,10 @@ int wgrad_group_launch(const sininn_wgrad_item* items, int n, int B, int H, int 
   for (int i = 0; i < n; ++i) {
     const sininn_wgrad_item& it = items[i];
     SININN_CHECK(it.in && it.dout && it.gw, "wgrad_group: null pointer in problem %d", i);
-    SININN_CHECK(it.in_stride >= it.Cin && it.in_stride % 4 == 0 && aligned16(it.in), "wgrad_group: in must be 16-byte aligned, stride %% 4 == 0");
-    SININN_CHECK(it.dout_stride >= it.N && it.dout_stride % 4 == 0 && aligned16(it.dout), "wgrad_group: dout must be 16-byte aligned, stride %% 4 == 0");
+    SININN_CHECK((it.in_stride >= it.Cin || it.in_group_stride > 0) && it.in_stride % 4 == 0 && aligned16(it.in), "wgrad_group: in must be 16-byte aligned, stride %% 4 == 0");
+    SININN_CHECK((it.dout_stride >= it.N || it.dout_group_stride > 0) && it.dout_stride % 4 == 0 && aligned16(it.dout), "wgrad_group: dout must be 16-byte aligned, stride %% 4 == 0");
+    SININN_CHECK((it.in_group_stride <= 0 && it.dout_group_stride <= 0) || (pl.wino && !it.in_bf16 && !it.dout_bf16),
+                 "wgrad_group: channel-group-major operands need the fp32 3x3 Winograd kernel");
     SININN_CHECK((it.in_bf16 == 0 || it.in_bf16 == 1) && (it.dout_bf16 == 0 || it.dout_bf16 == 1), "wgrad_group: dtype flags must be 0 / 1");
   }
   if (pl.mfma_bf16) {
