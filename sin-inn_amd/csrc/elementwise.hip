@@ -613,6 +613,86 @@ __global__ void flow_warp_l1_bwd_kernel(const float* __restrict__ img, const flo
   }
 }
 
+// Image-gradient form of the backward: block = 32 x 8 output pixels of one image.  The four taps of an output pixel lie
+// within a few pixels of it for the trainer's flows, so their contributions are accumulated in an LDS window (tile + 8 pixels
+// all round, per channel) with ds_add_f32 and the window is flushed once with row-contiguous global atomics; only taps
+// further away go to HBM atomics directly (plain per-tap global atomics made this kernel 17x slower than its flow-only
+// form: 1.3 ms at 16x3x512x512).
+constexpr int FB_TX = 32, FB_TY = 8, FB_R = 8, FB_WX = FB_TX + 2 * FB_R, FB_WY = FB_TY + 2 * FB_R;
+__global__ __launch_bounds__(FB_TX * FB_TY) void flow_warp_l1_bwd_tiled_kernel(
+    const float* __restrict__ img, const float* __restrict__ flow, const float* __restrict__ target,
+    const float* __restrict__ warped, const float* __restrict__ gwarped, const float* __restrict__ gmetric, int B, int C, int H,
+    int W, float* __restrict__ gimg, float* __restrict__ gflow) {
+  constexpr int CC = 4;                                                  // channels per window pass
+  __shared__ float win[CC][FB_WY][FB_WX];
+  const int tiles_x = (W + FB_TX - 1) / FB_TX, tiles_y = (H + FB_TY - 1) / FB_TY;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int bx0 = tx * FB_TX, by0 = ty * FB_TY;
+  const int x = bx0 + threadIdx.x % FB_TX, y = by0 + threadIdx.x / FB_TX;
+  const int64_t HW = (int64_t)H * W;
+  const bool live = x < W && y < H;
+  const int64_t r = live ? (int64_t)y * W + x : 0;
+  float fx = 0.f, fy = 0.f;
+  if (live) { fx = flow[(b * 2 + 0) * HW + r]; fy = flow[(b * 2 + 1) * HW + r]; }
+  const float gxn = (x + fx) / (float)(W - 1) * 2.f - 1.f, gyn = (y + fy) / (float)(H - 1) * 2.f - 1.f;
+  const float ix = ((gxn + 1.f) * W - 1.f) * 0.5f, iy = ((gyn + 1.f) * H - 1.f) * 0.5f;
+  const bool finite = live && fabsf(ix) < 1e9f && fabsf(iy) < 1e9f;      // also false for NaN
+  const float flx = finite ? floorf(ix) : 0.f, fly = finite ? floorf(iy) : 0.f;
+  const int x0 = (int)flx, y0 = (int)fly;
+  const float wx1 = ix - flx, wy1 = iy - fly, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+  const float gm = (live && gmetric) ? gmetric[(int64_t)b * HW + r] / (float)C : 0.f;
+  const int wx = x0 - (bx0 - FB_R), wy = y0 - (by0 - FB_R);             // window coordinates of the north-west tap
+  float gix = 0.f, giy = 0.f;
+  for (int c0 = 0; c0 < C; c0 += CC) {
+    const int cc = min(CC, C - c0);
+    for (int e = threadIdx.x; e < cc * FB_WY * FB_WX; e += FB_TX * FB_TY) (&win[0][0][0])[e] = 0.f;
+    __syncthreads();
+    if (finite) {
+      for (int c = 0; c < cc; ++c) {
+        const int64_t o = ((int64_t)b * C + c0 + c) * HW;
+        float g = gwarped ? gwarped[o + r] : 0.f;
+        if (gmetric) {
+          const float d = target[o + r] - warped[o + r];
+          g += (d > 0.f) ? -gm : ((d < 0.f) ? gm : 0.f);
+        }
+        const float* base = img + o;
+        auto tap = [&](int yy, int xx) -> float {
+          return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? base[(int64_t)yy * W + xx] : 0.f;
+        };
+        const float t00 = tap(y0, x0), t01 = tap(y0, x0 + 1), t10 = tap(y0 + 1, x0), t11 = tap(y0 + 1, x0 + 1);
+        gix += g * ((t01 - t00) * wy0 + (t11 - t10) * wy1);
+        giy += g * ((t10 - t00) * wx0 + (t11 - t01) * wx1);
+        auto put = [&](int dy, int dx, float wgt) {
+          const int yy = y0 + dy, xx = x0 + dx;
+          if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            const int qy = wy + dy, qx = wx + dx;
+            if (qy >= 0 && qy < FB_WY && qx >= 0 && qx < FB_WX) atomicAdd(&win[c][qy][qx], g * wgt);
+            else atomicAdd(gimg + o + (int64_t)yy * W + xx, g * wgt);
+          }
+        };
+        put(0, 0, wy0 * wx0); put(0, 1, wy0 * wx1); put(1, 0, wy1 * wx0); put(1, 1, wy1 * wx1);
+      }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < cc * FB_WY * FB_WX; e += FB_TX * FB_TY) {
+      const float v = (&win[0][0][0])[e];
+      if (v != 0.f) {
+        const int c = e / (FB_WY * FB_WX), q = e % (FB_WY * FB_WX);
+        const int gy = by0 - FB_R + q / FB_WX, gx = bx0 - FB_R + q % FB_WX;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) atomicAdd(gimg + ((int64_t)b * C + c0 + c) * HW + (int64_t)gy * W + gx, v);
+      }
+    }
+    __syncthreads();
+  }
+  if (live && gflow) {
+    gflow[(b * 2 + 0) * HW + r] = gix * (float)W / (float)(W - 1);
+    gflow[(b * 2 + 1) * HW + r] = giy * (float)H / (float)(H - 1);
+  }
+}
+
 int flow_warp_l1_bwd_launch(const float* img, const float* flow, const float* target, const float* warped,
                             const float* gwarped, const float* gmetric, int B, int C, int H, int W, float* gimg,
                             float* gflow, hipStream_t st) {
@@ -620,8 +700,14 @@ int flow_warp_l1_bwd_launch(const float* img, const float* flow, const float* ta
   SININN_CHECK(!gmetric || (target && warped), "flow_warp_l1_bwd: metric gradient needs target and warped");
   SININN_CHECK(B > 0 && C > 0 && C <= FW_MAXC && H > 1 && W > 1, "flow_warp_l1_bwd: bad shape");
   const int64_t total = (int64_t)B * H * W;
-  hipLaunchKernelGGL(flow_warp_l1_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, img, flow,
-                     target, warped, gwarped, gmetric, B, C, H, W, gimg, gflow);
+  if (gimg) {
+    const int tiles = B * ((H + FB_TY - 1) / FB_TY) * ((W + FB_TX - 1) / FB_TX);
+    hipLaunchKernelGGL(flow_warp_l1_bwd_tiled_kernel, dim3((unsigned)tiles), dim3(FB_TX * FB_TY), 0, st, img, flow, target, warped,
+                       gwarped, gmetric, B, C, H, W, gimg, gflow);
+  } else {
+    hipLaunchKernelGGL(flow_warp_l1_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, img, flow,
+                       target, warped, gwarped, gmetric, B, C, H, W, gimg, gflow);
+  }
   SININN_LAUNCH_CHECK("flow_warp_l1_bwd");
   return 0;
 }

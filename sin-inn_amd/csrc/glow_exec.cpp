@@ -28,23 +28,26 @@ int coupling_bwd_launch(const float* dy, int dy_stride, const int* dy_map, const
 static inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }   // floats -> keeps 256-byte alignment
 static inline int pad16i(int n) { return (n + 15) / 16 * 16; }
 
-// ---- cross-stream ordering: a small ring of timing-less events ------------------------------------
+// ---- cross-stream ordering: a small ring of timing-less events PER DEVICE (events belong to the device that was current
+// when they were created; one process per GPU is the deployment, but the library must not break with two devices) -----------
 static std::mutex g_ev_mutex;
-static hipEvent_t g_events[64];
-static bool g_events_ready = false;
-static unsigned g_ev_next = 0;
+struct EventRing { hipEvent_t ev[64]; bool ready = false; unsigned next = 0; };
+static EventRing g_rings[16];
 
 static int order_after(hipStream_t waiter, hipStream_t producer) {
   if (waiter == producer) return 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { set_error("glow: bad current device"); return 1; }
   hipEvent_t ev;
   {
     std::lock_guard<std::mutex> lock(g_ev_mutex);
-    if (!g_events_ready) {
-      for (auto& e : g_events)
+    EventRing& ring = g_rings[dev];
+    if (!ring.ready) {
+      for (auto& e : ring.ev)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { set_error("glow: cannot create events"); return 1; }
-      g_events_ready = true;
+      ring.ready = true;
     }
-    ev = g_events[g_ev_next++ % 64];
+    ev = ring.ev[ring.next++ % 64];
   }
   if (hipEventRecord(ev, producer) != hipSuccess || hipStreamWaitEvent(waiter, ev, 0) != hipSuccess) {
     set_error("glow: stream ordering failed");

@@ -65,6 +65,25 @@ def main():
     for order in (1, 2):
         rows.append((f'bilateral smooth fwd (order {order})', timeit(lambda: lib.sininn_bilateral_smooth(ptr(img), ptr(flow), b, 3, h, w, order, 1, 150.0, 0.1, ptr(acc), ptr(o), st()), a.reps), px * 4 * 5))
         rows.append((f'bilateral smooth bwd (order {order})', timeit(lambda: lib.sininn_bilateral_smooth_bwd(ptr(img), ptr(flow), b, 3, h, w, order, 1, 150.0, 0.1, None, ptr(gf), st()), a.reps), px * 4 * 7))
+    # flow warp + photometric L1 (Resample2d + trainer.py:61-62; north_star's second fused kernel) at config-3 size, batch 16
+    fb = max(b, 16)
+    fpx = fb * h * w
+    fimg = torch.rand(fb, 3, h, w, device=dev); ftgt = torch.rand(fb, 3, h, w, device=dev)
+    fflow = torch.randn(fb, 2, h, w, device=dev) * 2
+    fwarp = torch.empty_like(fimg); fmet = torch.empty(fb, 1, h, w, device=dev)
+    rows.append((f'flow_warp_l1 fwd (batch {fb}: warp + metric)',
+                 timeit(lambda: lib.sininn_flow_warp_l1(ptr(fimg), ptr(fflow), ptr(ftgt), fb, 3, h, w, ptr(fwarp), ptr(fmet), st()), a.reps),
+                 fpx * 4 * (3 + 2 + 3 + 3 + 1)))
+    gwp = torch.randn_like(fimg); gmt = torch.rand_like(fmet); gim = torch.zeros_like(fimg); gfl = torch.empty_like(fflow)
+
+    def fw_bwd():
+        gim.zero_()
+        lib.sininn_flow_warp_l1_bwd(ptr(fimg), ptr(fflow), ptr(ftgt), ptr(fwarp), ptr(gwp), ptr(gmt), fb, 3, h, w, ptr(gim), ptr(gfl), st())
+    rows.append((f'flow_warp_l1 bwd (batch {fb}: d img + d flow, incl. zero fill)', timeit(fw_bwd, a.reps),
+                 fpx * 4 * (3 + 2 + 3 + 3 + 3 + 1 + 3 + 3 + 2)))
+    rows.append((f'flow_warp_l1 bwd (batch {fb}: d flow only)',
+                 timeit(lambda: lib.sininn_flow_warp_l1_bwd(ptr(fimg), ptr(fflow), ptr(ftgt), ptr(fwarp), ptr(gwp), ptr(gmt), fb, 3, h, w, None, ptr(gfl), st()), a.reps),
+                 fpx * 4 * (3 + 2 + 3 + 3 + 3 + 1 + 2)))
     for name, ms, nbytes in rows:
         print(f'{name:42s} {ms * 1e3:9.1f} us  {nbytes / ms / 1e6:8.1f} GB/s algorithmic = {nbytes / ms / 1e6 / 8000 * 100:5.1f} % of the HBM roof')
 
