@@ -166,6 +166,8 @@ typedef struct sininn_wgrad_item {
                                                       stride in elements); the gradient accumulates in fp32          */
   int in_group_stride, dout_group_stride;          /* > 0: the operand is channel-group-major [C/8][B*H*W][8] (fp32, 3x3
                                                       Winograd kernels); value = floats between channel groups         */
+  int gap_begin, gap_len;                          /* gap_len > 0: input channels [gap_begin, gap_begin + gap_len) are padding
+                                                      that the weight does not have (gw rows hold Cin - gap_len channels)  */
 } sininn_wgrad_item;
 size_t sininn_wgrad_group_workspace_bytes(const sininn_wgrad_item* items, int n, int B, int H, int W, int ksize);
 int sininn_wgrad_group(const sininn_wgrad_item* items, int n, int B, int H, int W, int ksize,
@@ -198,6 +200,37 @@ int sininn_lrelu_bwd(float* g, int g_stride, const float* f, int f_stride, int64
 int sininn_irn_coupling_bwd(const float* dy, int dy_stride, const float* vy, int vy_stride, const float* hval,
                             int64_t M, int Co, float clamp, int inverse, float* dG, float* dh, float* dv,
                             int dv_stride, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * One DenseBlock of the IRN architecture per call (archs.py:74-133, with the InvBlockExp tail of archs.py:135-160 as the
+ * epilogue of its fifth conv): host-side launch sequence, like sininn_glow_forward / _backward for the SRF path.  The five
+ * dense-connected 3x3 convs write their 32-channel outputs into slots of ONE feature buffer buf [M][cinp + 128]
+ * (cinp = cin rounded up to 8; the torch.cat chain costs nothing); weights are packed for that padded channel order.
+ *   mode 0: out = conv5(...)                       1: out = aux1 + conv5(...)          (y1 = x1 + F(x2))
+ *   mode 2: out = aux1 * exp(s) + conv5(...)       3: out = (aux1 - conv5(...)) / exp(s),   s = clamp * (2 sigmoid(aux2) - 1)
+ * backward: dF [M][cinp + 128] (on return its first cin channels are d loss / d x), dv / dh (modes 2, 3: gradients w.r.t.
+ * aux1 and aux2; mode 1: the gradient w.r.t. aux1 is dout itself), OIHW weight / bias gradients (+=) of the UNPADDED convs.
+ * The five weight gradients run as one grouped launch pair on wgrad_stream.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sininn_dense_args {
+  int B, H, W, cin, cout, mode, winograd;
+  float clamp;
+  const float* x; int x_stride;
+  const float* aux1; int aux1_stride;
+  const float* aux2;                               /* [M][cout] */
+  float* buf; float* out;                          /* [M][cinp + 128], [M][cout] */
+  const float* w_fwd[5]; const float* b_fwd[5]; const float* w_dgrad[5];
+  /* backward only */
+  const float* dout;                               /* [M][cout] */
+  float* dF;                                       /* [M][cinp + 128] */
+  float* dD;                                       /* [M][cout rounded up to 8] scratch (modes 2, 3 and cout % 8 != 0)   */
+  float* dh; float* dv;                            /* modes 2, 3: [M][cout] each                                          */
+  float* gw[5]; float* gb[5];
+  void* workspace; size_t workspace_bytes;         /* sininn_dense_workspace_bytes                                        */
+} sininn_dense_args;
+size_t sininn_dense_workspace_bytes(int B, int H, int W, int cin, int cout);
+int sininn_dense_forward(const sininn_dense_args* args, void* stream);
+int sininn_dense_backward(const sininn_dense_args* args, void* stream, void* wgrad_stream);
 
 /* ------------------------------------------------------------------------------------------------
  * One GLOW coupling block per call (FrEIA GLOWCouplingBlock.forward / its autograd, SURVEY Appendix A;

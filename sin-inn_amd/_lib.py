@@ -58,7 +58,19 @@ class WgradItem(C.Structure):
     """Mirror of sininn_wgrad_item."""
     _fields_ = [('inp', c_f), ('in_stride', C.c_int), ('Cin', C.c_int), ('dout', c_f), ('dout_stride', C.c_int),
                 ('N', C.c_int), ('gw', c_f), ('gb', c_f), ('in_bf16', C.c_int), ('dout_bf16', C.c_int),
-                ('in_group_stride', C.c_int), ('dout_group_stride', C.c_int)]
+                ('in_group_stride', C.c_int), ('dout_group_stride', C.c_int), ('gap_begin', C.c_int), ('gap_len', C.c_int)]
+
+
+class DenseArgs(C.Structure):
+    """Mirror of sininn_dense_args."""
+    _fields_ = [('B', C.c_int), ('H', C.c_int), ('W', C.c_int), ('cin', C.c_int), ('cout', C.c_int), ('mode', C.c_int),
+                ('winograd', C.c_int), ('clamp', C.c_float),
+                ('x', c_f), ('x_stride', C.c_int), ('aux1', c_f), ('aux1_stride', C.c_int), ('aux2', c_f),
+                ('buf', c_f), ('out', c_f),
+                ('w_fwd', c_f * 5), ('b_fwd', c_f * 5), ('w_dgrad', c_f * 5),
+                ('dout', c_f), ('dF', c_f), ('dD', c_f), ('dh', c_f), ('dv', c_f),
+                ('gw', c_f * 5), ('gb', c_f * 5),
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
 
 
 class PackDesc(C.Structure):
@@ -113,6 +125,9 @@ _SIGS = {
     'sininn_glow_scratch_bytes': (C.c_size_t, [C.c_int] * 5),
     'sininn_glow_forward': (C.c_int, [C.POINTER(GlowArgs), C.c_void_p]),
     'sininn_glow_backward': (C.c_int, [C.POINTER(GlowArgs), C.c_void_p, C.c_void_p]),
+    'sininn_dense_workspace_bytes': (C.c_size_t, [C.c_int] * 5),
+    'sininn_dense_forward': (C.c_int, [C.POINTER(DenseArgs), C.c_void_p]),
+    'sininn_dense_backward': (C.c_int, [C.POINTER(DenseArgs), C.c_void_p, C.c_void_p]),
     'sininn_haar': (C.c_int, [c_f, I64x4, c_f, I64x4, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'sininn_lrelu_bwd': (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
     'sininn_irn_coupling_bwd': (C.c_int, [c_f, C.c_int, c_f, C.c_int, c_f, C.c_int64, C.c_int, C.c_float, C.c_int,

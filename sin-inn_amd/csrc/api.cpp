@@ -61,14 +61,17 @@ int haar_launch(const float* in, const int64_t is[4], float* out, const int64_t 
                 int inverse, hipStream_t st);
 int lrelu_bwd_launch(float* g, int g_stride, const float* f, int f_stride, int64_t M, int n, float slope, hipStream_t st);
 int irn_coupling_bwd_launch(const float* dy, int dy_stride, const float* vy, int vy_stride, const float* hval, int64_t M,
-                            int Co, float clamp, int inverse, float* dG, float* dh, float* dv, int dv_stride,
-                            hipStream_t st);
+                            int Co, float clamp, int inverse, float* dG, int dG_stride, int dG_pad, float* dh, float* dv,
+                            int dv_stride, hipStream_t st);
 int squeeze_rows_launch(const float* in, float* out, int B, int C, int H, int W, int levels, int inverse, const int* map,
                         hipStream_t st);
 int pack_bf16_launch(const float* w, const float* bias, int N, int Cin, int ksize, const int* colmap, int Np, void* wb_fwd,
                      float* b_fwd, int Cdp, void* wb_dgrad, hipStream_t st);
 int frames_to_u8_launch(const float* in, const int64_t is[4], uint8_t* out, int B, int C, int H, int W, int wrap,
                         hipStream_t st);
+size_t dense_workspace_bytes(int B, int H, int W, int cin, int cout);
+int dense_forward(const sininn_dense_args* a, hipStream_t st);
+int dense_backward(const sininn_dense_args* a, hipStream_t st, hipStream_t wst);
 void profile_classes_begin();
 int profile_classes_end(int n, double* ms, double* flops, int* launches);
 void profile_begin(int h, unsigned long long* stamps, int max_launches);
@@ -233,7 +236,7 @@ int sininn_lrelu_bwd(float* g, int g_stride, const float* f, int f_stride, int64
 int sininn_irn_coupling_bwd(const float* dy, int dy_stride, const float* vy, int vy_stride, const float* hval, int64_t M,
                             int Co, float clamp, int inverse, float* dG, float* dh, float* dv, int dv_stride,
                             void* stream) {
-  return irn_coupling_bwd_launch(dy, dy_stride, vy, vy_stride, hval, M, Co, clamp, inverse, dG, dh, dv, dv_stride,
+  return irn_coupling_bwd_launch(dy, dy_stride, vy, vy_stride, hval, M, Co, clamp, inverse, dG, Co, Co, dh, dv, dv_stride,
                                  ST(stream));
 }
 
@@ -320,6 +323,12 @@ int sininn_pack_conv_weights_bf16(const float* w_oihw, const float* bias, int N,
 
 void sininn_profile_classes_begin(void) { profile_classes_begin(); }
 int sininn_profile_classes_end(int n, double* ms, double* flops, int* launches) { return profile_classes_end(n, ms, flops, launches); }
+
+size_t sininn_dense_workspace_bytes(int B, int H, int W, int cin, int cout) { return dense_workspace_bytes(B, H, W, cin, cout); }
+int sininn_dense_forward(const sininn_dense_args* args, void* stream) { return dense_forward(args, ST(stream)); }
+int sininn_dense_backward(const sininn_dense_args* args, void* stream, void* wgrad_stream) {
+  return dense_backward(args, ST(stream), ST(wgrad_stream));
+}
 
 int sininn_frames_to_u8(const float* in, const int64_t in_strides[4], uint8_t* out, int B, int C, int H, int W, int wrap,
                         void* stream) {

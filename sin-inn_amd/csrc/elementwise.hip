@@ -872,8 +872,8 @@ int lrelu_bwd_launch(float* g, int g_stride, const float* f, int f_stride, int64
 
 __global__ void irn_coupling_bwd_kernel(const float* __restrict__ dy, int dy_stride, const float* __restrict__ vy,
                                         int vy_stride, const float* __restrict__ hval, int64_t total, int Co, float clamp,
-                                        int inverse, float* __restrict__ dG, float* __restrict__ dh,
-                                        float* __restrict__ dv, int dv_stride) {
+                                        int inverse, float* __restrict__ dG, int dG_stride, int dG_pad,
+                                        float* __restrict__ dh, float* __restrict__ dv, int dv_stride) {
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(idx % Co);
@@ -886,21 +886,25 @@ __global__ void irn_coupling_bwd_kernel(const float* __restrict__ dy, int dy_str
     float gG, gs, gv;
     if (!inverse) { gv = g * e; gG = g; gs = g * u * e; }      // y = v e + G
     else { gv = g / e; gG = -gv; gs = -g * u; }                // y = (v - G)/e ; d/ds = -y
-    dG[idx] = gG;
+    dG[m * dG_stride + c] = gG;
+    if (c == Co - 1)                                           // zero pad columns [Co, dG_pad) of the row
+      for (int j = Co; j < dG_pad; ++j) dG[m * dG_stride + j] = 0.f;
     dh[idx] = gs * ds_dh;
     dv[m * dv_stride + c] = gv;
   }
 }
 
 int irn_coupling_bwd_launch(const float* dy, int dy_stride, const float* vy, int vy_stride, const float* hval, int64_t M,
-                            int Co, float clamp, int inverse, float* dG, float* dh, float* dv, int dv_stride,
-                            hipStream_t st) {
+                            int Co, float clamp, int inverse, float* dG, int dG_stride, int dG_pad, float* dh, float* dv,
+                            int dv_stride, hipStream_t st) {
+  // dG rows have dG_stride floats; columns [Co, dG_pad) are written as zeros (K padding of the following conv)
   SININN_CHECK(dy && vy && hval && dG && dh && dv && M > 0 && Co > 0, "irn_coupling_bwd: bad arguments");
   SININN_CHECK(dy_stride >= Co && vy_stride >= Co && dv_stride >= Co, "irn_coupling_bwd: stride < Co");
+  SININN_CHECK(dG_pad >= Co && dG_stride >= dG_pad, "irn_coupling_bwd: dG_stride=%d dG_pad=%d Co=%d", dG_stride, dG_pad, Co);
   const int64_t total = M * Co;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(irn_coupling_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, dy_stride, vy, vy_stride, hval, total,
-                     Co, clamp, inverse, dG, dh, dv, dv_stride);
+                     Co, clamp, inverse, dG, dG_stride, dG_pad, dh, dv, dv_stride);
   SININN_LAUNCH_CHECK("irn_coupling_bwd");
   return 0;
 }

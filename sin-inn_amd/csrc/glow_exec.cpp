@@ -34,7 +34,7 @@ static std::mutex g_ev_mutex;
 struct EventRing { hipEvent_t ev[64]; bool ready = false; unsigned next = 0; };
 static EventRing g_rings[16];
 
-static int order_after(hipStream_t waiter, hipStream_t producer) {
+int order_after(hipStream_t waiter, hipStream_t producer) {
   if (waiter == producer) return 0;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { set_error("glow: bad current device"); return 1; }
@@ -332,11 +332,12 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
   const bool bf16 = a->dtype == 1;
   const bool grouped = bf16 || (wgrad_grouping_enabled() && k == 3);      // the bf16-operand loads exist in the grouped kernels
   const bool per_half = wgrad_group_mode() == 2;
-  sininn_wgrad_item items[4];
+  sininn_wgrad_item items[4] = {};
   int n_items = 0;
   auto add_item = [&](const float* in, int in_stride, int cin, const float* dout, int dout_stride, int n, float* gw, float* gb,
                       int in_b, int dout_b, int in_gs, int dout_gs) {
     sininn_wgrad_item& it = items[n_items++];
+    it = sininn_wgrad_item{};                  // optional fields (gap_*) default to 0
     it.in = in; it.in_stride = in_stride; it.Cin = cin; it.dout = dout; it.dout_stride = dout_stride; it.N = n; it.gw = gw; it.gb = gb;
     it.in_bf16 = in_b; it.dout_bf16 = dout_b; it.in_group_stride = in_gs; it.dout_group_stride = dout_gs;
   };

@@ -211,4 +211,27 @@ bool sample_windows_dense_try(const uint8_t* hr_clip, const uint8_t* lr_clip, co
   return true;
 }
 
+// out[m][c] = c < C ? in[m][c] : 0 for c < Cpad (C, Cpad multiples of 4): a channel slice into a padded buffer
+__global__ void copy_channels_kernel(const float* __restrict__ in, int in_stride, float* __restrict__ out, int out_stride,
+                                     int64_t M, int C4, int Cpad4) {
+  const int64_t total = M * Cpad4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % Cpad4);
+    const int64_t m = i / Cpad4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c4 < C4) v = *reinterpret_cast<const f32x4*>(in + m * in_stride + c4 * 4);
+    *reinterpret_cast<f32x4*>(out + m * out_stride + c4 * 4) = v;
+  }
+}
+
+int copy_channels_launch(const float* in, int in_stride, float* out, int out_stride, int64_t M, int C, int Cpad, hipStream_t st) {
+  SININN_CHECK(in && out && M > 0 && C > 0 && C % 4 == 0 && Cpad % 4 == 0 && Cpad >= C, "copy_channels: bad arguments");
+  SININN_CHECK(in_stride % 4 == 0 && out_stride % 4 == 0 && out_stride >= Cpad && aligned16(in) && aligned16(out), "copy_channels: alignment");
+  const int64_t total = M * (Cpad / 4);
+  const int64_t blocks = (total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192;
+  hipLaunchKernelGGL(copy_channels_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, in_stride, out, out_stride, M, C / 4, Cpad / 4);
+  SININN_LAUNCH_CHECK("copy_channels");
+  return 0;
+}
+
 }  // namespace sininn

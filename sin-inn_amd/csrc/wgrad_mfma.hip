@@ -615,6 +615,8 @@ constexpr int WG_MAXP = 8;
 struct WgradProb {
   WgradDev d;
   float* gw; float* gb;
+  int gap_begin, gap_len;  // operand channels [gap_begin, gap_begin + gap_len) are padding with no counterpart in the weight:
+                           // they are skipped and later channels shift down (IRN DenseBlock feature buffer, cin padded to 8)
   int S, nblk, cblk;
   int block_begin;       // first block of this problem in the grouped gradient grid
   int red_begin;         // first block of this problem in the grouped reduce grid
@@ -693,7 +695,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(WgradGroup g) {
     const int col2 = lb * RC + cl2;
     if (col2 < ncol) {
       const int n = col2 / c4n, c = (col2 - n * c4n) * 4 + j;
-      if (n < d.N && c < d.Cin) q.gw[((size_t)n * d.Cin + c) * TAPS + t2] += tile[e];
+      if (n < d.N && c < d.Cin && !(c >= q.gap_begin && c < q.gap_begin + q.gap_len)) {
+        const int cw = c < q.gap_begin ? c : c - q.gap_len;
+        q.gw[((size_t)n * (d.Cin - q.gap_len) + cw) * TAPS + t2] += tile[e];
+      }
     }
   }
 }
@@ -1033,6 +1038,7 @@ static int plan_group(const sininn_wgrad_item* items, int n, int B, int H, int W
     d.partial = ws ? ws + off : nullptr; off += (size_t)S * taps * d.Nr * d.Cc;
     d.bpartial = ws ? ws + off : nullptr; off += ((size_t)S * d.Nr + 3) / 4 * 4;
     q.gw = it.gw; q.gb = it.gb;
+    q.gap_begin = it.gap_len > 0 ? it.gap_begin : 0; q.gap_len = it.gap_len > 0 ? it.gap_len : 0;
     q.block_begin = gb; gb += S * q.nblk * q.cblk;
     q.red_begin = rb;
     const int ncol = d.Nr * (d.Cc / 4), rc = (taps == 9) ? RC3 : RC1;
@@ -1062,6 +1068,8 @@ int wgrad_group_launch(const sininn_wgrad_item* items, int n, int B, int H, int 
     SININN_CHECK((it.in_group_stride <= 0 && it.dout_group_stride <= 0) || (pl.wino && !it.in_bf16 && !it.dout_bf16),
                  "wgrad_group: channel-group-major operands need the fp32 3x3 Winograd kernel");
     SININN_CHECK((it.in_bf16 == 0 || it.in_bf16 == 1) && (it.dout_bf16 == 0 || it.dout_bf16 == 1), "wgrad_group: dtype flags must be 0 / 1");
+    SININN_CHECK(it.gap_len == 0 || (it.gap_len > 0 && it.gap_begin >= 0 && it.gap_begin + it.gap_len <= it.Cin),
+                 "wgrad_group: bad channel gap [%d, +%d) for Cin=%d in problem %d", it.gap_begin, it.gap_len, it.Cin, i);
   }
   if (pl.mfma_bf16) {
     if (ksize == 3) hipLaunchKernelGGL((wgrad_bf16_group_kernel<3>), dim3(pl.grad_blocks), dim3(256), 0, st, pl.g);

@@ -10,6 +10,8 @@ Execution is pixel-major (NHWC) like the SRF path and re-uses the same conv / wg
   * backward: hand-written chain (irn_coupling_bwd -> wgrad/dgrad of conv5 -> [lrelu_bwd, wgrad, dgrad-accumulate]
     for conv4..conv1) on the same kernels.
 """
+import ctypes
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -21,6 +23,7 @@ from .modules import USE_SIDE_STREAM, USE_WINOGRAD, WEIGHTS_EPOCH, _grad_buf, _s
 CONV_LRELU, CONV_IRN_FWD, CONV_IRN_INV = 6, 7, 8
 GC = 32
 SLOPE = 0.2
+DEBUG_SYNC = [False]      # diagnostic: device-synchronise after every DenseBlock backward
 
 
 def _vp(t, off=0, dtype=torch.float32):
@@ -118,8 +121,21 @@ class _DensePacks:
         return self.packs
 
 
+_MODES = {'linear': 0, 'add': 1, 'irn_fwd': 2, 'irn_inv': 3}
+
+
+def _dense_args(block, packs, b, h, w, mode, clamp):
+    a = _lib.DenseArgs(B=b, H=h, W=w, cin=block.channel_in, cout=block.channel_out, mode=_MODES[mode],
+                       winograd=int(USE_WINOGRAD[0]), clamp=float(clamp))
+    for i, (wf, bf, wd) in enumerate(packs):
+        a.w_fwd[i], a.b_fwd[i], a.w_dgrad[i] = wf.data_ptr(), bf.data_ptr(), wd.data_ptr()
+    return a
+
+
 class _DenseFn(torch.autograd.Function):
-    """out = tail(conv5(dense(x))) ; tail in {linear, add(aux1), irn_fwd(v=aux1, h=aux2), irn_inv(v=aux1, h=aux2)}."""
+    """out = tail(conv5(dense(x))) ; tail in {linear, add(aux1), irn_fwd(v=aux1, h=aux2), irn_inv(v=aux1, h=aux2)}.
+    One C-ABI call per pass (sininn_dense_forward / sininn_dense_backward: the launch sequence is issued from C++; the five
+    weight gradients of the block run as one grouped launch pair on the weight-gradient stream)."""
 
     @staticmethod
     def forward(ctx, x, aux1, aux2, block, mode, clamp, *params):
@@ -132,115 +148,72 @@ class _DenseFn(torch.autograd.Function):
         cinp, cout = block.cinp, block.channel_out
         bw = cinp + 4 * GC
         packs = block._packs.get(block)
-        # only the pad channels [cin, cinp) must be zero: x fills [0, cin), the four convs their 32-channel slots
         buf = torch.empty((m, bw), device=dev, dtype=torch.float32)
-        if cinp != cin:
-            buf[:, cin:cinp].zero_()
-        ar = block.arange(dev)
-        check(_lib.lib().sininn_permute_channels(_vp(xd), xs, _vp(buf), bw, m, cin, _vp(ar, dtype=torch.int32),
-                                                 ops._stream()))
-        for i in range(4):
-            k = cinp + GC * i
-            wf, bf, _ = packs[i]
-            ops.conv(in_=_vp(buf), in_stride=bw, Cin=k, w=_vp(wf), bias=_vp(bf), Np=GC, B=b, H=h, W=w, ksize=3,
-                     winograd=int(USE_WINOGRAD[0]), mode=CONV_LRELU, clamp=SLOPE, out=_vp(buf, k), out_stride=bw, N=GC)
-        wf, bf, _ = packs[4]
         out = torch.empty((b, h, w, cout), device=dev, dtype=torch.float32)
-        kw = dict(in_=_vp(buf), in_stride=bw, Cin=bw, w=_vp(wf), bias=_vp(bf), Np=ops.pad16(_pad8(cout)), B=b, H=h, W=w,
-                  ksize=3, winograd=int(USE_WINOGRAD[0]), out=_vp(out), out_stride=cout, N=cout)
+        a = _dense_args(block, packs, b, h, w, mode, clamp)
+        a.x, a.x_stride, a.buf, a.out = xd.data_ptr(), xs, buf.data_ptr(), out.data_ptr()
         a1 = a2 = None
-        if mode == 'linear':
-            kw.update(mode=CONV_LINEAR)
-        elif mode == 'add':
+        if mode != 'linear':
             a1, s1 = _pixel_view(aux1.detach())
-            kw.update(mode=CONV_ADD, addend=_vp(a1), addend_stride=s1)
-        else:
-            a1, s1 = _pixel_view(aux1.detach())
+            a.aux1, a.aux1_stride = a1.data_ptr(), s1
+        if mode in ('irn_fwd', 'irn_inv'):
             a2 = aux2.detach().contiguous()
-            kw.update(mode=CONV_IRN_FWD if mode == 'irn_fwd' else CONV_IRN_INV, v=_vp(a1), v_stride=s1,
-                      mask=_vp(a2), mask_stride=cout, clamp=clamp)
-        ops.conv(**kw)
+            a.aux2 = a2.data_ptr()
+        check(_lib.lib().sininn_dense_forward(a, ops._stream()))
         if any(ctx.needs_input_grad):
             ctx.block, ctx.mode, ctx.clamp, ctx.shape = block, mode, clamp, (b, h, w, cin)
-            ctx.save_for_backward(buf, out, a1 if a1 is not None else buf, a2 if a2 is not None else buf)
+            ctx.save_for_backward(buf, out, a1 if a1 is not None else buf, a2 if a2 is not None else buf, xd)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         block, mode, clamp = ctx.block, ctx.mode, ctx.clamp
-        buf, out, a1, a2 = ctx.saved_tensors
+        buf, out, a1, a2, xd = ctx.saved_tensors
         b, h, w, cin = ctx.shape
         m = b * h * w
         dev = buf.device
         cinp, cout = block.cinp, block.channel_out
-        bw = cinp + 4 * GC
+        bw, coutp = cinp + 4 * GC, _pad8(cout)
         packs = block._packs.get(block)
         convs = block.convs()
         dout = dout.contiguous()
-        coutp = _pad8(cout)
-        g_aux1 = g_aux2 = None
         lib = _lib.lib()
-
-        def padded(t):                       # [m][cout] -> [m][coutp] with zero pad columns (K of the conv5 dgrad)
-            if coutp == cout:
-                return t
-            tp = torch.zeros((m, coutp), device=dev, dtype=torch.float32)
-            check(lib.sininn_permute_channels(_vp(t), cout, _vp(tp), coutp, m, cout,
-                                              _vp(block.arange_out(dev), dtype=torch.int32), ops._stream()))
-            return tp
-
-        if mode == 'linear':
-            dD = padded(dout)
-        elif mode == 'add':
-            dD, g_aux1 = padded(dout), dout
-        else:
-            inv = 1 if mode == 'irn_inv' else 0
-            dG = torch.empty((m, cout), device=dev, dtype=torch.float32)
+        irn = mode in ('irn_fwd', 'irn_inv')
+        a = _dense_args(block, packs, b, h, w, mode, clamp)
+        a.x, a.x_stride = xd.data_ptr(), xd.stride(2)
+        a.buf, a.out, a.dout = buf.data_ptr(), out.data_ptr(), dout.data_ptr()
+        dF = torch.empty((m, bw), device=dev, dtype=torch.float32)        # fully written by conv5's data gradient
+        a.dF = dF.data_ptr()
+        dD = dh = dv = None
+        if irn or coutp != cout:
+            dD = torch.empty((m, coutp), device=dev, dtype=torch.float32)
+            a.dD = dD.data_ptr()
+        if mode != 'linear':
+            a.aux1, a.aux1_stride = a1.data_ptr(), a1.stride(2)
+        if irn:
             dh = torch.empty((m, cout), device=dev, dtype=torch.float32)
             dv = torch.empty((b, h, w, cout), device=dev, dtype=torch.float32)
-            vy, vs = (out, cout) if inv else _pixel_view(a1)
-            check(lib.sininn_irn_coupling_bwd(_vp(dout), cout, _vp(vy), vs, _vp(a2), m, cout, clamp, inv, _vp(dG),
-                                              _vp(dh), _vp(dv), cout, ops._stream()))
-            dD = padded(dG)
-            g_aux1, g_aux2 = dv, dh.view(b, h, w, cout)
-        dF = torch.empty((m, bw), device=dev, dtype=torch.float32)      # fully written by conv5's data gradient below
-
-        # weight gradients go to the dedicated side stream (like the GLOW executor's): they only read `buf` and a slice of
-        # the gradient buffer that is final by then, so they overlap the data-gradient chain, and every `+=` into a
-        # parameter gradient is issued on that ONE stream (two pass chains may then run concurrently)
+            a.aux2, a.dh, a.dv = a2.data_ptr(), dh.data_ptr(), dv.data_ptr()
+        for i, cv in enumerate(convs):
+            if cv.weight.requires_grad:
+                a.gw[i], a.gb[i] = _grad_buf(cv.weight).data_ptr(), _grad_buf(cv.bias).data_ptr()
+        nbytes = lib.sininn_dense_workspace_bytes(b, h, w, block.channel_in, cout)
+        ws = torch.empty((nbytes + 3) // 4, device=dev, dtype=torch.float32)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+        # weight gradients go to the dedicated side stream (like the GLOW executor's): every `+=` into a parameter gradient
+        # is issued on that ONE stream, so two pass chains may run concurrently
         main = torch.cuda.current_stream()
         side = _side_stream(dev) if USE_SIDE_STREAM[0] else main
-
-        def wgrad(i, k, dout_t, dout_off, dout_stride, n):
-            cv = convs[i]
-            if not cv.weight.requires_grad:
-                return
-            if side is not main:
-                side.wait_stream(main)
-            with torch.cuda.stream(side):
-                if cinp == cin:
-                    ops.wgrad(buf, 0, bw, k, dout_t, dout_stride, n, b, h, w, 3, _grad_buf(cv.weight), _grad_buf(cv.bias),
-                              dout_off=dout_off)
-                else:   # gradient w.r.t. the channel-padded weight, then drop the pad channels
-                    gwp = torch.zeros((n, k, 3, 3), device=dev, dtype=torch.float32)
-                    ops.wgrad(buf, 0, bw, k, dout_t, dout_stride, n, b, h, w, 3, gwp, _grad_buf(cv.bias), dout_off=dout_off)
-                    gw = _grad_buf(cv.weight)
-                    gw[:, :cin] += gwp[:, :cin]
-                    if i:
-                        gw[:, cin:] += gwp[:, cinp:]
-            if side is not main:
-                for t in (buf, dout_t):
+        check(lib.sininn_dense_backward(a, ctypes.c_void_p(main.cuda_stream), ctypes.c_void_p(side.cuda_stream)))
+        if DEBUG_SYNC[0]:
+            torch.cuda.synchronize()
+        if side is not main:
+            for t in (buf, dF, dD, ws, dout):
+                if t is not None:
                     t.record_stream(side)
-
-        # conv5: weight gradient, then dF[:, :bw] = its data gradient
-        wgrad(4, bw, dD, 0, coutp, cout)
-        _dgrad(dD, 0, coutp, coutp, packs[4][2], bw, dF, bw, b, h, w, accumulate=False)
-        for i in (3, 2, 1, 0):
-            k = cinp + GC * i
-            check(lib.sininn_lrelu_bwd(_vp(dF, k), bw, _vp(buf, k), bw, m, GC, SLOPE, ops._stream()))
-            wgrad(i, k, dF, k, bw, GC)
-            _dgrad(dF, k, bw, GC, packs[i][2], k, dF, bw, b, h, w, accumulate=True)
         dx = dF.view(b, h, w, bw)[..., :cin]
+        g_aux1 = dout if mode == 'add' else (dv if irn else None)
+        g_aux2 = dh.view(b, h, w, cout) if irn else None
         return (dx, g_aux1, g_aux2, None, None, None) + (None,) * 10
 
 

@@ -5,6 +5,8 @@ import types
 import pytest
 import torch
 
+import sin_inn_amd.modules
+
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4
 T = torch.from_numpy
@@ -59,6 +61,7 @@ def test_invblockexp_golden_and_gradients(golden, rev):
     xg = xin.cuda().requires_grad_(True); xc = xin.clone().requires_grad_(True)
     wgt = torch.randn(2, 8, 8, 8)
     (blk(xg, rev=rev) * wgt.cuda()).sum().backward(); (ref(xc, rev=rev) * wgt).sum().backward()
+    sin_inn_amd.modules.join_side_streams()                # weight gradients run on the side stream
     assert relerr(xg.grad, xc.grad) < RTOL
     for (n, pg), (_, pc) in zip(blk.named_parameters(), ref.named_parameters()):
         assert relerr(pg.grad, pc.grad) < 3e-4, n
@@ -87,6 +90,7 @@ def test_full_irn_matches_reference_fixture_and_oracle_gradients(golden):
     xg = x.cuda().requires_grad_(True); xc = x.clone().requires_grad_(True)
     wgt = torch.randn(2, 192, 8, 8)
     (net(xg) * wgt.cuda()).sum().backward(); (ref(xc) * wgt).sum().backward()
+    sin_inn_amd.modules.join_side_streams()
     assert relerr(xg.grad, xc.grad) < RTOL
     named = dict(net.named_parameters())
     for (n, pc) in ref.named_parameters():

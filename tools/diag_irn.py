@@ -1,0 +1,37 @@
+"""Diagnostic: IRN input / parameter gradients against the oracle, per block and for the full net."""
+import sys, os, types, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import archs
+import sin_inn_amd
+from sin_inn_amd import modules as M, irn as I
+from oracle import sininn_oracle as O
+def relerr(a, b): return float((a.detach().cpu() - b.detach().cpu()).abs().max() / b.detach().abs().max().clamp_min(1e-30))
+opt = types.SimpleNamespace(scale=4, num_coupling=int(os.environ.get('NC', 4)), lr_dims=12)
+torch.manual_seed(5)
+net = archs.InvRescaleNet(3, 64, 64, opt)
+g5 = torch.Generator().manual_seed(55)
+for m in net.modules():
+    if isinstance(m, archs.DenseBlock):
+        m.conv5.weight.data = torch.randn(m.conv5.weight.shape, generator=g5) * 0.02
+ref = O.IRNOracle(3, 12, scale=4, num_coupling=opt.num_coupling)
+O.load_reference_irn_state(ref, {k: v.detach().clone() for k, v in net.state_dict().items()})
+net.cuda()
+x = torch.rand(2, 3, 64, 64)
+wgt = torch.randn(2, 192, 8, 8)
+xc = x.clone().requires_grad_(True)
+(ref(xc) * wgt).sum().backward()
+for name, side, sync in [('default', True, False), ('no side stream', False, False), ('sync each', True, True), ('default again', True, False)]:
+    M.USE_SIDE_STREAM[0] = side
+    I.DEBUG_SYNC[0] = sync
+    for p in net.parameters(): p.grad = None
+    xg = x.cuda().requires_grad_(True)
+    (net(xg) * wgt.cuda()).sum().backward()
+    M.join_side_streams(); torch.cuda.synchronize()
+    named = dict(net.named_parameters())
+    worst = (0, '')
+    for (n, pc) in ref.named_parameters():
+        parts = n.split('.')
+        op_ids = sorted({int(k.split('.')[1]) for k in named if '.conv' in k})
+        key = f'operations.{op_ids[int(parts[1])]}.{parts[2]}.conv{int(parts[4]) + 1}.{parts[5]}'
+        worst = max(worst, (relerr(named[key].grad, pc.grad), key))
+    print(name, 'dx', relerr(xg.grad, xc.grad), 'param', worst, flush=True)
