@@ -88,7 +88,10 @@ def cpu_baseline(args, opt, seconds_budget=30.0):
     from oracle import sininn_oracle as O
     torch.manual_seed(0)
     b = args.cpu_batch
-    ref = O.SRFlowOracle(3, args.height, args.width, scale=4, num_coupling=args.num_coupling)
+    if getattr(args, 'arch', 'SRF') == 'IRN':
+        ref = O.IRNOracle(3, opt.lr_dims, scale=4, num_coupling=args.num_coupling)
+    else:
+        ref = O.SRFlowOracle(3, args.height, args.width, scale=4, num_coupling=args.num_coupling)
     o = torch.optim.Adam(ref.parameters(), lr=1e-4, betas=(0.9, 0.99), weight_decay=1e-5)
     hr = torch.rand(b, 3, args.height, args.width)
     lr = torch.rand(b, opt.lr_dims, args.height // 8, args.width // 8)
@@ -108,7 +111,7 @@ def cpu_baseline(args, opt, seconds_budget=30.0):
     return {'value': b / dt, 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'sample': f'{n} timed + 1 warm-up training steps of the torch-CPU oracle (fp32), batch {b} (frames/s = batch / step '
                       f'time, i.e. per-frame normalised from batch {b}, not the benchmark batch), '
-                      f'{args.width}x{args.height}, -c {args.num_coupling}'}
+                      f'{args.width}x{args.height}, -c {args.num_coupling}, {getattr(args, "arch", "SRF")}'}
 
 
 def self_launch(n):
@@ -170,7 +173,13 @@ CLASS_NAMES = ['conv1 forward (+ReLU)', 'conv2 forward + coupling + log-det', 'd
                'coupling backward tail (HBM-bound, no FLOPs counted)']
 
 
-def class_roofline(precision):
+IRN_CLASS_NAMES = ['DenseBlock conv1-4 forward (+LeakyReLU, 32 output channels each)', 'DenseBlock conv5 forward (+ fused add / affine tail)',
+                   'data gradient of conv5', 'data gradients of conv1-4 (accumulating into the feature-gradient buffer)',
+                   'the five weight gradients of a DenseBlock (one grouped launch + ordered slab reduce)',
+                   'elementwise: LeakyReLU backward, affine-tail backward, channel copies (HBM-bound, no FLOPs counted)']
+
+
+def class_roofline(precision, arch='SRF'):
     """roofline.classes from the executor's per-launch HIP-event brackets (single-stream steps): algorithmic TF/s per kernel
     class, its fraction of the dtype's dense MFMA peak, and -- for the Winograd classes of the fp32 path -- the fraction of
     the f32 matrix pipe the EXECUTED FLOPs occupy (Winograd F(2x2,3x3) executes 2.25x fewer than it is credited with)."""
@@ -187,7 +196,7 @@ def class_roofline(precision):
         cls = i % 6
         wgrad_fp32 = cls == 4                              # weight gradients accumulate on the f32 pipe in both precisions
         peak = PEAK_F32_MFMA_TFLOPS if (precision == 'fp32' or wgrad_fp32) else PEAK_BF16_MFMA_TFLOPS
-        rec = {'class': f'{k}x{k} {CLASS_NAMES[cls]}', 'launches': cnt[i], 'ms': ms[i]}
+        rec = {'class': f'{k}x{k} {(IRN_CLASS_NAMES if arch == "IRN" else CLASS_NAMES)[cls]}', 'launches': cnt[i], 'ms': ms[i]}
         if fl[i] > 0:
             tf = fl[i] / (ms[i] * 1e-3) / 1e12
             rec.update(alg_tflops=tf, peak_tflops=peak, frac=tf / peak, bound='mfma')
@@ -214,6 +223,8 @@ def main():
     ap.add_argument('--width', type=int, default=None)
     ap.add_argument('--num-coupling', type=int, default=None, help='GLOW blocks per level (2 levels): 4 -> 8-block INN')
     ap.add_argument('--precision', choices=['fp32', 'bf16'], default=None)
+    ap.add_argument('--arch', choices=['SRF', 'IRN'], default='SRF', help='SRF = the GLOW-block INN of the headline; IRN = the '
+                    'reference\'s second architecture (-a IRN: Haar + DenseBlock couplings, archs.py:135-233), fp32 only')
     ap.add_argument('--lr-window', type=int, default=10)
     ap.add_argument('--frames', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -263,6 +274,11 @@ def main():
         _m.USE_SIDE_STREAM[0] = False
     opt = make_opt(args.num_coupling, args.lr_window)
     opt.precision = args.precision
+    opt.architecture = args.arch
+    irn = args.arch == 'IRN'
+    if irn:
+        assert args.precision == 'fp32', 'the IRN path is fp32 only'
+        custom = True
     torch.manual_seed(0)                                   # identical random-init weights on every rank
     model = lit_wrapper.SingleVideoINN(3, args.height, args.width, opt).to(dev)
     if args.no_overlap or args.overlap == 'none':
@@ -332,7 +348,7 @@ def main():
         torch.cuda.synchronize()
         iso_ms = (time.perf_counter() - t1) / n_iso * 1e3
         iso.stop()
-        classes = class_roofline(args.precision)
+        classes = class_roofline(args.precision, args.arch)
         for c in classes:
             c['ms_per_step'] = c.pop('ms') / n_iso
             c['launches_per_step'] = c.pop('launches') // n_iso
@@ -391,17 +407,34 @@ def main():
                 fwd += 2.0 * mm * kk * (cc // 2 * 256 + 256 * cc) * 2
         roof['step'] = {'alg_tflop_per_step': 6 * fwd / 1e12, 'alg_tflops': 6 * fwd / (ms_per_step * 1e-3) / 1e12,
                         'frac_of_peak': 6 * fwd / (ms_per_step * 1e-3) / 1e12 / peak}
+    if irn:
+        # dominant kernel class of the IRN step = the one with the largest single-stream time; same accounting as above
+        # (algorithmic direct-convolution FLOPs / HIP-event bracket on the launch stream, f32 matrix-pipe peak)
+        dom = max((c for c in classes if c.get('alg_tflops')), key=lambda c: c['ms_per_step'])
+        fwd = 0.0
+        for mm, ch in ((m0, 48), (m0 // 4, 192)):
+            s1 = min(opt.lr_dims, ch // 2)
+            for cin, cout in ((ch - s1, s1), (s1, ch - s1), (s1, ch - s1)):          # F, G, H (archs.py:135-160)
+                fwd += args.num_coupling * 2.0 * mm * 9 * (32 * (4 * cin + 192) + (cin + 128) * cout)
+        roof = {'bound': 'mfma', 'achieved': dom['alg_tflops'], 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': dom['frac'], 'executed_mfma_frac': dom.get('executed_mfma_frac'), 'traffic': None,
+                'kernel': 'IRN: ' + dom['class'] + ' -- average over all its launches of a step (both levels)',
+                'avg_ms': dom['ms_per_step'] / max(dom['launches_per_step'], 1),
+                'avg_ms_source': 'HIP events on the launch stream, single-stream steps run right after the timed region',
+                'classes': classes, 'single_stream_ms_per_step': iso_ms,
+                'step': {'alg_tflop_per_step': 6 * fwd / 1e12, 'alg_tflops': 6 * fwd / (ms_per_step * 1e-3) / 1e12,
+                         'frac_of_peak': 6 * fwd / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}}
     out = {'metric': 'training frames/sec at 256x256 bs=16', 'value': value, 'unit': 'frames/s', 'n_gpus': ws,
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if bf16 else 'f32', 'data': 'synthetic',
-           'config': {'workload': (preset['name'] if not custom else f'custom: {args.height}x{args.width}x3, -c {args.num_coupling}, {args.precision}')
+           'config': {'workload': (preset['name'] if not custom else f'custom: {args.arch} {args.height}x{args.width}x3, -c {args.num_coupling}, {args.precision}')
                                   + f', synthetic clip ({args.frames} frames, lr_window {args.lr_window}), batch {b}/GPU, '
                                     'full training step (fwd+bwd, rev+bwd, Adam)',
                       'baseline_config': args.config, 'height': args.height, 'width': args.width,
-                      'global_batch': ws * b, 'num_coupling': args.num_coupling, 'parallelism': f'dp{ws}'},
+                      'global_batch': ws * b, 'num_coupling': args.num_coupling, 'architecture': args.arch, 'parallelism': f'dp{ws}'},
            'roofline': roof}
     if args.config != 1 or custom:
-        out['metric'] = f'training frames/sec at {args.width}x{args.height} bs={b}'
+        out['metric'] = f'training frames/sec at {args.width}x{args.height} bs={b}' + (' (IRN architecture)' if irn else '')
     if not args.no_cpu_baseline and ws == 1:
         out['cpu_baseline'] = cpu_baseline(args, opt)
     else:

@@ -18,6 +18,18 @@ int wgrad_group_launch(const sininn_wgrad_item* items, int n, int B, int H, int 
                        hipStream_t st);
 int copy_channels_launch(const float* in, int in_stride, float* out, int out_stride, int64_t M, int C, int Cpad, hipStream_t st);
 
+// per-class launch brackets of bench.py's roofline.classes (glow_exec.cpp); IRN uses the class slots as
+//   0 conv1-4 forward (+LeakyReLU)   1 conv5 forward (+ fused tail)   2 data gradient of conv5   3 data gradients of conv1-4
+//   4 the five weight gradients (one grouped launch pair)             5 elementwise (HBM-bound, no FLOPs counted)
+hipEvent_t class_scope_open(int cls, int ksize, double flops, hipStream_t st);
+void class_scope_close(hipEvent_t end, hipStream_t st);
+struct Scope {
+  hipStream_t st; hipEvent_t b;
+  Scope(int cls, double flops, hipStream_t s) : st(s), b(class_scope_open(cls, 3, flops, s)) {}
+  ~Scope() { class_scope_close(b, st); }
+};
+static inline double cflops(int64_t M, int cin, int n) { return 2.0 * (double)M * 9 * cin * n; }
+
 static constexpr int GC = 32;
 static constexpr float SLOPE = 0.2f;
 static inline int pad8(int n) { return (n + 7) / 8 * 8; }
@@ -62,9 +74,13 @@ int dense_forward(const sininn_dense_args* a, hipStream_t st) {
   const int64_t M = (int64_t)a->B * a->H * a->W;
   const int cin = a->cin, cinp = pad8(cin), bw = cinp + 4 * GC, cout = a->cout;
   // x -> buf[:, :cin], pad channels [cin, cinp) zeroed
-  if (int rc = copy_channels_launch(a->x, a->x_stride, a->buf, bw, M, cin, cinp, st)) return rc;
+  {
+    Scope sc(5, 0.0, st);
+    if (int rc = copy_channels_launch(a->x, a->x_stride, a->buf, bw, M, cin, cinp, st)) return rc;
+  }
   for (int i = 0; i < 4; ++i) {
     const int k = cinp + GC * i;
+    Scope sc(0, cflops(M, cin + GC * i, GC), st);
     sininn_conv_args c = {};
     c.in = a->buf; c.in_stride = bw; c.Cin = k; c.w = a->w_fwd[i]; c.bias = a->b_fwd[i]; c.Np = GC; c.winograd = a->winograd;
     c.B = a->B; c.H = a->H; c.W = a->W; c.ksize = 3; c.mode = SININN_CONV_LRELU; c.clamp = SLOPE;
@@ -80,6 +96,7 @@ int dense_forward(const sininn_dense_args* a, hipStream_t st) {
     c.mode = a->mode == 2 ? SININN_CONV_IRN_FWD : SININN_CONV_IRN_INV;
     c.v = a->aux1; c.v_stride = a->aux1_stride; c.mask = a->aux2; c.mask_stride = cout; c.clamp = a->clamp;
   }
+  Scope sc(1, cflops(M, cin + 4 * GC, cout), st);
   return conv_launch(&c, st);
 }
 
@@ -102,10 +119,12 @@ int dense_backward(const sininn_dense_args* a, hipStream_t st, hipStream_t wst) 
     const float* vy = inv ? a->out : a->aux1;
     const int vs = inv ? cout : a->aux1_stride;
     // dG goes straight into dD with zero pad columns: the data-gradient conv of conv5 has K = coutp
+    Scope sc(5, 0.0, st);
     if (int rc = irn_coupling_bwd_launch(a->dout, cout, vy, vs, a->aux2, M, cout, a->clamp, inv, a->dD, coutp, coutp, a->dh,
                                          a->dv, cout, st)) return rc;
     dD = a->dD; dD_stride = coutp;
   } else if (coutp != cout) {
+    Scope sc(5, 0.0, st);
     if (int rc = copy_channels_launch(a->dout, cout, a->dD, coutp, M, cout, coutp, st)) return rc;
     dD = a->dD; dD_stride = coutp;
   }
@@ -118,10 +137,17 @@ int dense_backward(const sininn_dense_args* a, hipStream_t st, hipStream_t wst) 
     else c.mode = SININN_CONV_LINEAR;
     return conv_launch(&c, st);
   };
-  if (int rc = dgrad(dD, dD_stride, coutp, a->w_dgrad[4], bw, false)) return rc;
+  {
+    Scope sc(2, cflops(M, cout, cin + 4 * GC), st);
+    if (int rc = dgrad(dD, dD_stride, coutp, a->w_dgrad[4], bw, false)) return rc;
+  }
   for (int i = 3; i >= 0; --i) {
     const int k = cinp + GC * i;
-    if (int rc = lrelu_bwd_launch(a->dF + k, bw, a->buf + k, bw, M, GC, SLOPE, st)) return rc;
+    {
+      Scope sc(5, 0.0, st);
+      if (int rc = lrelu_bwd_launch(a->dF + k, bw, a->buf + k, bw, M, GC, SLOPE, st)) return rc;
+    }
+    Scope sc(3, cflops(M, GC, cin + GC * i), st);
     if (int rc = dgrad(a->dF + k, bw, GC, a->w_dgrad[i], k, true)) return rc;
   }
   // ---- the five weight gradients: every dF slot is final now -> one grouped launch pair on the weight-gradient stream ----
@@ -136,6 +162,10 @@ int dense_backward(const sininn_dense_args* a, hipStream_t st, hipStream_t wst) 
     if (it[i].gw) live[n++] = it[i];
   if (n > 0) {
     if (int rc = order_after(wst, st)) return rc;
+    double fl = 0.0;
+    for (int i = 0; i < 5; ++i)
+      if (it[i].gw) fl += cflops(M, cin + GC * i, i < 4 ? GC : cout);
+    Scope sc(4, fl, wst);
     if (int rc = wgrad_group_launch(live, n, a->B, a->H, a->W, 3, a->workspace, a->workspace_bytes, wst)) return rc;
   }
   return 0;

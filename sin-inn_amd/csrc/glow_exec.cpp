@@ -138,20 +138,24 @@ int profile_classes_end(int n, double* ms, double* flops, int* launches) {
   return 0;
 }
 
+// start bracket of one launch (nullptr when class profiling is off); class_scope_close records the end event
+hipEvent_t class_scope_open(int cls, int ksize, double flops, hipStream_t st) {
+  if (!g_pc_on) return nullptr;
+  std::lock_guard<std::mutex> lock(g_ev_mutex);
+  if (g_pc_recs.size() >= 60000) return nullptr;
+  std::pair<hipEvent_t, hipEvent_t> p;
+  if (!g_pc_pool.empty()) { p = g_pc_pool.back(); g_pc_pool.pop_back(); }
+  else if (hipEventCreate(&p.first) != hipSuccess || hipEventCreate(&p.second) != hipSuccess) return nullptr;
+  g_pc_recs.push_back(ClassRec{p.first, p.second, cls + (ksize == 1 ? PC_PER_K : 0), flops});
+  (void)hipEventRecord(p.first, st);
+  return p.second;
+}
+void class_scope_close(hipEvent_t end, hipStream_t st) { if (end) (void)hipEventRecord(end, st); }
+
 struct ClassScope {           // RAII bracket: records the start event now and the end event when it goes out of scope
-  hipStream_t st; hipEvent_t b; bool live;
-  ClassScope(int cls, int ksize, double flops, hipStream_t s) : st(s), b(nullptr), live(false) {
-    if (!g_pc_on) return;
-    std::lock_guard<std::mutex> lock(g_ev_mutex);
-    if (g_pc_recs.size() >= 60000) return;
-    std::pair<hipEvent_t, hipEvent_t> p;
-    if (!g_pc_pool.empty()) { p = g_pc_pool.back(); g_pc_pool.pop_back(); }
-    else if (hipEventCreate(&p.first) != hipSuccess || hipEventCreate(&p.second) != hipSuccess) return;
-    g_pc_recs.push_back(ClassRec{p.first, p.second, cls + (ksize == 1 ? PC_PER_K : 0), flops});
-    (void)hipEventRecord(p.first, st);
-    b = p.second; live = true;
-  }
-  ~ClassScope() { if (live) (void)hipEventRecord(b, st); }
+  hipStream_t st; hipEvent_t b;
+  ClassScope(int cls, int ksize, double flops, hipStream_t s) : st(s), b(class_scope_open(cls, ksize, flops, s)) {}
+  ~ClassScope() { class_scope_close(b, st); }
 };
 static inline double conv_flops(size_t M, int k, int cin, int n) { return 2.0 * (double)M * k * k * cin * n; }
 
