@@ -14,3 +14,12 @@ def pytest_configure(config):
 def golden():
     import numpy as np
     return np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_reference.npz'))
+
+
+def free_port():
+    """A TCP port that is free right now (rendezvous of the multi-process tests: a fixed port collides with the TIME_WAIT
+    socket of a run that ended seconds ago)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]

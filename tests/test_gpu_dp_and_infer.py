@@ -8,6 +8,8 @@ import types
 import pytest
 import torch
 
+from conftest import free_port
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -60,7 +62,7 @@ def _run(tmp_path, nproc, port):
 
 
 def test_two_rank_data_parallel_equals_single_process_on_the_global_batch(tmp_path):
-    _run(tmp_path, 2, 29731)
+    _run(tmp_path, 2, free_port())
     _run(tmp_path, 1, 0)
     r0 = torch.load(tmp_path / 'params_ws2_rank0.pt')
     r1 = torch.load(tmp_path / 'params_ws2_rank1.pt')
@@ -97,7 +99,7 @@ def test_cli_training_under_two_ranks(tmp_path):
                SININN_FORCE_DEVICE='0')
     wd = str(tmp_path / 'exp')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29741', os.path.join(ROOT, 'main.py'), 'train', '--synthetic', '52', '32', '32', '--fps', '10',
+           '--master-port', str(free_port()), os.path.join(ROOT, 'main.py'), 'train', '--synthetic', '52', '32', '32', '--fps', '10',
            '--lr_window', '1', '-c', '1', '-b', '1', '-e', '2', '--save_iter', '2', '-p', '1', '-w', wd, '--suffix', 'dp']
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]

@@ -152,11 +152,12 @@ print('rank', rank, 'ok')
 
 
 def test_data_parallel_glue_world2_gloo(tmp_path):
+    from conftest import free_port
     script = tmp_path / 'dp.py'
     script.write_text(_DP_SCRIPT % ROOT)
     env = dict(os.environ, MASTER_ADDR='127.0.0.1')
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-                          '--master-addr', '127.0.0.1', '--master-port', '29713', str(script)],
+                          '--master-addr', '127.0.0.1', '--master-port', str(free_port()), str(script)],
                          capture_output=True, text=True, env=env, timeout=240)
     assert out.returncode == 0, out.stdout + out.stderr
     assert 'rank 0 ok' in out.stdout and 'rank 1 ok' in out.stdout
