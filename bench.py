@@ -194,13 +194,14 @@ def class_roofline(precision, arch='SRF'):
             continue
         k = 1 if i >= 6 else 3
         cls = i % 6
-        wgrad_fp32 = cls == 4                              # weight gradients accumulate on the f32 pipe in both precisions
-        peak = PEAK_F32_MFMA_TFLOPS if (precision == 'fp32' or wgrad_fp32) else PEAK_BF16_MFMA_TFLOPS
+        # fp32 path: f32 matrix pipe everywhere; bf16 path: every conv class AND the weight gradients (transposing
+        # bf16-MFMA kernel, fp32 accumulation) run on the bf16 pipe
+        peak = PEAK_F32_MFMA_TFLOPS if precision == 'fp32' else PEAK_BF16_MFMA_TFLOPS
         rec = {'class': f'{k}x{k} {(IRN_CLASS_NAMES if arch == "IRN" else CLASS_NAMES)[cls]}', 'launches': cnt[i], 'ms': ms[i]}
         if fl[i] > 0:
             tf = fl[i] / (ms[i] * 1e-3) / 1e12
             rec.update(alg_tflops=tf, peak_tflops=peak, frac=tf / peak, bound='mfma')
-            wino = k == 3 and (precision == 'fp32' or wgrad_fp32)
+            wino = k == 3 and precision == 'fp32'
             if wino:
                 rec['executed_mfma_frac'] = tf / 2.25 / peak
                 rec['note'] = 'Winograd: executes 2.25x fewer MFMA FLOPs than the algorithmic count'
