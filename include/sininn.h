@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SININN_ABI_VERSION 2
+#define SININN_ABI_VERSION 3
 #define SININN_HIDDEN 256 /* hidden width of subnet_conv / subnet_conv_1x1, archs.py:12,16 */
 
 int sininn_version(void);
@@ -143,6 +143,17 @@ typedef struct sininn_conv_args {
 } sininn_conv_args;
 
 int sininn_conv(const sininn_conv_args* args, void* stream);
+
+/* Two chained 1x1 convs of a GLOW subnet in one launch (subnet_conv_1x1, archs.py:15-17, called from FrEIA's
+ * GLOWCouplingBlock, archs.py:56-64): `first` produces the 256-channel hidden tensor (mode RELU: h = relu(x W1 + b1), or
+ * mode MASK: dh = (dr W2) . [h > 0]), `second` consumes it (any non-IRN mode: the coupling epilogues forward, the skip-add /
+ * fused coupling-backward epilogues backward).  The hidden tile stays in LDS between the two GEMMs; it is still written to
+ * first->out once (training needs it) unless first->out is NULL (no-grad passes: the hidden tensor never reaches HBM;
+ * second->in is then ignored).  Same results as sininn_conv(first) followed by sininn_conv(second) up to fp32 summation
+ * order.  fp32, pixel-major operands only; sininn_conv_pair_k1_supported returns 1 when the pair's shapes / modes qualify
+ * (hidden width 256, first->Cin % 8 == 0 and <= 192, second->Np in {16, 32, 48, 64, 96, 192}). */
+int sininn_conv_pair_k1_supported(const sininn_conv_args* first, const sininn_conv_args* second);
+int sininn_conv_pair_k1(const sininn_conv_args* first, const sininn_conv_args* second, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Weight gradient: dW[n][c][tap] += sum_pixels dout[pix][n] * in[pix+tap][c], db[n] += sum dout.
@@ -266,6 +277,9 @@ typedef struct sininn_glow_args {
                                             subnets run on bf16 MFMA with fp32 accumulation (packs from
                                             sininn_pack_conv_weights_bf16, hidden tensors stored as bf16), the flow tensors,
                                             the coupling arithmetic, log-det and all gradients w.r.t. parameters stay fp32 */
+  int no_save;                           /* forward: nothing will be differentiated (torch.no_grad passes: validation /
+                                            inference, lit_wrapper.py:79-128) -- the saved s and, where the subnet runs as one
+                                            launch (1x1: sininn_conv_pair_k1), the hidden tensor are not written to HBM   */
 } sininn_glow_args;
 
 /* Live timing for bench.py: between begin and end, every forward 3x3 coupling conv (conv2 + affine epilogue) of the

@@ -51,7 +51,7 @@ class GlowArgs(C.Structure):
                 ('x', c_f), ('out', c_f), ('dst_map', c_i), ('logdet', c_f),
                 ('s1', SubnetArgs), ('s2', SubnetArgs),
                 ('saved', c_f), ('scratch', C.c_void_p), ('scratch_bytes', C.c_size_t),
-                ('dout', c_f), ('gld', c_f), ('dx', c_f), ('skip_dx', C.c_int), ('dtype', C.c_int)]
+                ('dout', c_f), ('gld', c_f), ('dx', c_f), ('skip_dx', C.c_int), ('dtype', C.c_int), ('no_save', C.c_int)]
 
 
 class WgradItem(C.Structure):
@@ -107,6 +107,7 @@ _SIGS = {
     'sininn_conv': (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     'sininn_conv_test_hooks': (None, [C.c_int, C.c_int]),
     'sininn_wgrad_test_hooks': (None, [C.c_int]),
+    'sininn_pair_k1_test_hook': (None, [C.c_int]),
     'sininn_wgrad_workspace_bytes': (C.c_size_t, [C.c_int] * 6),
     'sininn_wgrad': (C.c_int, [c_f, C.c_int, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -125,6 +126,8 @@ _SIGS = {
     'sininn_glow_scratch_bytes': (C.c_size_t, [C.c_int] * 5),
     'sininn_glow_forward': (C.c_int, [C.POINTER(GlowArgs), C.c_void_p]),
     'sininn_glow_backward': (C.c_int, [C.POINTER(GlowArgs), C.c_void_p, C.c_void_p]),
+    'sininn_conv_pair_k1_supported': (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs)]),
+    'sininn_conv_pair_k1': (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs), C.c_void_p]),
     'sininn_dense_workspace_bytes': (C.c_size_t, [C.c_int] * 5),
     'sininn_dense_forward': (C.c_int, [C.POINTER(DenseArgs), C.c_void_p]),
     'sininn_dense_backward': (C.c_int, [C.POINTER(DenseArgs), C.c_void_p, C.c_void_p]),
@@ -173,7 +176,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(handle, name)          # AttributeError if the ABI lost a symbol
             fn.restype, fn.argtypes = res, args
-        if handle.sininn_version() != 2:
+        if handle.sininn_version() != 3:
             raise ImportError('libsininn.so ABI version mismatch')
         _lib = handle
     return _lib

@@ -15,6 +15,9 @@ void set_error(const char* fmt, ...) {
 }
 
 int conv_launch(const sininn_conv_args* a, hipStream_t st);
+int conv_pair_k1_supported(const sininn_conv_args* f, const sininn_conv_args* s);
+int conv_pair_k1_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st);
+void conv_pair_k1_enable(int on);
 void conv_set_test_hooks(int force_cfg, int force_ck);
 void wgrad_set_force16(int on);
 size_t wgrad_workspace_bytes(int N, int Cin, int ksize, int B, int H, int W);
@@ -188,10 +191,17 @@ void sininn_coupling_colmap(int Co, int tile, int* colmap_host) {
 }
 
 int sininn_conv(const sininn_conv_args* args, void* stream) { return conv_launch(args, ST(stream)); }
+int sininn_conv_pair_k1_supported(const sininn_conv_args* first, const sininn_conv_args* second) {
+  return conv_pair_k1_supported(first, second);
+}
+int sininn_conv_pair_k1(const sininn_conv_args* first, const sininn_conv_args* second, void* stream) {
+  return conv_pair_k1_launch(first, second, ST(stream));
+}
 
 /* test hook (not part of the documented surface): force tile configuration / channel chunk */
 void sininn_conv_test_hooks(int force_cfg, int force_ck) { conv_set_test_hooks(force_cfg, force_ck); }
 void sininn_wgrad_test_hooks(int force16) { wgrad_set_force16(force16); }
+void sininn_pair_k1_test_hook(int on) { conv_pair_k1_enable(on); }
 
 size_t sininn_wgrad_workspace_bytes(int N, int Cin, int ksize, int B, int H, int W) {
   return wgrad_workspace_bytes(N, Cin, ksize, B, H, W);

@@ -17,9 +17,9 @@ static int g_ablate = 0;     // diagnostic: see ConvDev::ablate (results are wro
 
 int conv_bf16_launch(const sininn_conv_args* a, hipStream_t st);
 
-int conv_launch(const sininn_conv_args* a, hipStream_t st) {
+// argument validation + device-side descriptor of one fp32 conv (shared by conv_launch and the fused 1x1 pair)
+int conv_prepare(const sininn_conv_args* a, ConvDev& d) {
   SININN_CHECK(a != nullptr, "conv: null args");
-  if (a->w_bf16) return conv_bf16_launch(a, st);
   SININN_CHECK(a->ksize == 1 || a->ksize == 3, "conv: ksize %d not in {1,3}", a->ksize);
   SININN_CHECK(a->Cin > 0 && a->Cin % 8 == 0, "conv: Cin=%d must be a positive multiple of 8", a->Cin);
   SININN_CHECK(a->Np > 0 && a->Np % 16 == 0, "conv: Np=%d must be a positive multiple of 16", a->Np);
@@ -58,7 +58,6 @@ int conv_launch(const sininn_conv_args* a, hipStream_t st) {
   SININN_CHECK(a->N % 4 == 0 || couple, "conv: N must be a multiple of 4");
   if ((a->mode == SININN_CONV_ADD || a->mode == SININN_CONV_ADD_CBWD_FWD || a->mode == SININN_CONV_ADD_CBWD_INV) && !a->addend_map)
     SININN_CHECK(aligned16(a->addend) && a->addend_stride % 4 == 0, "conv: addend must be 16-byte aligned");
-  ConvDev d;
   d.in = a->in; d.in_stride = a->in_stride; d.Cin = a->Cin;
   d.w = a->w; d.bias = a->bias; d.Np = a->Np;
   d.B = a->B; d.H = a->H; d.W = a->W;
@@ -87,6 +86,16 @@ int conv_launch(const sininn_conv_args* a, hipStream_t st) {
   for (int c : {32, 24, 16, 8}) if (a->Cin % c == 0) { ck = c; break; }
   if (g_force_ck && a->Cin % g_force_ck == 0 && g_force_ck % 8 == 0 && g_force_ck <= 32) ck = g_force_ck;
   d.CK = ck;
+  d.tiles_x = d.tiles_y = 0;
+  return 0;
+}
+
+int conv_launch(const sininn_conv_args* a, hipStream_t st) {
+  SININN_CHECK(a != nullptr, "conv: null args");
+  if (a->w_bf16) return conv_bf16_launch(a, st);
+  ConvDev d;
+  if (int rc = conv_prepare(a, d)) return rc;
+  const bool couple = a->mode == SININN_CONV_COUPLE_FWD || a->mode == SININN_CONV_COUPLE_INV;
   if (a->winograd) {
     SININN_CHECK(a->ksize == 3, "conv: the Winograd pack needs ksize 3");
     d.col_tile = (couple && a->col_tile == 32) ? 32 : 16;

@@ -1,0 +1,287 @@
+// Two chained 1x1 convs of a GLOW subnet in ONE launch, the 256-channel hidden tile kept in LDS between them
+// (reference: subnet_conv_1x1, archs.py:15-17, inside FrEIA's GLOWCouplingBlock, archs.py:56-64):
+//   forward :  h  = relu(x W1^T + b1)          ->  (s,t) = h W2^T + b2   -> affine coupling epilogue
+//   backward:  dh = (dr W2) . [h > 0]          ->  dx    = dh W1         -> skip-add / fused coupling-backward epilogue
+// The two-kernel path moves the hidden tensor (67 MB at BASELINE configs[1], level 0) through HBM / the Infinity Cache
+// twice per pair -- once written by the first conv at the CU's store-drain rate, once re-read by the second with two
+// blocks per CU in flight ("1x1 subnets").  Here the first conv's tile stays on chip for the second; it is still
+// written to HBM once (training needs h for the ReLU mask / weight gradient, dh for the weight gradient) but that store
+// now overlaps the second GEMM, and it is skipped entirely when `first->out` is NULL (no-grad passes).
+//
+// Block = TH x 16 pixels (P = 16 TH; 64 pixels when the second conv has fewer than four 16-column tiles, else 32 so that two
+// blocks fit a CU's LDS and one block's HBM pass overlaps the other's MFMAs), 256 threads.  Both GEMMs run on v_mfma_f32_16x16x4_f32, rows = pixels:
+//   stage 1: wave w owns hidden columns [64 w, 64 w + 64); A = the staged input tile (LDS), B = rows of the packed weights
+//            [256][K1] read straight from L2 (16 bytes per lane per 16 channels: the k order inside a 16-channel step is
+//            permuted identically for A and B, so one float4 feeds four MFMAs);
+//   pass   : bias + ReLU (or the ReLU mask read from HBM) over the LDS tile with 16-byte accesses, the same pass writes
+//            the tile to HBM;
+//   stage 2: the N2 / 16 column tiles are dealt round-robin to the waves, all TH row tiles each; A = the hidden tile (LDS),
+//            B = rows of the second conv's packed weights [N2][256] from L2; accumulators -> T[pixel][N2 + 4] in LDS ->
+//            the shared epilogue (conv_mfma_impl.h), so every mode of the two-kernel path behaves identically.
+#include "conv_mfma_impl.h"
+
+namespace sininn {
+
+int conv_prepare(const sininn_conv_args* a, ConvDev& d);
+
+struct PairDev { ConvDev a, b; };
+
+constexpr int PK_HID = 256;           // hidden channels (SININN_HIDDEN)
+constexpr int PK_HS = PK_HID + 4;     // floats per pixel row of the hidden tile in LDS
+
+template <int TH, int BN2, int HT>
+__global__ __launch_bounds__(256) void conv_pair_k1_kernel(PairDev q) {
+  constexpr int P = TH * 16, MT = TH;
+  constexpr int NT2 = BN2 / 16;
+  const ConvDev& pa = q.a;
+  const ConvDev& pb = q.b;
+  extern __shared__ __attribute__((aligned(16))) float smem_pair[];
+  const int K1 = pa.Cin, K1R = (K1 + 15) / 16 * 16, XS = K1R + 4;
+  float* const hs = smem_pair;                     // [P][PK_HS]; later T[P][BN2 + 4]
+  float* const xs = smem_pair + P * PK_HS;         // [P][XS]
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, kq = lane >> 4;
+  int bid = blockIdx.x;
+  const int tx = bid % pa.tiles_x; bid /= pa.tiles_x;
+  const int ty = bid % pa.tiles_y;
+  const int b = bid / pa.tiles_y;
+  const int y0 = ty * TH, x0 = tx * 16;
+
+  // phase stamps (diagnostic, second->stamp -> 8 words: input staging, GEMM 1, activation pass, GEMM 2, epilogue, -, total,
+  // blocks): thread 0 of every block adds its shader-clock deltas (tools/bench_pair.py --phases)
+  const bool stamping = pb.stamp != nullptr && tid == 0;
+  unsigned long long tprev = stamping ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long tstart = tprev;
+  auto mark = [&](int k) {
+    if (stamping) { const unsigned long long t = __builtin_amdgcn_s_memtime(); atomicAdd(pb.stamp + k, t - tprev); tprev = t; }
+  };
+
+  // ---- stage 0: input tile -> LDS (zero beyond the image and beyond K1) --------------------------------------------
+  {
+    const int q4 = K1R / 4;
+    for (int f = tid; f < P * q4; f += 256) {
+      const int pl = f / q4, c = (f - pl * q4) * 4;
+      const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gy < pa.H && gx < pa.W && c < K1)
+        v = *reinterpret_cast<const f32x4*>(pa.in + ((size_t)(b * pa.H + gy) * pa.W + gx) * pa.in_stride + c);
+      *reinterpret_cast<f32x4*>(xs + pl * XS + c) = v;
+    }
+  }
+  __syncthreads();
+  mark(0);
+
+  // ---- stage 1: hidden[P][256] = in[P][K1] . Wa[256][K1]^T ; wave w -> columns 64 w .. 64 w + 63 -----------------------
+  {
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* wrow = pa.w + (size_t)(wave * 64 + li) * K1 + 4 * kq;
+    const int nsteps = K1R / 16;
+    auto load_b = [&](int s, f32x4 (&bf)[4]) {
+      const bool live = 16 * s + 4 * kq < K1;         // K1 % 4 == 0 (host check)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        bf[n] = live ? *reinterpret_cast<const f32x4*>(wrow + (size_t)n * 16 * K1 + ((pa.ablate & 1) ? 0 : 16 * s)) : z;
+      }
+    };
+    f32x4 bf[4], bn[4];
+    load_b(0, bf);
+    for (int s = 0; s < nsteps; ++s) {
+      if (s + 1 < nsteps) load_b(s + 1, bn);
+      f32x4 af[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const f32x4*>(xs + (m * 16 + li) * XS + 16 * s + 4 * kq);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][j], bf[n][j], acc[m][n], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) bf[n] = bn[n];
+    }
+    // D[row = 4 kq + r][col = li] -> hs[pixel][column] (raw sums; bias / activation in the pass below)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hs[(m * 16 + 4 * kq + r) * PK_HS + wave * 64 + n * 16 + li] = acc[m][n][r];
+  }
+  __syncthreads();
+  mark(1);
+
+  // ---- pass: bias + ReLU (forward) / ReLU mask (backward) on the tile, 16 bytes per access; the tile goes to HBM ---------
+  {
+    constexpr int Q = PK_HID / 4;                    // 64 quads per pixel: a thread keeps its quad, 4 pixels per iteration
+    const int cq = (tid & 63) * 4;
+    f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+    if (pa.bias) bq = *reinterpret_cast<const f32x4*>(pa.bias + cq);
+    const bool masked = pa.mode == SININN_CONV_MASK;
+#pragma unroll 4
+    for (int pl = tid >> 6; pl < P; pl += 4) {
+      const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+      const bool inimg = gy < pa.H && gx < pa.W;
+      const size_t pix = (size_t)(b * pa.H + gy) * pa.W + gx;
+      f32x4 v = *reinterpret_cast<const f32x4*>(hs + pl * PK_HS + cq) + bq;
+      if (masked) {
+        f32x4 m = {0.f, 0.f, 0.f, 0.f};
+        if (inimg) m = *reinterpret_cast<const f32x4*>(pa.mask + pix * pa.mask_stride + cq);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = m[j] > 0.f ? v[j] : 0.f;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      if (!inimg) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(hs + pl * PK_HS + cq) = v;
+      if (inimg && pa.out && !(pa.ablate & 2)) *reinterpret_cast<f32x4*>(pa.out + pix * pa.out_stride + cq) = v;
+    }
+    (void)Q;
+  }
+  __syncthreads();
+  mark(2);
+
+  // ---- stage 2: out[P][BN2] = hidden[P][256] . Wb[BN2][256]^T -------------------------------------------------------------
+  // >= 4 column tiles: they are dealt round-robin to the waves (nt = wave, wave + 4, ...), every wave takes all row tiles;
+  // fewer (level-0 shapes: N2 = 48 / 32): every wave takes ONE row tile and all column tiles, so no wave idles -- its
+  // 4 * NT2 MFMAs per 16-channel step are shorter than an L2 round trip, hence the weights are requested two steps ahead
+  constexpr bool MSPLIT = NT2 < 4;
+  // wave grid of stage 2: WM x WN = 4; row-split: one row tile per wave (P = 64: WM = 4) or per wave pair (P = 32: WM = 2,
+  // the pair's two waves take alternate column tiles)
+  constexpr int WM = MSPLIT ? MT : 1, WN = 4 / WM;
+  static_assert(!MSPLIT || MT == 4 || MT == 2, "row-tile split needs 2 or 4 row tiles");
+  constexpr int NI = (NT2 + WN - 1) / WN, MI = MSPLIT ? 1 : MT, DEPTH = MSPLIT ? 2 : 1;
+  f32x4 acc2[NI][MI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int m = 0; m < MI; ++m) acc2[i][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto nt_of = [&](int i) -> int { return (wave / WM) + WN * i; };
+  auto mt_of = [&](int m) -> int { return MSPLIT ? (wave % WM) : m; };
+  {
+    const float* wrow = pb.w + (size_t)li * PK_HID + 4 * kq;
+    constexpr int NSTEPS = PK_HID / 16;
+    f32x4 bf[DEPTH + 1][NI];
+    auto load_b = [&](int s, f32x4 (&dst)[NI]) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int nt = nt_of(i);
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        dst[i] = nt < NT2 ? *reinterpret_cast<const f32x4*>(wrow + (size_t)((pa.ablate & 1) ? 0 : nt) * 16 * PK_HID + ((pa.ablate & 1) ? 0 : 16 * s)) : z;
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) load_b(s, bf[s]);
+#pragma unroll
+    for (int s = 0; s < NSTEPS; ++s) {
+      if (s + DEPTH < NSTEPS) load_b(s + DEPTH, bf[(s + DEPTH) % (DEPTH + 1)]);
+      f32x4 af[MI];
+#pragma unroll
+      for (int m = 0; m < MI; ++m) af[m] = *reinterpret_cast<const f32x4*>(hs + (mt_of(m) * 16 + li) * PK_HS + 16 * s + 4 * kq);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int m = 0; m < MI; ++m)
+            acc2[i][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][j], bf[s % (DEPTH + 1)][i][j], acc2[i][m], 0, 0, 0);
+    }
+  }
+  __syncthreads();                                   // every wave is done reading the hidden tile
+  mark(3);
+  constexpr int TS = BN2 + 4;
+  float* const T = smem_pair;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int nt = nt_of(i);
+    if (nt < NT2) {
+#pragma unroll
+      for (int m = 0; m < MI; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[(mt_of(m) * 16 + 4 * kq + r) * TS + nt * 16 + li] = acc2[i][m][r];
+    }
+  }
+  __syncthreads();
+  __shared__ float red[4];
+  conv_epilogue_tile<TH, BN2, HT, 256>(pb, T, b, y0, x0, 0, tid, red);
+  if (stamping) {
+    mark(4);
+    atomicAdd(pb.stamp + 6, tprev - tstart);
+    atomicAdd(pb.stamp + 7, 1ull);
+  }
+}
+
+template <int TH, int BN2, int HT>
+static int pair_launch(PairDev& q, hipStream_t st) {
+  constexpr int P = TH * 16;
+  q.a.tiles_x = q.b.tiles_x = (q.a.W + 15) / 16;
+  q.a.tiles_y = q.b.tiles_y = (q.a.H + TH - 1) / TH;
+  const int K1R = (q.a.Cin + 15) / 16 * 16;
+  const size_t lds = (size_t)(P * PK_HS + P * (K1R + 4)) * sizeof(float);
+  SININN_CHECK(lds <= 160 * 1024 && (size_t)P * (BN2 + 4) <= (size_t)P * PK_HS, "conv_pair: LDS tile too large");
+  auto k = conv_pair_k1_kernel<TH, BN2, HT>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("conv_pair: cannot raise LDS limit to %zu", lds); return 1; }
+  }
+  hipLaunchKernelGGL(k, dim3(q.a.tiles_x * q.a.tiles_y * q.a.B), dim3(256), lds, st, q);
+  SININN_LAUNCH_CHECK("conv_pair_k1");
+  return 0;
+}
+
+void conv_pair_k1_enable(int on);
+#ifndef PAIR_TH
+#define PAIR_TH 2
+#endif
+static bool g_pair_enabled = getenv("SININN_PAIR_K1") == nullptr || atoi(getenv("SININN_PAIR_K1")) != 0;   // A/B switch
+
+void conv_pair_k1_enable(int on) { g_pair_enabled = on != 0; }     // test hook: A/B against the two-launch path
+
+// 1 when the pair (first: RELU or MASK into the 256-channel hidden tensor; second: any mode reading it) can run fused
+int conv_pair_k1_supported(const sininn_conv_args* f, const sininn_conv_args* s) {
+  if (!g_pair_enabled || !f || !s) return 0;
+  if (f->ksize != 1 || s->ksize != 1 || f->w_bf16 || s->w_bf16 || f->winograd || s->winograd) return 0;
+  if (f->in_bf16 || f->out_bf16 || f->mask_bf16 || s->in_bf16 || s->out_bf16 || s->mask_bf16) return 0;
+  if (f->in_group_stride > 0 || f->out_group_stride > 0 || f->mask_group_stride > 0 || s->in_group_stride > 0 ||
+      s->out_group_stride > 0 || s->mask_group_stride > 0) return 0;
+  if (!(f->mode == SININN_CONV_RELU || f->mode == SININN_CONV_MASK)) return 0;
+  if (f->Np != PK_HID || f->N != PK_HID || s->Cin != PK_HID || s->in_stride != PK_HID) return 0;
+  if (f->out && (s->in != f->out || f->out_stride != PK_HID)) return 0;
+  if (f->Cin % 8 != 0 || f->Cin > 192) return 0;
+  if (f->B != s->B || f->H != s->H || f->W != s->W) return 0;
+  if (s->mode == SININN_CONV_IRN_FWD || s->mode == SININN_CONV_IRN_INV || s->mode == SININN_CONV_LRELU) return 0;
+  const bool couple = s->mode == SININN_CONV_COUPLE_FWD || s->mode == SININN_CONV_COUPLE_INV;
+  if (couple && s->col_tile == 32) return s->Np == 64 || s->Np == 192 || s->Np == 96 || s->Np == 32;
+  return s->Np == 16 || s->Np == 32 || s->Np == 48 || s->Np == 64 || s->Np == 96 || s->Np == 192;
+}
+
+int conv_pair_k1_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st) {
+  SININN_CHECK(conv_pair_k1_supported(f, s), "conv_pair: unsupported pair (check sininn_conv_pair_k1_supported first)");
+  PairDev q;
+  sininn_conv_args fa = *f;
+  alignas(16) float dummy_out[4] = {0.f, 0.f, 0.f, 0.f};   // conv_prepare insists on an output pointer; NULL = "do not store h"
+  if (!fa.out) { fa.out = dummy_out; fa.out_stride = PK_HID; }
+  if (int rc = conv_prepare(&fa, q.a)) return rc;
+  if (!f->out) q.a.out = nullptr;
+  sininn_conv_args sa = *s;
+  if (!f->out) sa.in = q.a.in;                        // never dereferenced: the second conv reads the LDS tile
+  if (int rc = conv_prepare(&sa, q.b)) return rc;
+  const bool couple = s->mode == SININN_CONV_COUPLE_FWD || s->mode == SININN_CONV_COUPLE_INV;
+  const bool ht16 = couple && s->col_tile == 32;
+#define PAIR_CASE(BN) case BN: return ht16 ? pair_launch<PAIR_TH, BN, 16>(q, st) : pair_launch<PAIR_TH, BN, 8>(q, st)
+  switch (s->Np) {
+    PAIR_CASE(16); PAIR_CASE(32); PAIR_CASE(48); PAIR_CASE(64); PAIR_CASE(96); PAIR_CASE(192);
+    default: set_error("conv_pair: unsupported Np=%d", s->Np); return 1;
+  }
+#undef PAIR_CASE
+}
+
+}  // namespace sininn

@@ -13,6 +13,8 @@
 namespace sininn {
 
 int conv_launch(const sininn_conv_args* a, hipStream_t st);
+int conv_pair_k1_supported(const sininn_conv_args* f, const sininn_conv_args* s);
+int conv_pair_k1_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st);
 size_t wgrad_workspace_bytes(int N, int Cin, int ksize, int B, int H, int W);
 int wgrad_launch(const float* in, int in_stride, int Cin, const float* dout, int dout_stride, int N, int B, int H, int W,
                  int ksize, float* gw, float* gb, void* ws, size_t ws_bytes, hipStream_t st);
@@ -283,10 +285,6 @@ int glow_forward(const sininn_glow_args* a, hipStream_t st) {
     // chunk are then contiguous runs for the K = 256 convs that read them (dominant kernel -10 %)
     const bool gm = group_major_hidden(a, h.net);
     if (gm) c1.out_group_stride = (int)(M * 8);
-    {
-      ClassScope sc(PC_CONV1, a->ksize, conv_flops(M, a->ksize, c1.Cin, SININN_HIDDEN), st);
-      if (int rc = conv_launch(&c1, st)) return rc;
-    }
     sininn_conv_args c2 = {};
     c2.in = hbuf; c2.in_stride = SININN_HIDDEN; c2.Cin = SININN_HIDDEN;
     c2.w = h.net->w2; c2.bias = h.net->b2; c2.Np = 2 * h.co; c2.winograd = (h.net->winograd & 2) && a->ksize == 3;
@@ -299,6 +297,18 @@ int glow_forward(const sininn_glow_args* a, hipStream_t st) {
     c2.sbuf = sbuf; c2.logdet = a->logdet; c2.Co = h.co; c2.clamp = a->clamp; c2.col_tile = col_tile_of(h.co);
     if (bf16) { c2.winograd = 0; c2.w_bf16 = 1; c2.in_bf16 = 1; }                       // h bf16 -> fp32 coupling epilogue
     if (gm) { c2.in_stride = 8; c2.in_group_stride = (int)(M * 8); }
+    if (a->no_save) c2.sbuf = nullptr;               // s is kept for the backward pass only
+    // 1x1 subnets (fp32): both convs in one launch, the hidden tile stays in LDS between them (conv_pair_k1.hip)
+    if (conv_pair_k1_supported(&c1, &c2)) {
+      if (a->no_save) c1.out = nullptr;              // ... and then the hidden tensor never reaches HBM
+      ClassScope sc(PC_COUPLE, a->ksize, conv_flops(M, a->ksize, c1.Cin, SININN_HIDDEN) + conv_flops(M, a->ksize, SININN_HIDDEN, 2 * h.co), st);
+      if (int rc = conv_pair_k1_launch(&c1, &c2, st)) return rc;
+      continue;
+    }
+    {
+      ClassScope sc(PC_CONV1, a->ksize, conv_flops(M, a->ksize, c1.Cin, SININN_HIDDEN), st);
+      if (int rc = conv_launch(&c1, st)) return rc;
+    }
     hipEvent_t e0, e1;
     unsigned long long* stamp = nullptr;
     const bool timed = g_prof_h != 0 && a->ksize == 3 && a->H == g_prof_h && prof_pair(&e0, &e1, &stamp);
@@ -378,7 +388,29 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
     d2.out = dh; d2.out_stride = SININN_HIDDEN; d2.N = SININN_HIDDEN; d2.mask = hbuf; d2.mask_stride = SININN_HIDDEN;
     if (bf16) { d2.winograd = 0; d2.w_bf16 = 1; d2.in_bf16 = 0; d2.out_bf16 = 1; d2.mask_bf16 = 1; }   // dr fp32 -> dh bf16
     if (gm) { d2.out_group_stride = gs; d2.mask_group_stride = gs; }
-    {
+    // the data gradient of conv1 (d1) is described first: a 1x1 pair (d2 -> d1) runs as one launch with dh kept in LDS
+    // (still written once for conv1's weight gradient)
+    sininn_conv_args d1 = {};
+    d1.in = dh; d1.in_stride = SININN_HIDDEN; d1.Cin = SININN_HIDDEN; d1.w = net->w1_dgrad;
+    d1.winograd = (net->winograd & 4) && k == 3;
+    if (bf16) { d1.winograd = 0; d1.w_bf16 = 1; d1.in_bf16 = 1; }                                       // dh bf16 -> fp32 epilogue
+    if (gm) { d1.in_stride = 8; d1.in_group_stride = gs; }
+    d1.Np = d1.winograd ? (cond_cin + 31) / 32 * 32 : pad16i(cond_cin);
+    d1.B = B; d1.H = H; d1.W = W; d1.ksize = k; d1.mode = SININN_CONV_ADD;
+    d1.out = dcond; d1.out_stride = dcond_stride; d1.N = cond_cin;
+    d1.addend = addend; d1.addend_stride = add_stride; d1.addend_map = add_map;
+    if (fuse) {
+      d1.mode = inv ? SININN_CONV_ADD_CBWD_INV : SININN_CONV_ADD_CBWD_FWD;
+      d1.out = fuse->dr; d1.out_stride = 2 * cond_cin;
+      d1.v = fuse->vy; d1.v_stride = fuse->vy_stride; d1.sbuf = const_cast<float*>(fuse->s);
+      d1.out2 = a->dx + hv[0].base; d1.out2_stride = C;
+      d1.logdet = const_cast<float*>(a->gld); d1.Co = cond_cin; d1.clamp = a->clamp;
+    }
+    const bool pair = !skip_d1 && conv_pair_k1_supported(&d2, &d1);
+    if (pair) {
+      ClassScope scp(PC_DGRAD2, k, conv_flops(M, k, 2 * h.co, SININN_HIDDEN) + conv_flops(M, k, SININN_HIDDEN, cond_cin), st);
+      if (int rc = conv_pair_k1_launch(&d2, &d1, st)) return rc;
+    } else {
       ClassScope scp(PC_DGRAD2, k, conv_flops(M, k, 2 * h.co, SININN_HIDDEN), st);
       if (int rc = conv_launch(&d2, st)) return rc;
     }
@@ -399,23 +431,7 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
         n_items = 0;
       }
     }
-    if (skip_d1) return 0;                           // the gradient w.r.t. this half's condition is not needed
-    sininn_conv_args d1 = {};
-    d1.in = dh; d1.in_stride = SININN_HIDDEN; d1.Cin = SININN_HIDDEN; d1.w = net->w1_dgrad;
-    d1.winograd = (net->winograd & 4) && k == 3;
-    if (bf16) { d1.winograd = 0; d1.w_bf16 = 1; d1.in_bf16 = 1; }                                       // dh bf16 -> fp32 epilogue
-    if (gm) { d1.in_stride = 8; d1.in_group_stride = gs; }
-    d1.Np = d1.winograd ? (cond_cin + 31) / 32 * 32 : pad16i(cond_cin);
-    d1.B = B; d1.H = H; d1.W = W; d1.ksize = k; d1.mode = SININN_CONV_ADD;
-    d1.out = dcond; d1.out_stride = dcond_stride; d1.N = cond_cin;
-    d1.addend = addend; d1.addend_stride = add_stride; d1.addend_map = add_map;
-    if (fuse) {
-      d1.mode = inv ? SININN_CONV_ADD_CBWD_INV : SININN_CONV_ADD_CBWD_FWD;
-      d1.out = fuse->dr; d1.out_stride = 2 * cond_cin;
-      d1.v = fuse->vy; d1.v_stride = fuse->vy_stride; d1.sbuf = const_cast<float*>(fuse->s);
-      d1.out2 = a->dx + hv[0].base; d1.out2_stride = C;
-      d1.logdet = const_cast<float*>(a->gld); d1.Co = cond_cin; d1.clamp = a->clamp;
-    }
+    if (skip_d1 || pair) return 0;                   // the gradient w.r.t. this half's condition is not needed / already done
     ClassScope scp(PC_DGRAD1, k, conv_flops(M, k, SININN_HIDDEN, cond_cin), st);
     return conv_launch(&d1, st);
   };

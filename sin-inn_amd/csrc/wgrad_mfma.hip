@@ -818,15 +818,29 @@ __device__ __forceinline__ unsigned pack_bf16_pair(float lo, float hi) {
   return *reinterpret_cast<unsigned*>(&v);
 }
 
-template <int KS>
-__device__ __forceinline__ void wgrad_bf16_body(const WgradDev& p, const int split, const int n0, const int c0, const int zblock) {
+// Staging is split into a load phase (global -> registers, issued for the NEXT pixel tile before the MFMA loop of the
+// current one) and a store phase (registers -> transposed LDS tile): the first build loaded and stored in one loop between
+// the two barriers, which left every tile's global-load latency exposed (only the CU's second block covered it).
+// IN_BF16 / DOUT_BF16 = storage type of the two operands (an fp32 operand is rounded while it is stored).  A 3x3 problem
+// holds 144 accumulator registers, so only its bf16 operand (the 256-channel hidden tensor / hidden gradient: the HBM
+// stream) is prefetched across the MFMA loop (16-32 VGPRs); the fp32 operand's loads (32-64 VGPRs) are issued after the
+// loop, not live across it -- prefetching both spilled 98 VGPRs.  1x1 problems (16 accumulators) prefetch both.
+constexpr int WGB_PD = 128 * 2 + 16;                                  // bytes per dout row (channel n): 4-bank step
+constexpr int wgb_pi(int ks) { return (((8 + 2 * (ks / 2)) * 24 * 2 + 255) / 256) * 256 + 16; }   // bytes per in row (channel c)
+
+template <int KS, bool IN_BF16, bool DOUT_BF16>
+__device__ __forceinline__ void wgrad_bf16_body(const WgradDev& p, const int split, const int n0, const int c0, const int zblock,
+                                                unsigned char* const lds) {
   constexpr int HALO = KS / 2, TAPS = KS * KS, TH = 8;
   constexpr int IROWS = TH + 2 * HALO, IWV = 16 + 2 * HALO;          // staged halo rows, valid pixels per halo row
   constexpr int IROWP = 24;                                           // pixels per halo row in LDS (x = 16 .. 23 readable)
-  constexpr int PD = 128 * 2 + 16;                                    // bytes per dout row (channel n): 4-bank step
-  constexpr int PI = ((IROWS * IROWP * 2 + 255) / 256) * 256 + 16;    // bytes per in row (channel c): 4-bank step
+  constexpr int PD = WGB_PD, PI = wgb_pi(KS);
   constexpr int IPAIRS = IROWS * (IWV / 2);                           // pixel pairs of the halo tile
-  __shared__ __attribute__((aligned(16))) unsigned char lds[64 * PD + 64 * PI];
+  constexpr int DG = DOUT_BF16 ? 8 : 16, IG = IN_BF16 ? 8 : 16;       // channel groups of the 64 staged channels (8 bf16 / 4 fp32 per load)
+  constexpr int D_ITEMS = 64 * DG / 256;                              // (pixel pair, group) items per thread: 2 / 4
+  constexpr int I_GRPS = 64 * IG / 256, I_RND = (IPAIRS + 63) / 64;   // groups per thread, rounds of 64 pixel pairs
+  constexpr int I_ITEMS = I_GRPS * I_RND;
+  constexpr bool PF_I = IN_BF16 || KS == 1, PF_D = (DOUT_BF16 && !(IN_BF16 && KS == 3)) || KS == 1;
   unsigned char* const dT = lds;
   unsigned char* const iT = lds + 64 * PD;
 
@@ -844,88 +858,140 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradDev& p, const int spl
 
   const int t_begin = split * p.tiles_per_split;
   const int t_end = min(t_begin + p.tiles_per_split, p.ntiles);
-  const int dgrp = p.dout_bf16 ? 8 : 16;        // channel groups of the 64 staged dout channels (8 bf16 / 4 fp32 per load)
-  const int igrp = p.in_bf16 ? 8 : 16;
 
-  for (int tile = t_begin; tile < t_end; ++tile) {
+  wgb_u32x4 d_reg[PF_D ? D_ITEMS : 1][2], i_reg[PF_I ? I_ITEMS : 1][2];   // (pixel, pixel + 1) of one channel group, raw 16 bytes each
+  const wgb_u32x4 zero4 = {0u, 0u, 0u, 0u};
+  auto tile_origin = [&](int tile, int& b, int& y0, int& x0) {
     int tt = tile;
     const int tx = tt % p.tiles_x; tt /= p.tiles_x;
     const int ty = tt % p.tiles_y;
-    const int b = tt / p.tiles_y;
-    const int y0 = ty * TH, x0 = tx * 16;
-    __syncthreads();                              // the previous tile's fragment reads are done
-    // ---- dout tile: 64 pixel pairs x channel groups, transposed into dT[n][pixel] -------------------------------
-    for (int f = tid; f < 64 * dgrp; f += 256) {
+    b = tt / p.tiles_y; y0 = ty * TH; x0 = tx * 16;
+  };
+  auto load16 = [&](const float* base, size_t elem, bool is_bf16) -> wgb_u32x4 {
+    return is_bf16 ? *reinterpret_cast<const wgb_u32x4*>(reinterpret_cast<const __bf16*>(base) + elem)
+                   : *reinterpret_cast<const wgb_u32x4*>(base + elem);
+  };
+  auto load_d = [&](int tile) {
+    int b, y0, x0; tile_origin(tile, b, y0, x0);
+#pragma unroll
+    for (int i = 0; i < D_ITEMS; ++i) {
+      const int f = tid + 256 * i;
       const int pp = f & 63, g = f >> 6;
-      const int py = pp >> 3, px = (pp & 7) * 2;
-      const int gy = y0 + py, gx = x0 + px;
-      const bool in0 = gy < p.H && gx < p.W, in1 = gy < p.H && gx + 1 < p.W;
-      const size_t base = ((size_t)(b * p.H + gy) * p.W + gx) * p.dout_stride;
-      if (p.dout_bf16) {
-        const int n = n0 + g * 8;
-        wgb_bf16x8 v0 = {}, v1 = {};
-        if (n < p.N) {                             // N % 8 == 0 on this path (host check)
-          if (in0) v0 = *reinterpret_cast<const wgb_bf16x8*>(reinterpret_cast<const __bf16*>(p.dout) + base + n);
-          if (in1) v1 = *reinterpret_cast<const wgb_bf16x8*>(reinterpret_cast<const __bf16*>(p.dout) + base + p.dout_stride + n);
-        }
-        const unsigned short* a = reinterpret_cast<const unsigned short*>(&v0);
-        const unsigned short* c = reinterpret_cast<const unsigned short*>(&v1);
+      const int gy = y0 + (pp >> 3), gx = x0 + (pp & 7) * 2;
+      const int n = n0 + g * (DOUT_BF16 ? 8 : 4);
+      const bool rowok = gy < p.H && n < p.N;                        // N % 8 (bf16) / % 4 (fp32) == 0: host check
+      const size_t base = ((size_t)(b * p.H + gy) * p.W + gx) * p.dout_stride + n;
+      d_reg[i][0] = (rowok && gx < p.W) ? load16(p.dout, base, DOUT_BF16) : zero4;
+      d_reg[i][1] = (rowok && gx + 1 < p.W) ? load16(p.dout, base + p.dout_stride, DOUT_BF16) : zero4;
+    }
+  };
+  auto load_i = [&](int tile) {
+    int b, y0, x0; tile_origin(tile, b, y0, x0);
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          *reinterpret_cast<unsigned*>(dT + (g * 8 + j) * PD + pp * 4) = (unsigned)a[j] | ((unsigned)c[j] << 16);
-      } else {
-        const int n = n0 + g * 4;
-        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
-        if (n < p.N) {
-          if (in0) v0 = *reinterpret_cast<const f32x4*>(p.dout + base + n);
-          if (in1) v1 = *reinterpret_cast<const f32x4*>(p.dout + base + p.dout_stride + n);
-        }
+    for (int gi = 0; gi < I_GRPS; ++gi) {
+      const int f = tid + 256 * gi;
+      const int g = f >> 6, l = f & 63;
+      const int c = c0 + g * (IN_BF16 ? 8 : 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          *reinterpret_cast<unsigned*>(dT + (g * 4 + j) * PD + pp * 4) = pack_bf16_pair(v0[j], v1[j]);
+      for (int rnd = 0; rnd < I_RND; ++rnd) {
+        const int q = l + 64 * rnd;
+        const int row = q / (IWV / 2), pr = q - row * (IWV / 2);
+        const int gy = y0 + row - HALO, gx = x0 + pr * 2 - HALO;
+        const bool rowok = q < IPAIRS && gy >= 0 && gy < p.H && c < p.Cin;
+        const size_t base = ((size_t)(b * p.H + gy) * p.W + gx) * p.in_stride + c;       // used only when in range
+        i_reg[gi * I_RND + rnd][0] = (rowok && gx >= 0 && gx < p.W) ? load16(p.in, base, IN_BF16) : zero4;
+        i_reg[gi * I_RND + rnd][1] = (rowok && gx + 1 >= 0 && gx + 1 < p.W) ? load16(p.in, base + p.in_stride, IN_BF16) : zero4;
       }
     }
-    // ---- in halo tile: pixel pairs of (TH + 2) x 18 pixels, transposed into iT[c][row][x] ---------------------------
-    for (int f = tid; f < 64 * igrp; f += 256) {
-      // 64 lanes = 64 consecutive pixel pairs of one channel group; IPAIRS (<= 90) pairs take two rounds
+  };
+  // (pixel, pixel + 1) pairs of channel j of a group -> one dword; rows of the transposed tile are `pitch` bytes apart
+  auto store_pairs = [&](unsigned char* dst, int pitch, const wgb_u32x4& v0, const wgb_u32x4& v1, bool is_bf16) {
+    if (is_bf16) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        *reinterpret_cast<unsigned*>(dst + (2 * k) * pitch) = (v0[k] & 0xffffu) | (v1[k] << 16);
+        *reinterpret_cast<unsigned*>(dst + (2 * k + 1) * pitch) = (v0[k] >> 16) | (v1[k] & 0xffff0000u);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<unsigned*>(dst + j * pitch) = pack_bf16_pair(__uint_as_float(v0[j]), __uint_as_float(v1[j]));
+    }
+  };
+  auto store_d = [&]() {
+#pragma unroll
+    for (int i = 0; i < D_ITEMS; ++i) {
+      const int f = tid + 256 * i;
+      const int pp = f & 63, g = f >> 6;
+      store_pairs(dT + (g * (DOUT_BF16 ? 8 : 4)) * PD + pp * 4, PD, d_reg[i][0], d_reg[i][1], DOUT_BF16);
+    }
+  };
+  auto store_i = [&]() {
+#pragma unroll
+    for (int gi = 0; gi < I_GRPS; ++gi) {
+      const int f = tid + 256 * gi;
       const int g = f >> 6, l = f & 63;
 #pragma unroll
-      for (int rnd = 0; rnd < (IPAIRS + 63) / 64; ++rnd) {
+      for (int rnd = 0; rnd < I_RND; ++rnd) {
         const int q = l + 64 * rnd;
         if (q < IPAIRS) {
           const int row = q / (IWV / 2), pr = q - row * (IWV / 2);
-          const int gy = y0 + row - HALO, gx = x0 + pr * 2 - HALO;
-          const bool rowok = gy >= 0 && gy < p.H;
-          const bool in0 = rowok && gx >= 0 && gx < p.W, in1 = rowok && gx + 1 >= 0 && gx + 1 < p.W;
-          const size_t base = ((size_t)(b * p.H + gy) * p.W + gx) * p.in_stride;     // used only when in0 / in1
-          unsigned char* dst = iT + row * (IROWP * 2) + pr * 4;
-          if (p.in_bf16) {
-            const int c = c0 + g * 8;
-            wgb_bf16x8 v0 = {}, v1 = {};
-            if (c < p.Cin) {                         // Cin % 8 == 0 on this path (host check)
-              if (in0) v0 = *reinterpret_cast<const wgb_bf16x8*>(reinterpret_cast<const __bf16*>(p.in) + base + c);
-              if (in1) v1 = *reinterpret_cast<const wgb_bf16x8*>(reinterpret_cast<const __bf16*>(p.in) + base + p.in_stride + c);
-            }
-            const unsigned short* a = reinterpret_cast<const unsigned short*>(&v0);
-            const unsigned short* e = reinterpret_cast<const unsigned short*>(&v1);
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              *reinterpret_cast<unsigned*>(dst + (g * 8 + j) * PI) = (unsigned)a[j] | ((unsigned)e[j] << 16);
-          } else {
-            const int c = c0 + g * 4;
-            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
-            if (c < p.Cin) {
-              if (in0) v0 = *reinterpret_cast<const f32x4*>(p.in + base + c);
-              if (in1) v1 = *reinterpret_cast<const f32x4*>(p.in + base + p.in_stride + c);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              *reinterpret_cast<unsigned*>(dst + (g * 4 + j) * PI) = pack_bf16_pair(v0[j], v1[j]);
-          }
+          store_pairs(iT + (g * (IN_BF16 ? 8 : 4)) * PI + row * (IROWP * 2) + pr * 4, PI,
+                      i_reg[gi * I_RND + rnd][0], i_reg[gi * I_RND + rnd][1], IN_BF16);
         }
       }
     }
+  };
+
+  // operand that is not prefetched: one (load, load, store) item at a time between the barriers (8 transient VGPRs)
+  auto stage_d_direct = [&](int tile) {
+    int b, y0, x0; tile_origin(tile, b, y0, x0);
+#pragma unroll 1
+    for (int i = 0; i < D_ITEMS; ++i) {
+      const int f = tid + 256 * i;
+      const int pp = f & 63, g = f >> 6;
+      const int gy = y0 + (pp >> 3), gx = x0 + (pp & 7) * 2;
+      const int n = n0 + g * (DOUT_BF16 ? 8 : 4);
+      const bool rowok = gy < p.H && n < p.N;
+      const size_t base = ((size_t)(b * p.H + gy) * p.W + gx) * p.dout_stride + n;
+      const wgb_u32x4 v0 = (rowok && gx < p.W) ? load16(p.dout, base, DOUT_BF16) : zero4;
+      const wgb_u32x4 v1 = (rowok && gx + 1 < p.W) ? load16(p.dout, base + p.dout_stride, DOUT_BF16) : zero4;
+      store_pairs(dT + (g * (DOUT_BF16 ? 8 : 4)) * PD + pp * 4, PD, v0, v1, DOUT_BF16);
+    }
+  };
+  auto stage_i_direct = [&](int tile) {
+    int b, y0, x0; tile_origin(tile, b, y0, x0);
+#pragma unroll 1
+    for (int it = 0; it < I_ITEMS; ++it) {
+      const int gi = it / I_RND, rnd = it - gi * I_RND;
+      const int f = tid + 256 * gi;
+      const int g = f >> 6, q = (f & 63) + 64 * rnd;
+      const int c = c0 + g * (IN_BF16 ? 8 : 4);
+      if (q < IPAIRS) {
+        const int row = q / (IWV / 2), pr = q - row * (IWV / 2);
+        const int gy = y0 + row - HALO, gx = x0 + pr * 2 - HALO;
+        const bool rowok = gy >= 0 && gy < p.H && c < p.Cin;
+        const size_t base = ((size_t)(b * p.H + gy) * p.W + gx) * p.in_stride + c;
+        const wgb_u32x4 v0 = (rowok && gx >= 0 && gx < p.W) ? load16(p.in, base, IN_BF16) : zero4;
+        const wgb_u32x4 v1 = (rowok && gx + 1 >= 0 && gx + 1 < p.W) ? load16(p.in, base + p.in_stride, IN_BF16) : zero4;
+        store_pairs(iT + (g * (IN_BF16 ? 8 : 4)) * PI + row * (IROWP * 2) + pr * 4, PI, v0, v1, IN_BF16);
+      }
+    }
+  };
+
+  if (t_begin < t_end) {
+    if constexpr (PF_D) load_d(t_begin);
+    if constexpr (PF_I) load_i(t_begin);
+  }
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();                              // the previous tile's fragment reads are done
+    if constexpr (PF_D) store_d(); else stage_d_direct(tile);
+    if constexpr (PF_I) store_i(); else stage_i_direct(tile);
     __syncthreads();
+    if (tile + 1 < t_end) {                       // in flight under the MFMAs below
+      if constexpr (PF_D) load_d(tile + 1);
+      if constexpr (PF_I) load_i(tile + 1);
+    }
     // ---- TH k-steps of 16 pixels (one tile row each) -----------------------------------------------------------------
     const unsigned char* arow = dT + (wr * 32 + r) * PD + h * 16;
     const unsigned char* brow = iT + (wc * 32 + r) * PI + h * 16;
@@ -979,11 +1045,16 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradDev& p, const int spl
 
 template <int KS>
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_group_kernel(WgradGroup g) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[64 * WGB_PD + 64 * wgb_pi(KS)];
   const int pi = group_problem(g, blockIdx.x, false);
   const WgradProb& q = g.p[pi];
   const int lb = blockIdx.x - q.block_begin;
   const int split = lb % q.S, nb = (lb / q.S) % q.nblk, cb = lb / (q.S * q.nblk);
-  wgrad_bf16_body<KS>(q.d, split, nb * 64, cb * 64, cb);
+  // operand storage types are per problem (block-uniform): conv2's gradient reads a bf16 hidden tensor and the fp32 tail
+  // gradient, conv1's the fp32 input and the bf16 hidden gradient
+  if (q.d.in_bf16 && !q.d.dout_bf16) wgrad_bf16_body<KS, true, false>(q.d, split, nb * 64, cb * 64, cb, lds);
+  else if (!q.d.in_bf16 && q.d.dout_bf16) wgrad_bf16_body<KS, false, true>(q.d, split, nb * 64, cb * 64, cb, lds);
+  else wgrad_bf16_body<KS, true, true>(q.d, split, nb * 64, cb * 64, cb, lds);
 }
 
 // ---- grouped launch (host) ---------------------------------------------------------------------------------------

@@ -256,7 +256,7 @@ class _GlowFn(torch.autograd.Function):
         s2, keep2 = _subnet_args(block, block.s2, block.split_len1, dev, need_grad, False)
         a = GlowArgs(B=b, H=h, W=w, C=c, ksize=block.ksize, rev=1 if rev else 0, clamp=block.clamp, x=_pv(x),
                      out=_pv(out), dst_map=_pv(dst), logdet=_pv(logdet), s1=s1, s2=s2, saved=_pv(saved),
-                     dtype=1 if block.precision == 'bf16' else 0)
+                     dtype=1 if block.precision == 'bf16' else 0, no_save=0 if need_grad else 1)
         _lib.check(lib.sininn_glow_forward(C.byref(a), ops._stream()))
         if need_grad:
             ctx.block, ctx.rev, ctx.dst = block, rev, dst

@@ -78,6 +78,42 @@ def test_glow_block(ksize, rev, channels, hw):
     assert relerr(back, x) < RTOL
 
 
+@pytest.mark.parametrize('rev', [False, True])
+@pytest.mark.parametrize('channels,hw', [(48, (13, 21)), (192, (6, 18)), (16, (9, 33)), (96, (4, 16))])
+def test_fused_1x1_pair_matches_the_two_launch_path(rev, channels, hw):
+    """1x1 subnets run conv1 -> conv2 (and dgrad2 -> dgrad1) as ONE launch with the hidden tile in LDS (conv_pair_k1.hip);
+    same block, same inputs through the two-launch path: equal up to fp32 summation order, forward and every gradient,
+    at ragged image sizes and all supported channel counts; a no-grad pass (hidden tensor never stored) agrees too."""
+    import archs
+    import sin_inn_amd as S
+    from sin_inn_amd import _lib
+    torch.manual_seed(channels)
+    h, w = hw
+    blk = S.GLOWCouplingBlock([(channels, h, w)], subnet_constructor=archs.subnet_conv_1x1, clamp=1.2)
+    for p in blk.parameters():
+        p.data.mul_(3.0)
+    blk.cuda()
+    x = torch.randn(2, channels, h, w, device='cuda')
+    wgt, ld_w = torch.randn_like(x), torch.randn(2, device='cuda')
+    res = []
+    try:
+        for fused in (1, 0):
+            _lib.lib().sininn_pair_k1_test_hook(fused)
+            blk.zero_grad()
+            xg = x.clone().requires_grad_(True)
+            y = blk([xg], rev=rev)[0]
+            ((y * wgt).sum() + (blk.last_jac * ld_w).sum()).backward()
+            S.modules.join_side_streams()
+            with torch.no_grad():
+                y_ng = blk([x], rev=rev)[0]
+            res.append([y.detach(), blk.last_jac.detach().clone(), xg.grad, y_ng] + [p.grad.clone() for p in blk.parameters()])
+    finally:
+        _lib.lib().sininn_pair_k1_test_hook(1)
+    for a, b in zip(*res):
+        assert relerr(a, b) < 1e-5          # fp32 summation order only (amplified through exp / the inverse's division)
+    assert relerr(res[0][3], res[0][0]) < 1e-5
+
+
 @pytest.mark.parametrize('num_coupling', [1, 2])
 def test_srflow_network_and_gradients(num_coupling):
     import archs

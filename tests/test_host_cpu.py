@@ -22,7 +22,7 @@ def test_abi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(handle, name), f'{name} declared in include/sininn.h but not exported'
     assert declared <= set(_lib.EXPORTED) | {'sininn_conv_args'}
-    assert handle.sininn_version() == 2
+    assert handle.sininn_version() == 3
 
 
 def test_cpu_tensors_are_refused_loudly():
