@@ -123,7 +123,11 @@ class VideoDataset(torch.utils.data.Dataset):
 
     def batch(self, positions):
         """dict(hr=(n,3,H,W), lr=(n,(2w+1)*4,h,w)) for dataset positions, produced on the store's device."""
-        idx = torch.as_tensor([self.frames[int(p)] for p in positions], dtype=torch.int32, device=self.store.device)
+        idx = torch.tensor([self.frames[int(p)] for p in positions], dtype=torch.int32)
+        if self.store.device.type == 'cuda':
+            # pinned + non_blocking: a pageable H2D copy is synchronous, i.e. the host would wait for the previous step's last
+            # kernel on this stream before it may enqueue the next step (the host then never runs ahead of the GPU)
+            idx = idx.pin_memory().to(self.store.device, non_blocking=True)
         hr, lr = sample_windows(self.store.hr, self.store.lr, idx, self.win_size)
         sample = {'hr': hr, 'lr': lr}
         return self.transform(sample) if self.transform else sample
