@@ -147,9 +147,25 @@ class SingleVideoINN(pl.LightningModule):
         self.overlap_passes = True                 # forward / reverse pass on two HIP streams
 
     # ---- training --------------------------------------------------------------------------------
+    # Host run-ahead is bounded to MAX_STEPS_IN_FLIGHT training steps: nothing in a step synchronises host and GPU any
+    # more (frame indices go up pinned + non_blocking), so without this the host would queue steps as fast as Python allows;
+    # every step in flight holds its own saved tensors (28 GB at 720p, -c 12) and the caching allocator then has to grow /
+    # flush (a 10x slowdown was measured at BASELINE configs[4]).  One step of run-ahead is all the GPU needs to never idle;
+    # batches of >= 8 M HR pixels (720p x 16: 170 ms of GPU work against 16 ms of host work per step) get none -- the
+    # second step's saved tensors cost more (allocator growth, +3.5 %) than the ~1 ms start-up gap the run-ahead hides.
+    MAX_STEPS_IN_FLIGHT = 2
+
+    def _throttle(self, hr):
+        ring = self.__dict__.setdefault('_step_events', [])
+        depth = 1 if hr.numel() // hr.shape[1] >= (8 << 20) else self.MAX_STEPS_IN_FLIGHT
+        while len(ring) >= depth:
+            ring.pop(0).synchronize()                 # the step `depth` back has finished
+        return ring
+
     def training_step(self, batch, batch_idx):
         o = self.opt
         optim = self.optimizers()
+        ring = self._throttle(batch[0]['hr']) if batch[0]['hr'].is_cuda else None
         optim.zero_grad()
         hr, lr = batch[0]['hr'], batch[0]['lr']
         b, _, h, w = lr.shape
@@ -212,6 +228,10 @@ class SingleVideoINN(pl.LightningModule):
 
         optim.step()
         self.log('train', (fwd_loss.detach() + bwd_loss.detach().to(fwd_loss.device) + tcr_loss))
+        if ring is not None:
+            ev = torch.cuda.Event()
+            ev.record()                                # on the main stream, behind the optimiser step
+            ring.append(ev)
 
     def validation_step(self, batch, batch_idx):
         o = self.opt
