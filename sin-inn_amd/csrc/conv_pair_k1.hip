@@ -75,11 +75,17 @@ __global__ __launch_bounds__(256) void conv_pair_k1_kernel(PairDev q) {
 
   // ---- stage 1: hidden[P][256] = in[P][K1] . Wa[256][K1]^T ; wave w -> columns 64 w .. 64 w + 63 -----------------------
   {
-    f32x4 acc[MT][4];
+    // an accumulator should come round again no sooner than every ~16 MFMAs (tools/mfma_peak.hip: 4 / 8 / 16 independent
+    // accumulators -> 44.7 / 36.6 / 32.4 clocks per v_mfma_f32_16x16x4_f32): with few tiles per wave the k-steps of a
+    // 16-channel step alternate between KS accumulator sets that are summed at the end
+    constexpr int KS1 = (MT * 4 >= 16) ? 1 : 2;
+    f32x4 accs[KS1][MT][4];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int k = 0; k < KS1; ++k)
 #pragma unroll
-      for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) accs[k][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* wrow = pa.w + (size_t)(wave * 64 + li) * K1 + 4 * kq;
     const int nsteps = K1R / 16;
     auto load_b = [&](int s, f32x4 (&bf)[4]) {
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(256) void conv_pair_k1_kernel(PairDev q) {
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int n = 0; n < 4; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][j], bf[n][j], acc[m][n], 0, 0, 0);
+            accs[j % KS1][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][j], bf[n][j], accs[j % KS1][m][n], 0, 0, 0);
 #pragma unroll
       for (int n = 0; n < 4; ++n) bf[n] = bn[n];
     }
@@ -113,7 +119,12 @@ __global__ __launch_bounds__(256) void conv_pair_k1_kernel(PairDev q) {
 #pragma unroll
       for (int n = 0; n < 4; ++n)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hs[(m * 16 + 4 * kq + r) * PK_HS + wave * 64 + n * 16 + li] = acc[m][n][r];
+        for (int r = 0; r < 4; ++r) {
+          float v = accs[0][m][n][r];
+#pragma unroll
+          for (int k = 1; k < KS1; ++k) v += accs[k][m][n][r];
+          hs[(m * 16 + 4 * kq + r) * PK_HS + wave * 64 + n * 16 + li] = v;
+        }
   }
   __syncthreads();
   mark(1);
@@ -159,11 +170,14 @@ __global__ __launch_bounds__(256) void conv_pair_k1_kernel(PairDev q) {
   constexpr int WM = MSPLIT ? MT : 1, WN = 4 / WM;
   static_assert(!MSPLIT || MT == 4 || MT == 2, "row-tile split needs 2 or 4 row tiles");
   constexpr int NI = (NT2 + WN - 1) / WN, MI = MSPLIT ? 1 : MT, DEPTH = MSPLIT ? 2 : 1;
-  f32x4 acc2[NI][MI];
+  constexpr int KS2 = (NI * MI <= 4) ? 4 : ((NI * MI <= 8) ? 2 : 1);     // accumulator sets, see stage 1
+  f32x4 acc2[KS2][NI][MI];
 #pragma unroll
-  for (int i = 0; i < NI; ++i)
+  for (int k = 0; k < KS2; ++k)
 #pragma unroll
-    for (int m = 0; m < MI; ++m) acc2[i][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int m = 0; m < MI; ++m) acc2[k][i][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
   auto nt_of = [&](int i) -> int { return (wave / WM) + WN * i; };
   auto mt_of = [&](int m) -> int { return MSPLIT ? (wave % WM) : m; };
   {
@@ -192,7 +206,7 @@ __global__ __launch_bounds__(256) void conv_pair_k1_kernel(PairDev q) {
         for (int i = 0; i < NI; ++i)
 #pragma unroll
           for (int m = 0; m < MI; ++m)
-            acc2[i][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][j], bf[s % (DEPTH + 1)][i][j], acc2[i][m], 0, 0, 0);
+            acc2[j % KS2][i][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][j], bf[s % (DEPTH + 1)][i][j], acc2[j % KS2][i][m], 0, 0, 0);
     }
   }
   __syncthreads();                                   // every wave is done reading the hidden tile
@@ -206,7 +220,12 @@ __global__ __launch_bounds__(256) void conv_pair_k1_kernel(PairDev q) {
 #pragma unroll
       for (int m = 0; m < MI; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) T[(mt_of(m) * 16 + 4 * kq + r) * TS + nt * 16 + li] = acc2[i][m][r];
+        for (int r = 0; r < 4; ++r) {
+          float v = acc2[0][i][m][r];
+#pragma unroll
+          for (int k = 1; k < KS2; ++k) v += acc2[k][i][m][r];
+          T[(mt_of(m) * 16 + 4 * kq + r) * TS + nt * 16 + li] = v;
+        }
     }
   }
   __syncthreads();

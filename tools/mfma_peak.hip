@@ -2,6 +2,9 @@
 //   variant 0: v_mfma_f32_16x16x4_f32 from registers, NACC independent accumulators, W waves per SIMD
 //   variant 1: same + one ds_read_b64 pair per 2 MFMAs (operands re-read from LDS)
 //   variant 2: v_mfma_f32_32x32x2_f32 from registers
+//   variant 3 / 4: 16x16x4 with the A and B operand taken from component j / j and j + 1 of two float4 register quads that
+//                  change on every instruction (the pattern of a GEMM loop fed by 16-byte fragment loads): same / different
+//                  register index modulo 4 for A and B
 // Reports TFLOP/s and the in-kernel clock (s_memtime / s_memrealtime).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -30,7 +33,13 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, unsigned long lo
     for (int j = 0; j < NACC; ++j) acc[j] = (f32x4){0, 0, 0, 0};
     const float2* lp = reinterpret_cast<const float2*>(lds) + (threadIdx.x & 63) * 9;
     for (int it = 0; it < iters; ++it) {
-      if constexpr (VAR == 1) {
+      if constexpr (VAR == 3 || VAR == 4) {
+        const f32x4 fa = *reinterpret_cast<const f32x4*>(lds + (threadIdx.x & 63) * 4 + ((it & 3) << 8));
+        const f32x4 fb = *reinterpret_cast<const f32x4*>(lds + 2048 + (threadIdx.x & 63) * 4 + ((it & 3) << 8));
+#pragma unroll
+        for (int j = 0; j < NACC; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j & 3], fb[(j + (VAR == 4 ? 1 : 0)) & 3], acc[j], 0, 0, 0);
+      } else if constexpr (VAR == 1) {
 #pragma unroll
         for (int j = 0; j < NACC; j += 2) {
           float2 fa = lp[(it * 2 + j) & 255], fb = lp[(it * 2 + j + 1) & 255];
@@ -74,6 +83,10 @@ int main() {
   run<0, 8>("16x16x4 regs, 8 acc", 2, 2048);
   run<1, 8>("16x16x4 + ds_read_b64 per 2 mfma, 8 acc", 1, 2048);
   run<1, 8>("16x16x4 + ds_read_b64 per 2 mfma, 8 acc", 2, 2048);
+  run<3, 16>("16x16x4, A = fa[j], B = fb[j], 16 acc", 1, 2048);
+  run<4, 16>("16x16x4, A = fa[j], B = fb[j+1], 16 acc", 1, 2048);
+  run<3, 4>("16x16x4, A = fa[j], B = fb[j], 4 acc", 1, 2048);
+  run<3, 16>("16x16x4, A = fa[j], B = fb[j], 16 acc", 2, 2048);
   run<2, 4>("32x32x2 regs, 4 acc", 1, 4096);
   run<2, 4>("32x32x2 regs, 4 acc", 2, 4096);
   return 0;
