@@ -150,8 +150,10 @@ int sininn_conv(const sininn_conv_args* args, void* stream);
  * fused coupling-backward epilogues backward).  The hidden tile stays in LDS between the two GEMMs; it is still written to
  * first->out once (training needs it) unless first->out is NULL (no-grad passes: the hidden tensor never reaches HBM;
  * second->in is then ignored).  Same results as sininn_conv(first) followed by sininn_conv(second) up to fp32 summation
- * order.  fp32, pixel-major operands only; sininn_conv_pair_k1_supported returns 1 when the pair's shapes / modes qualify
- * (hidden width 256, first->Cin % 8 == 0 and <= 192, second->Np in {16, 32, 48, 64, 96, 192}). */
+ * order.  Pixel-major operands only; fp32 pairs, or mixed-precision pairs (both convs w_bf16: first fp32 in -> bf16 hidden
+ * tensor, second bf16 hidden tensor -> fp32 epilogue; the hidden values are rounded to bf16 exactly once, as in the two-launch
+ * path).  sininn_conv_pair_k1_supported returns 1 when the pair's shapes / modes qualify (hidden width 256, first->Cin % 8 == 0
+ * and <= 192, second->Np in {16, 32, 48, 64, 96, 192}). */
 int sininn_conv_pair_k1_supported(const sininn_conv_args* first, const sininn_conv_args* second);
 int sininn_conv_pair_k1(const sininn_conv_args* first, const sininn_conv_args* second, void* stream);
 

@@ -18,23 +18,9 @@
 //     ({0-3,12-15,20-27}, ...: MI355X_MICROARCH.md, LDS table) hit 16 distinct 4-bank slots.
 //   * epilogue: accumulators -> fp32 LDS tile T[pixel][BN + 4] -> the shared float4 epilogue of the fp32 kernels
 //     (coupling / add / fused coupling backward), or the bf16-output epilogues here (ReLU -> h, mask -> dh).
-#include "conv_mfma_impl.h"
+#include "conv_bf16_types.h"
 
 namespace sininn {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct ConvDevB {
-  ConvDev c;                 // fp32-side description (epilogue operands, shapes); c.in / c.w / c.out are unused when the
-  const void* in;            // typed pointers below replace them
-  const __bf16* w;           // [taps][Np][Kp] bf16
-  __bf16* out_b;             // bf16 output (RELU / LINEAR / MASK modes with out_bf16)
-  const __bf16* mask_b;      // bf16 ReLU mask source (MASK mode with out_bf16)
-  int Kp;                    // channels of the weight pack (Cin rounded up to a multiple of 16)
-  int in_bf16, out_bf16;
-};
 
 template <int CK> struct BfGeom {
   static constexpr int PIXB = CK * 2 + 16;                               // bytes per staged pixel / weight column
@@ -341,7 +327,8 @@ static int launch_ks(const ConvDevB& q, hipStream_t st) {
 }
 
 // a->w: bf16 pack [taps][Np][Kp], Kp = Cin rounded up to 16; a->in: fp32 or (in_bf16) bf16; a->out: fp32 or (out_bf16) bf16
-int conv_bf16_launch(const sininn_conv_args* a, hipStream_t st) {
+// argument validation + device-side descriptor (shared by conv_bf16_launch and the fused 1x1 pair, conv_pair_bf16.hip)
+int conv_bf16_prepare(const sininn_conv_args* a, ConvDevB& q) {
   SININN_CHECK(a->ksize == 1 || a->ksize == 3, "conv_bf16: ksize %d not in {1,3}", a->ksize);
   SININN_CHECK(a->Cin > 0 && a->Cin % 8 == 0, "conv_bf16: Cin=%d must be a positive multiple of 8", a->Cin);
   SININN_CHECK(a->Np > 0 && a->Np % 16 == 0, "conv_bf16: Np=%d must be a positive multiple of 16", a->Np);
@@ -376,7 +363,7 @@ int conv_bf16_launch(const sininn_conv_args* a, hipStream_t st) {
     }
   }
   SININN_CHECK(!a->bias || aligned16(a->bias), "conv_bf16: bias must be 16-byte aligned");
-  ConvDevB q = {};
+  q = ConvDevB{};
   ConvDev& d = q.c;
   d.in = nullptr; d.in_stride = a->in_stride; d.Cin = a->Cin;
   d.w = nullptr; d.bias = a->bias; d.Np = a->Np;
@@ -394,7 +381,12 @@ int conv_bf16_launch(const sininn_conv_args* a, hipStream_t st) {
   q.mask_b = reinterpret_cast<const __bf16*>(a->mask);
   q.Kp = (a->Cin + 15) / 16 * 16;
   q.in_bf16 = a->in_bf16; q.out_bf16 = a->out_bf16;
+  return 0;
+}
 
+int conv_bf16_launch(const sininn_conv_args* a, hipStream_t st) {
+  ConvDevB q;
+  if (int rc = conv_bf16_prepare(a, q)) return rc;
   return a->ksize == 3 ? launch_ks<3>(q, st) : launch_ks<1>(q, st);
 }
 

@@ -23,6 +23,8 @@
 namespace sininn {
 
 int conv_prepare(const sininn_conv_args* a, ConvDev& d);
+int conv_pair_bf16_supported(const sininn_conv_args* f, const sininn_conv_args* s);      // conv_pair_bf16.hip
+int conv_pair_bf16_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st);
 
 struct PairDev { ConvDev a, b; };
 
@@ -267,6 +269,7 @@ void conv_pair_k1_enable(int on) { g_pair_enabled = on != 0; }     // test hook:
 // 1 when the pair (first: RELU or MASK into the 256-channel hidden tensor; second: any mode reading it) can run fused
 int conv_pair_k1_supported(const sininn_conv_args* f, const sininn_conv_args* s) {
   if (!g_pair_enabled || !f || !s) return 0;
+  if (f->w_bf16 || s->w_bf16) return conv_pair_bf16_supported(f, s);          // mixed-precision twin
   if (f->ksize != 1 || s->ksize != 1 || f->w_bf16 || s->w_bf16 || f->winograd || s->winograd) return 0;
   if (f->in_bf16 || f->out_bf16 || f->mask_bf16 || s->in_bf16 || s->out_bf16 || s->mask_bf16) return 0;
   if (f->in_group_stride > 0 || f->out_group_stride > 0 || f->mask_group_stride > 0 || s->in_group_stride > 0 ||
@@ -284,6 +287,7 @@ int conv_pair_k1_supported(const sininn_conv_args* f, const sininn_conv_args* s)
 
 int conv_pair_k1_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st) {
   SININN_CHECK(conv_pair_k1_supported(f, s), "conv_pair: unsupported pair (check sininn_conv_pair_k1_supported first)");
+  if (f->w_bf16) return conv_pair_bf16_launch(f, s, st);
   PairDev q;
   sininn_conv_args fa = *f;
   alignas(16) float dummy_out[4] = {0.f, 0.f, 0.f, 0.f};   // conv_prepare insists on an output pointer; NULL = "do not store h"
