@@ -412,3 +412,25 @@ def test_training_is_bitwise_reproducible(arch):
     assert torch.equal(p1, p2)
     # the logged loss scalar is reduced with float atomics (order varies); the gradients do not depend on it
     assert abs(l1 - l2) <= 1e-5 * abs(l1)
+
+
+def test_training_steps_run_ahead_is_bounded():
+    """No call inside a training step synchronises host and GPU (the loader uploads indices pinned + non_blocking), so the
+    step itself bounds how far the host may run ahead: at most MAX_STEPS_IN_FLIGHT end-of-step events are outstanding --
+    every step in flight keeps its saved tensors alive."""
+    import lit_wrapper
+    from data import FrameStore
+    from sin_inn_amd.functional import sample_windows
+    torch.manual_seed(0)
+    opt = make_opt(num_coupling=1)
+    model = lit_wrapper.SingleVideoINN(3, 32, 32, opt).cuda()
+    model.attach_optimizer()
+    store = FrameStore.synthetic(8, 32, 32).to('cuda')
+    idx = torch.tensor([2, 3], dtype=torch.int32).pin_memory().to('cuda', non_blocking=True)
+    for _ in range(6):
+        hr, lr = sample_windows(store.hr, store.lr, idx, 1)
+        model.training_step([{'hr': hr, 'lr': lr}, {'hr': hr, 'lr': lr}], 0)
+        assert len(model._step_events) <= model.MAX_STEPS_IN_FLIGHT
+    torch.cuda.synchronize()
+    assert all(e.query() for e in model._step_events)
+    assert torch.isfinite(model._logged['train'])
