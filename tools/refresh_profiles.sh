@@ -29,7 +29,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/write" -- python3 bench.py
 python tools/pmc_traffic.py "$O/fetch" "$O/write" "wino_kernel<2, 8, 2>" 131072 > "$O/traffic_dominant.json"
 rm -rf "$O/fetch" "$O/write"
 
-step "bench lines"
+step "bench lines (configs[3] / [4] are better re-measured in a call of their own: right after the profiler passes they read 8-25 % slow)"
 python bench.py --steps 20 --warmup 5 > "$O/${TAG}_bench_cfg1.json" 2> "$O/bench_cfg1.err" || exit 1
 python bench.py --config 3 --steps 10 > "$O/${TAG}_bench_cfg3.json" 2> "$O/bench_cfg3.err" || exit 1
 python bench.py --config 4 --steps 5 > "$O/${TAG}_bench_cfg4.json" 2> "$O/bench_cfg4.err" || exit 1
