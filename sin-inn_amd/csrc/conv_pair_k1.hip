@@ -77,9 +77,9 @@ __global__ __launch_bounds__(256) void conv_pair_k1_kernel(PairDev q) {
 
   // ---- stage 1: hidden[P][256] = in[P][K1] . Wa[256][K1]^T ; wave w -> columns 64 w .. 64 w + 63 -----------------------
   {
-    // an accumulator should come round again no sooner than every ~16 MFMAs (tools/mfma_peak.hip: 4 / 8 / 16 independent
-    // accumulators -> 44.7 / 36.6 / 32.4 clocks per v_mfma_f32_16x16x4_f32): with few tiles per wave the k-steps of a
-    // 16-channel step alternate between KS accumulator sets that are summed at the end
+    // with few tiles per wave an accumulator would come round again after 2-8 MFMAs (40-clock dependent latency against a
+    // 32-clock issue interval, plus the waits in between): the k-steps of a 16-channel step alternate between KS accumulator
+    // sets that are summed at the end (per-block GEMM time -25 % at level 0)
     constexpr int KS1 = (MT * 4 >= 16) ? 1 : 2;
     f32x4 accs[KS1][MT][4];
 #pragma unroll
