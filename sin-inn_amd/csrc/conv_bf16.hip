@@ -6,9 +6,10 @@
 //     executor's own kernels touch and which therefore live in HBM as bf16: half the bytes of the 67..600 MB round
 //     trip); weights are packed bf16 [tap][column][K] once per optimiser step; accumulation and every epilogue
 //     (bias, ReLU, affine coupling + log-det, ReLU mask, skip-gradient add) run in fp32.
-//   * block = 16 x 16 output pixels x 64 columns, four waves as 2 (pixel rows) x 2 (columns); a wave owns four
-//     accumulator tiles of 32 x 32 (lane = column, 16 registers = pixel rows), i.e. 128 pixels x 32 columns: the weights
-//     staged per chunk (37 KB, the larger part of the staging traffic) serve 256 pixels, and 5 LDS fragment reads feed 4 MFMAs.
+//   * block = 16 x 16 output pixels x 64 columns (8 x 16 for 1x1); a 3x3 wave owns two 32-pixel row tiles x both 32-column
+//     tiles (four accumulator tiles of 32 x 32, lane = column, 16 registers = pixel rows): the weights staged per chunk (37 KB,
+//     the larger part of the staging traffic) serve 256 pixels and 4 LDS fragment reads feed 4 MFMAs.  (Four row tiles x one
+//     column tile per wave -- 5 reads per 4 MFMAs -- measured the same: the loop is not bound by the fragment reads.)
 //   * K loop = channel chunks (CK = 32 or 16): the halo tile of a chunk AND the weights of all nine taps of that chunk are
 //     staged together (one LDS buffer, two barriers per chunk, 36 MFMAs per wave between them; the next chunk's global
 //     loads are in flight under the MFMAs, and the CU's second block computes while this one stages); shifted LDS
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvDevB q) {
   const ConvDev& p = q.c;
   // 3x3: 16 x 16 output pixels per block (the nine taps' weights staged per chunk then serve 256 pixels), 4 row tiles of two
   // pixel rows per wave; 1x1: 8 x 16 pixels (HBM-bound on the hidden tensor: more, smaller blocks stream better)
-  constexpr int TH = (KS == 3) ? 16 : 8, MT = TH / 4;
+  constexpr int TH = (KS == 3) ? 16 : 8;
   constexpr int HALO = KS / 2, IW = 16 + 2 * HALO, IH = TH + 2 * HALO, NPIX_IN = IH * IW, TAPS = KS * KS;
   constexpr int BN = 64;
   constexpr int PIXB = BfGeom<CK>::PIXB, PITCH = BfGeom<CK>::pitch(IW);
@@ -107,7 +108,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvDevB q) {
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  const int wm = wave >> 1, wn = wave & 1;
+  // wave tile: 3x3 -> each wave two row tiles x BOTH 32-column tiles (4 fragment reads per 4 MFMAs instead of 5: the MFMA loop
+  // is LDS-bound); 1x1 (four row tiles per block) -> 2 x 2 waves, two row tiles x one column tile each
+  constexpr int WN = (KS == 3) ? 1 : 2, WM = 4 / WN, MW = (TH / 2) / WM, NW = 2 / WN;   // row / column tiles per wave
+  const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
 
   int bid = blockIdx.x;
@@ -210,15 +214,17 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvDevB q) {
         *reinterpret_cast<bf16x8*>(w_lds + w_l0 + i * W_LSTEP) = w_reg[i];
   };
 
-  f32x16 acc[MT];
+  f32x16 acc[MW][NW];
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+  for (int m = 0; m < MW; ++m)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+    for (int n = 0; n < NW; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
 
   // A fragment of lane (r, h) for row tile m: pixel (row 8 wm + 2 m + (r >> 4), column r & 15), channels 8 h .. 8 h + 7
-  const int a_off0 = (2 * MT * wm + (r >> 4)) * PITCH + (r & 15) * PIXB + h * 16;
-  const int b_off = (wn * 32 + r) * PIXB + h * 16;
+  const int a_off0 = (2 * MW * wm + (r >> 4)) * PITCH + (r & 15) * PIXB + h * 16;
+  const int b_off = (wn * NW * 32 + r) * PIXB + h * 16;
 
   // phase stamps (diagnostic, sininn_conv_args.stamp -> 8 words: barrier A, staging, barrier B, load issue, MFMA loop,
   // epilogue, total, blocks): wave 0 / lane 0 of every block adds its shader-clock deltas
@@ -247,12 +253,15 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvDevB q) {
       const unsigned char* B = w_lds + tap * W_TAP + b_off;
 #pragma unroll
       for (int ks = 0; ks < CK / 16; ++ks) {
-        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(B + ks * 32);
-        bf16x8 af[MT];
+        bf16x8 bfr[NW], af[MW];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const bf16x8*>(A + a_off0 + m * 2 * PITCH + ks * 32);
+        for (int n = 0; n < NW; ++n) bfr[n] = *reinterpret_cast<const bf16x8*>(B + n * 32 * PIXB + ks * 32);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], b0, acc[m], 0, 0, 0);
+        for (int m = 0; m < MW; ++m) af[m] = *reinterpret_cast<const bf16x8*>(A + a_off0 + m * 2 * PITCH + ks * 32);
+#pragma unroll
+        for (int m = 0; m < MW; ++m)
+#pragma unroll
+          for (int n = 0; n < NW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
       }
     }
     mark(4);
@@ -263,13 +272,15 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvDevB q) {
   constexpr int TS = BN + 4;
   float* const T = reinterpret_cast<float*>(smem_b);
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+  for (int m = 0; m < MW; ++m)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-      const int pl = wm * (MT * 32) + m * 32 + row;
-      T[pl * TS + wn * 32 + r] = acc[m][e];
-    }
+    for (int n = 0; n < NW; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int pl = wm * (MW * 32) + m * 32 + row;
+        T[pl * TS + (wn * NW + n) * 32 + r] = acc[m][n][e];
+      }
   __syncthreads();
   if (q.out_bf16) {
     epilogue_bf16<BN, TH * 16>(q, T, b, y0, x0, n0, tid);
