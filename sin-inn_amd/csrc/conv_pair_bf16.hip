@@ -22,7 +22,7 @@ constexpr int PB_HID = 256;
 constexpr int PB_HSB = PB_HID * 2 + 16;      // bytes per pixel row of the hidden tile: 16 (mod 256) -> conflict-free ds_read_b128
 
 template <int BN2, int HT>
-__global__ __launch_bounds__(256) void conv_pair_bf16_kernel(PairDevB q) {
+__global__ __launch_bounds__(256, 4) void conv_pair_bf16_kernel(PairDevB q) {
   constexpr int TH = 4, P = 64, MT = 2;
   constexpr int NT2 = (BN2 + 31) / 32, TILES2 = MT * NT2, NI = (TILES2 + 3) / 4, TS = BN2 + 4;
   const ConvDev& pa = q.a.c;
