@@ -85,14 +85,14 @@ __device__ __forceinline__ void epilogue_bf16(const ConvDevB& q, const float* T,
   }
 }
 
-template <int KS, int CK, int HT, bool IN_BF16>
+template <int KS, int CK, int HT, bool IN_BF16, int BN = 64>
 __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvDevB q) {
   const ConvDev& p = q.c;
   // 3x3: 16 x 16 output pixels per block (the nine taps' weights staged per chunk then serve 256 pixels), 4 row tiles of two
   // pixel rows per wave; 1x1: 8 x 16 pixels (HBM-bound on the hidden tensor: more, smaller blocks stream better)
   constexpr int TH = (KS == 3) ? 16 : 8;
   constexpr int HALO = KS / 2, IW = 16 + 2 * HALO, IH = TH + 2 * HALO, NPIX_IN = IH * IW, TAPS = KS * KS;
-  constexpr int BN = 64;
+  static_assert(BN == 64 || (BN == 32 && KS == 3), "32-column blocks: 3x3 convs with at most 32 packed columns (the level-0 data gradient of conv1)");
   constexpr int PIXB = BfGeom<CK>::PIXB, PITCH = BfGeom<CK>::pitch(IW);
   constexpr int IN_BYTES = IH * PITCH, W_TAP = BN * PIXB;
   // staging work items: input = (pixel, 4 fp32 channels -> 8 bytes) or (pixel, 8 bf16 channels -> 16 bytes)
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvDevB q) {
   const int wave = tid >> 6, lane = tid & 63;
   // wave tile: 3x3 -> each wave two row tiles x BOTH 32-column tiles (4 fragment reads per 4 MFMAs instead of 5: the MFMA loop
   // is LDS-bound); 1x1 (four row tiles per block) -> 2 x 2 waves, two row tiles x one column tile each
-  constexpr int WN = (KS == 3) ? 1 : 2, WM = 4 / WN, MW = (TH / 2) / WM, NW = 2 / WN;   // row / column tiles per wave
+  constexpr int WN = (KS == 3) ? 1 : 2, WM = 4 / WN, MW = (TH / 2) / WM, NW = (BN / 32) / WN;   // row / column tiles per wave
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
 
@@ -297,16 +297,16 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvDevB q) {
   }
 }
 
-template <int KS, int CK, int HT, bool IN_BF16>
+template <int KS, int CK, int HT, bool IN_BF16, int BN = 64>
 static int launch_one(const ConvDevB& q, hipStream_t st) {
   constexpr int TH = (KS == 3) ? 16 : 8;
-  constexpr int HALO = KS / 2, IW = 16 + 2 * HALO, IH = TH + 2 * HALO, BN = 64, TAPS = KS * KS;
+  constexpr int HALO = KS / 2, IW = 16 + 2 * HALO, IH = TH + 2 * HALO, TAPS = KS * KS;
   constexpr size_t lds_main = (size_t)IH * BfGeom<CK>::pitch(IW) + (size_t)TAPS * BN * BfGeom<CK>::PIXB;
   constexpr size_t lds_epi = (size_t)TH * 16 * (BN + 4) * sizeof(float);
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   static_assert(lds <= 80 * 1024, "two blocks per CU must fit");
   static_assert(CK != 16 || KS != 3 || lds_main <= 53 * 1024, "CK 16: three blocks per CU by the main-loop footprint");
-  auto k = conv_bf16_kernel<KS, CK, HT, IN_BF16>;
+  auto k = conv_bf16_kernel<KS, CK, HT, IN_BF16, BN>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { set_error("conv_bf16: cannot raise LDS limit to %zu", lds); return 1; }
   dim3 grid(q.c.tiles_x * q.c.tiles_y * q.c.B, (q.c.Np + BN - 1) / BN);
@@ -318,6 +318,11 @@ static int launch_one(const ConvDevB& q, hipStream_t st) {
 template <int KS, int CK>
 static int launch_ht(const ConvDevB& q, hipStream_t st) {
   const bool ht16 = q.c.col_tile == 32;            // coupling interleave half-width (irrelevant for the other modes)
+  if constexpr (KS == 3 && CK == 32) {
+    // at most 32 packed columns (level-0 data gradient of conv1, N = 24): 32-column blocks -- half the weight staging and
+    // MFMAs of a 64-column block that is 62 % padding, 46 KB of LDS (three blocks per CU)
+    if (q.in_bf16 && q.c.Np <= 32 && !ht16) return launch_one<KS, CK, 8, true, 32>(q, st);
+  }
   if (q.in_bf16) return ht16 ? launch_one<KS, CK, 16, true>(q, st) : launch_one<KS, CK, 8, true>(q, st);
   // fp32 inputs only feed the bf16-output convs of the path (cond -> h, dr -> dh): the coupling half-width is irrelevant
   SININN_CHECK(q.out_bf16, "conv_bf16: an fp32-input conv must have a bf16 output");
