@@ -176,27 +176,21 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvDevB q) {
     }
   };
   auto store_chunk = [&](int chunk) {
+    // fp32 inputs (cond, dr: at most six chunks) are not prefetched across the MFMA loop -- eleven float4 per thread would
+    // push the kernel into scratch; they are loaded, rounded and stored here while the CU's other block computes.  All
+    // global loads of the chunk are ISSUED first, inputs then weights (returns are in order: the inputs can be converted
+    // and stored while the weights are still in flight); waiting for each group in turn cost two exposed round trips per
+    // chunk, 46-61 % of the block time of the small-K convs that produce the hidden tensor (tools/bf16_phases.py --hidden-out)
+    f32x4 in_raw[IN_BF16 ? 1 : IN_ITEMS];
     if constexpr (!IN_BF16) {
-      // fp32 inputs (cond, dr: at most six chunks) are not prefetched through registers -- eleven float4 per thread would
-      // push the kernel into scratch; they are loaded, rounded and stored here while the CU's other block computes
 #pragma unroll
       for (int i = 0; i < IN_ITEMS; ++i) {
         const int part = (tid + 256 * i) % IN_PER_PIX;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        in_raw[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int go = in_offset(i);
         const bool live = go >= 0 && chunk * CK + part * 4 < p.Cin;             // Cin % 4 == 0 (host check)
-        if (live) v = *reinterpret_cast<const f32x4*>(static_cast<const float*>(q.in) + go + chunk * CK);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) in_reg[i][j] = (__bf16)v[j];
+        if (live) in_raw[i] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(q.in) + go + chunk * CK);
       }
-    }
-#pragma unroll
-    for (int i = 0; i < IN_ITEMS; ++i) {
-      const int f = tid + 256 * i;
-      const int pix = f / IN_PER_PIX, part = f - pix * IN_PER_PIX;
-      const int py = pix / IW, px = pix - py * IW;
-      if (pix < NPIX_IN)
-        *reinterpret_cast<in_reg_t*>(in_lds + py * PITCH + px * PIXB + part * (IN_BF16 ? 16 : 8)) = in_reg[i];
     }
     if constexpr (!W_PREFETCH) {
       // 3x3: the nine taps' weights (36 VGPRs per thread) are NOT held across the MFMA loop -- with them the kernel sat at
@@ -207,6 +201,20 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvDevB q) {
         bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
         w_reg[i] = w_live(i) ? *reinterpret_cast<const bf16x8*>(q.w + w_g0 + i * w_gstep + chunk * CK) : z;
       }
+    }
+    if constexpr (!IN_BF16) {
+#pragma unroll
+      for (int i = 0; i < IN_ITEMS; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) in_reg[i][j] = (__bf16)in_raw[i][j];
+    }
+#pragma unroll
+    for (int i = 0; i < IN_ITEMS; ++i) {
+      const int f = tid + 256 * i;
+      const int pix = f / IN_PER_PIX, part = f - pix * IN_PER_PIX;
+      const int py = pix / IW, px = pix - py * IW;
+      if (pix < NPIX_IN)
+        *reinterpret_cast<in_reg_t*>(in_lds + py * PITCH + px * PIXB + part * (IN_BF16 ? 16 : 8)) = in_reg[i];
     }
 #pragma unroll
     for (int i = 0; i < W_ITEMS; ++i)

@@ -7,21 +7,34 @@ sys.path.insert(0, ROOT)
 import sin_inn_amd
 from sin_inn_amd import ops, _lib
 
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument('--cin', type=int, default=256)
+ap.add_argument('--n', type=int, default=64)
+ap.add_argument('--hidden-out', action='store_true', help='the conv1 / dgrad2 shape: fp32 input, ReLU, bf16 output (the hidden tensor)')
+args = ap.parse_args()
 dev = torch.device('cuda')
-b, h, w, cin, n = 16, 128, 128, 256, 64
+b, h, w, cin, n = 16, 128, 128, args.cin, args.n
 torch.manual_seed(0)
 conv = torch.nn.Conv2d(cin, n, 3, padding=1).cuda()
 wf, bfw, wd = ops.pack_conv_bf16(conv.weight.detach().contiguous(), conv.bias.detach().contiguous(), None, False)
-x = torch.randn(b, h, w, cin, device=dev).to(torch.bfloat16)
-out = torch.empty((b, h, w, n), device=dev)
+x = torch.randn(b, h, w, cin, device=dev)
+if not args.hidden_out:
+    x = x.to(torch.bfloat16)
+out = torch.empty((b, h, w, n), device=dev, dtype=torch.bfloat16 if args.hidden_out else torch.float32)
 names = ['barrier A', 'staging (store_chunk)', 'barrier B', 'global load issue', 'MFMA loop', 'epilogue']
 for rep in range(3):
     st = torch.zeros(8, dtype=torch.int64, device=dev)
     t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
     t0.record()
-    ops.conv(in_=ops.ptr(x, dtype=torch.bfloat16), in_stride=cin, Cin=cin, w=ops.ptr(wf, dtype=torch.bfloat16), bias=ops.ptr(bfw),
-             Np=n, B=b, H=h, W=w, ksize=3, mode=_lib.CONV_LINEAR, out=ops.ptr(out), out_stride=n, N=n, w_bf16=1, in_bf16=1,
-             stamp=st.data_ptr() if rep == 2 else None)
+    if args.hidden_out:
+        ops.conv(in_=ops.ptr(x), in_stride=cin, Cin=cin, w=ops.ptr(wf, dtype=torch.bfloat16), bias=ops.ptr(bfw),
+                 Np=n, B=b, H=h, W=w, ksize=3, mode=_lib.CONV_RELU, out=ops.ptr(out, dtype=torch.bfloat16), out_stride=n, N=n, w_bf16=1,
+                 in_bf16=0, out_bf16=1, stamp=st.data_ptr() if rep == 2 else None)
+    else:
+        ops.conv(in_=ops.ptr(x, dtype=torch.bfloat16), in_stride=cin, Cin=cin, w=ops.ptr(wf, dtype=torch.bfloat16), bias=ops.ptr(bfw),
+                 Np=n, B=b, H=h, W=w, ksize=3, mode=_lib.CONV_LINEAR, out=ops.ptr(out), out_stride=n, N=n, w_bf16=1, in_bf16=1,
+                 stamp=st.data_ptr() if rep == 2 else None)
     t1.record(); torch.cuda.synchronize()
     print(f'rep {rep}: {t0.elapsed_time(t1) * 1e3:.1f} us', 2.0 * b * h * w * 9 * cin * n / (t0.elapsed_time(t1) * 1e-3) / 1e12, 'TF/s')
 s = st.cpu().tolist()
