@@ -497,3 +497,57 @@ def test_conv_kernels_at_baseline_config_shapes(env, cin, n, hw):
         gw2, gb2 = torch.zeros_like(gw), torch.zeros_like(gb)
         ops.wgrad_group([(xg, 0, cin, cin, gg, 0, n, n, gw2, gb2)], 16, h, w, ksize)
         assert relerr(gw2, conv.weight.grad) < RTOL and relerr(gb2, conv.bias.grad) < RTOL
+
+
+# ---------------------------------------------------------------------------------------------------
+# fused 1x1 conv pair through the C ABI (sininn_conv_pair_k1) against two sininn_conv launches on the same packs
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('co,hw', [(24, (13, 21)), (96, (6, 18)), (8, (9, 33))])
+def test_conv_pair_c_abi_matches_two_launches(env, co, hw):
+    import ctypes as C
+    S, O, dev = env
+    from sin_inn_amd import _lib, ops
+    lib = _lib.lib()
+    torch.manual_seed(co)
+    b, (h, w) = 2, hw
+    c, m = 2 * co, 2 * hw[0] * hw[1]
+    x = torch.randn(m, c, device=dev)
+    w1 = torch.randn(256 * co, device=dev) * 0.2; b1 = torch.randn(256, device=dev) * 0.1
+    w2 = torch.randn(2 * co * 256, device=dev) * 0.05; b2 = torch.randn(2 * co, device=dev) * 0.1
+
+    def args(**kw):
+        a = _lib.ConvArgs()
+        for k, v in kw.items():
+            setattr(a, 'inp' if k == 'in_' else k, v)
+        return a
+
+    def run(fused, store_hidden=True):
+        hid = torch.zeros(m, 256, device=dev); out = torch.zeros(m, c, device=dev)
+        sb = torch.zeros(m, co, device=dev); ld = torch.zeros(b, device=dev)
+        common = dict(B=b, H=h, W=w, ksize=1)
+        f = args(in_=ops.ptr(x, co), in_stride=c, Cin=co, w=ops.ptr(w1), bias=ops.ptr(b1), Np=256, mode=_lib.CONV_RELU,
+                 out=ops.ptr(hid) if store_hidden else None, out_stride=256, N=256, **common)
+        s = args(in_=ops.ptr(hid), in_stride=256, Cin=256, w=ops.ptr(w2), bias=ops.ptr(b2), Np=2 * co, mode=_lib.CONV_COUPLE_FWD,
+                 out=ops.ptr(out), out_stride=c, v=ops.ptr(x), v_stride=c, sbuf=ops.ptr(sb), logdet=ops.ptr(ld), Co=co,
+                 clamp=1.2, col_tile=ops.coupling_tile(co), **common)
+        if fused:
+            assert lib.sininn_conv_pair_k1_supported(C.byref(f), C.byref(s)) == 1
+            _lib.check(lib.sininn_conv_pair_k1(C.byref(f), C.byref(s), ops._stream()))
+        else:
+            _lib.check(lib.sininn_conv(C.byref(f), ops._stream()))
+            _lib.check(lib.sininn_conv(C.byref(s), ops._stream()))
+        return hid, out[:, :co], sb, ld
+
+    ref = run(False)
+    got = run(True)
+    for a, r in zip(got, ref):
+        assert relerr(a, r) < 1e-5
+    ng = run(True, store_hidden=False)                     # no-grad form: the hidden tensor never reaches HBM
+    assert float(ng[0].abs().max()) == 0.0
+    for a, r in zip(ng[1:], ref[1:]):
+        assert relerr(a, r) < 1e-5
+    # a 3x3 first conv is not a pair
+    f3 = args(in_=ops.ptr(x, co), in_stride=c, Cin=co, w=ops.ptr(w1), bias=ops.ptr(b1), Np=256, mode=_lib.CONV_RELU, out_stride=256,
+              N=256, B=b, H=h, W=w, ksize=3)
+    s1 = args(in_=ops.ptr(x), in_stride=256, Cin=256, w=ops.ptr(w2), Np=2 * co, mode=_lib.CONV_LINEAR, B=b, H=h, W=w, ksize=1)
+    assert lib.sininn_conv_pair_k1_supported(C.byref(f3), C.byref(s1)) == 0
