@@ -147,7 +147,7 @@ batches = list(L(D41(), 4))
 assert len(batches) == len(L(D41(), 4)) == 6 and [len(b) for b in batches] == [4, 4, 4, 4, 4, 1], batches
 mine = [x for b in batches for x in b]
 assert mine == (D41.frames + D41.frames[:1])[rank::2]
-print('rank', rank, 'ok')
+sys.stdout.write(f'rank {rank} ok\n'); sys.stdout.flush()      # one write: the two ranks share the pipe
 '''
 
 
