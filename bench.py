@@ -148,12 +148,14 @@ def rehearse(args, rank, ws):
         torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
     assert abs(float(flat[0]) - (ws + 1) / 2.0) < 1e-5
     if rank == 0:
-        print(json.dumps({'metric': 'training frames/sec at 256x256 bs=16', 'value': None, 'unit': 'frames/s', 'n_gpus': ws,
+        line = json.dumps({'metric': 'training frames/sec at 256x256 bs=16', 'value': None, 'unit': 'frames/s', 'n_gpus': ws,
                           'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': float(dt) / args.steps * 1e3,
                           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
                           'data': 'synthetic', 'rehearsal': True,
                           'config': {'workload': 'REHEARSAL of the multi-rank plumbing on CPU (gloo): no kernels run',
-                                     'global_batch': ws * args.batch, 'parallelism': f'dp{ws}'}}))
+                                     'global_batch': ws * args.batch, 'parallelism': f'dp{ws}'}})
+        sys.stdout.write(line + '\n')                     # one write: the ranks share the launcher's stdout pipe
+        sys.stdout.flush()
     return 0
 
 
@@ -447,7 +449,8 @@ def main():
         out['cpu_baseline'] = cpu_baseline(args, opt)
     else:
         out['cpu_baseline'] = None
-    print(json.dumps(out))
+    sys.stdout.write(json.dumps(out) + '\n')          # one write: under a launcher the ranks share the stdout pipe
+    sys.stdout.flush()
 
 
 if __name__ == '__main__':
