@@ -9,9 +9,11 @@ fused Adam) on a batch drawn by the frame-window sampler kernel from a synthetic
 resident in HBM.  Workload = BASELINE configs[1]: 8 GLOW blocks (-c 4 per level x 2 levels), 256x256x3 frames,
 batch 16 per GPU, fp32 (f32 MFMA).  N>1: weak scaling, one RCCL all-reduce of the flat gradient per step.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the f32-MFMA implicit-GEMM conv of the 3x3
-coupling subnet, 256 -> 2*Co channels at level 0) timed with HIP events on the launch stream inside the timed
-region; `cpu_baseline` times the CPU oracle (torch-CPU restatement, "port") on a bounded sample.
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fused 3x3 coupling conv 256 -> 2*Co channels +
+affine + log-det at level 0): `achieved` / `frac` count the FLOPs the matrix pipe EXECUTES (Winograd F(2x2,3x3) in fp32:
+2.25x fewer than the direct convolution `achieved_algorithmic` credits) over the kernel's execution window (in-kernel
+stamps == the duration a rocprofv3 kernel trace reports; the HIP-event bracket is given beside it); `cpu_baseline` times
+the CPU oracle (torch-CPU restatement, "port") on every host core the process may use.
 """
 import argparse
 import json
@@ -83,6 +85,23 @@ class KernelTimer:
         return self.total_ms / self.count if self.count else None
 
 
+def host_cores():
+    n = len(os.sched_getaffinity(0))
+    try:                                       # cgroup v2 / v1 CPU quota
+        if os.path.isfile('/sys/fs/cgroup/cpu.max'):
+            q, p = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+            if q != 'max':
+                n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+        elif os.path.isfile('/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return int(os.environ.get('SININN_CPU_THREADS', n))
+
+
 def cpu_baseline(args, opt, seconds_budget=30.0):
     """The CPU oracle's training step on the host cores (same architecture / sizes; bounded sample)."""
     from oracle import sininn_oracle as O
@@ -97,8 +116,9 @@ def cpu_baseline(args, opt, seconds_budget=30.0):
     lr = torch.rand(b, opt.lr_dims, args.height // 8, args.width // 8)
     z = torch.randn(b, opt.z_dims, args.height // 8, args.width // 8)
     lam = dict(fwd_rec=1.0, fwd_mmd=0.0, latent_nll=0.0, bwd_rec=1.0, bwd_mmd=0.0)
-    # host cores actually available to this process (the box's CPU share), not the machine's core count
-    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get('SININN_CPU_THREADS', '16')))
+    # every host core this process may use: the affinity mask, capped by the container's CPU quota when there is one (a
+    # box exposes all of the node's cores in the mask but schedules its CPU share); SININN_CPU_THREADS overrides
+    cores = host_cores()
     torch.set_num_threads(cores)
     tw = time.time()
     O.training_step(ref, hr, lr, z, lam, opt.lr_dims); o.step()          # warm-up
@@ -109,9 +129,11 @@ def cpu_baseline(args, opt, seconds_budget=30.0):
         n += 1
     dt = (time.time() - t0) / n if n else tw
     return {'value': b / dt, 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'{n} timed + 1 warm-up training steps of the torch-CPU oracle (fp32), batch {b} (frames/s = batch / step '
-                      f'time, i.e. per-frame normalised from batch {b}, not the benchmark batch), '
-                      f'{args.width}x{args.height}, -c {args.num_coupling}, {getattr(args, "arch", "SRF")}'}
+            'host_cores': {'used': torch.get_num_threads(), 'affinity_mask': len(os.sched_getaffinity(0)), 'node': os.cpu_count()},
+            'sample': f'{n} timed + 1 warm-up training steps of the torch-CPU oracle (fp32), batch {b}'
+                      + ('' if b == args.batch else f' (frames/s = batch / step time, per-frame normalised from batch {b}, not the benchmark batch {args.batch})')
+                      + f', {args.width}x{args.height}, -c {args.num_coupling}, {getattr(args, "arch", "SRF")}, '
+                      f'{torch.get_num_threads()} threads = every core this process may use'}
 
 
 def self_launch(n):
@@ -202,11 +224,11 @@ def class_roofline(precision, arch='SRF'):
         rec = {'class': f'{k}x{k} {(IRN_CLASS_NAMES if arch == "IRN" else CLASS_NAMES)[cls]}', 'launches': cnt[i], 'ms': ms[i]}
         if fl[i] > 0:
             tf = fl[i] / (ms[i] * 1e-3) / 1e12
-            rec.update(alg_tflops=tf, peak_tflops=peak, frac=tf / peak, bound='mfma')
             wino = k == 3 and precision == 'fp32'
+            ex = tf / 2.25 if wino else tf           # what the matrix pipe executes (Winograd F(2x2,3x3): 16 instead of 36 multiplies)
+            rec.update(alg_tflops=tf, executed_tflops=ex, peak_tflops=peak, frac=ex / peak, frac_algorithmic=tf / peak, bound='mfma')
             if wino:
-                rec['executed_mfma_frac'] = tf / 2.25 / peak
-                rec['note'] = 'Winograd: executes 2.25x fewer MFMA FLOPs than the algorithmic count'
+                rec['note'] = 'Winograd: frac counts the EXECUTED MFMA FLOPs (2.25x fewer than the algorithmic direct-conv count)'
         else:
             rec['bound'] = 'hbm'
         out.append(rec)
@@ -248,7 +270,8 @@ def main():
         if getattr(args, k) is None:
             setattr(args, k, preset[k])
     if args.cpu_batch is None:
-        args.cpu_batch = 2 if args.height * args.width <= 256 * 256 else 1
+        # the benchmark's own batch where a CPU step is about a second (configs[1]); the bigger configs: a bounded sample
+        args.cpu_batch = args.batch if args.height * args.width <= 256 * 256 else 1
     custom = any(getattr(args, k) != preset[k] for k in ('height', 'width', 'num_coupling', 'precision', 'batch'))
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -369,7 +392,17 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = ws * b * args.steps / dt
     # roofline of the dominant kernel: algorithmic FLOPs (2 * pixels * 9*256 * 2*Co) per launch
-    kms = (iso or timer).mean_event_ms()      # HIP events on the launch stream
+    # Per-launch duration of the dominant kernel: its EXECUTION WINDOW (first block's entry to last block's exit, stamped from
+    # inside the kernel, sininn_conv_args.stamp) over the single-stream launches -- the quantity a rocprofv3 kernel trace
+    # reports for the same kernel + grid (profiles/*_single_stream_by_grid.csv; the window starts a few us after the
+    # dispatch, so the trace reads ~5 % longer).  The HIP-event bracket on the launch stream is reported next to it: it also
+    # contains the two event packets' dispatch gaps (~12 us), i.e. time in which the GPU is free for other streams' kernels.
+    tm = iso or timer
+    kms_events = tm.mean_event_ms()
+    kms = tm.stamp_ms if tm.stamp_ms is not None else kms_events
+    kms_src = ('in-kernel execution window (s_memrealtime stamps), single-stream steps run right after the timed region'
+               if tm.stamp_ms is not None else 'HIP events on the launch stream (no in-kernel stamps in this kernel), single-stream steps '
+               'run right after the timed region')
     flops = 2.0 * m0 * 9 * 256 * (2 * co0)
     roof = None
     bf16 = args.precision == 'bf16'
@@ -387,22 +420,28 @@ def main():
                   'v_mfma_f32_32x32x16_bf16, bf16 hidden tensor in, fp32 flow out)') if bf16 else \
                  ('wino_kernel<2,8,2> (fused 3x3 coupling conv 256->48 + affine + log-det, level 0; Winograd F(2x2,3x3): executes '
                   '2.25x fewer MFMA FLOPs than the algorithmic direct-conv count used here)')
-        roof = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
-                'frac': ach / peak, 'traffic': traffic, 'traffic_source': traffic_src,
+        # fp32: the kernel is Winograd F(2x2,3x3) -- the matrix pipe executes 16 multiplies per 2x2 outputs where the direct
+        # convolution the algorithmic count credits needs 36.  A roofline fraction has to be about work the pipe EXECUTES, so
+        # `achieved` / `frac` are the executed rate; the algorithmic (direct-convolution) rate is kept beside it.
+        executed = ach if bf16 else ach / 2.25
+        roof = {'bound': 'mfma', 'achieved': executed, 'peak': peak, 'unit': 'TFLOP/s',
+                'frac': executed / peak, 'traffic': traffic, 'traffic_source': traffic_src,
                 'kernel': kernel,
-                'launches_timed': (iso or timer).count, 'avg_ms': kms,
-                'avg_ms_source': 'HIP events on the launch stream, single-stream steps run right after the timed region',
-                'avg_ms_execution_window': (iso or timer).stamp_ms,     # in-kernel wall-clock stamps, same launches (fp32 kernels)
+                'achieved_algorithmic': ach, 'frac_algorithmic': ach / peak,
+                'launches_timed': tm.count, 'avg_ms': kms, 'avg_ms_source': kms_src,
+                'avg_ms_hip_events': kms_events,
                 'timed_region': {'launches': timer.count, 'avg_ms_execution_window': timer.stamp_ms,
                                  'avg_ms_hip_events': timer.mean_event_ms(),
                                  'note': 'three streams in flight: the window contains other kernels\' blocks'},
-                'alg_flops_per_launch': flops, 'alg_bytes_per_launch': abytes}
+                'alg_flops_per_launch': flops, 'executed_flops_per_launch': flops if bf16 else flops / 2.25,
+                'alg_bytes_per_launch': abytes}
         if not bf16:
-            # what the matrix pipe actually executes: Winograd F(2x2,3x3) needs 16 multiplies per 2x2 outputs instead of 36
-            roof['executed_mfma_frac'] = ach / 2.25 / peak
-            roof['bound_note'] = ('algorithmic FLOPs are credited at the direct-convolution count; the f32 matrix pipe is '
-                                  f'{ach / 2.25 / peak:.0%} busy with the Winograd products, the rest of the time goes to the per-lane '
-                                  'input / output transforms (VALU), LDS operand staging and the HBM-bound epilogue (DESIGN 6)')
+            roof['limiter'] = ('nearest roof is the f32 matrix pipe (168 algorithmic FLOP/B against a ridge of 20), but the pipe is '
+                               f'only {executed / peak:.0%} busy: in-kernel phase stamps (DESIGN 6) put the rest in the per-lane Winograd '
+                               'input / output transforms (vector ALU), LDS operand staging and the store-drain of the epilogue')
+        else:
+            roof['limiter'] = ('nearest roof is the bf16 matrix pipe; phase stamps (DESIGN 6): operand staging, epilogue store '
+                               'drain and LDS fragment reads around an MFMA loop that is a third of the block time')
         # the same launch against the HBM roof (north_star quotes an HBM fraction): algorithmic bytes / time / 8 TB/s
         roof['hbm'] = {'achieved': abytes / (kms * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                        'frac': abytes / (kms * 1e-3) / 1e9 / PEAK_HBM_GBS,
@@ -415,8 +454,17 @@ def main():
             for blk in range(args.num_coupling):
                 kk = 9 if blk % 2 == 0 else 1
                 fwd += 2.0 * mm * kk * (cc // 2 * 256 + 256 * cc) * 2
+        # executed: the 3x3 subnets (Winograd in fp32: / 2.25), the 1x1 subnets as counted
+        fwd_ex = 0.0
+        for lvl, (mm, cc) in enumerate(((m0, 48), (m0 // 4, 192))):
+            for blk in range(args.num_coupling):
+                kk = 9 if blk % 2 == 0 else 1
+                f = 2.0 * mm * kk * (cc // 2 * 256 + 256 * cc) * 2
+                fwd_ex += f / 2.25 if (kk == 9 and not bf16) else f
         roof['step'] = {'alg_tflop_per_step': 6 * fwd / 1e12, 'alg_tflops': 6 * fwd / (ms_per_step * 1e-3) / 1e12,
-                        'frac_of_peak': 6 * fwd / (ms_per_step * 1e-3) / 1e12 / peak}
+                        'frac_of_peak_algorithmic': 6 * fwd / (ms_per_step * 1e-3) / 1e12 / peak,
+                        'executed_tflops': 6 * fwd_ex / (ms_per_step * 1e-3) / 1e12,
+                        'frac_of_peak': 6 * fwd_ex / (ms_per_step * 1e-3) / 1e12 / peak}
     if irn:
         # dominant kernel class of the IRN step = the one with the largest single-stream time; same accounting as above
         # (algorithmic direct-convolution FLOPs / HIP-event bracket on the launch stream, f32 matrix-pipe peak)
@@ -426,8 +474,8 @@ def main():
             s1 = min(opt.lr_dims, ch // 2)
             for cin, cout in ((ch - s1, s1), (s1, ch - s1), (s1, ch - s1)):          # F, G, H (archs.py:135-160)
                 fwd += args.num_coupling * 2.0 * mm * 9 * (32 * (4 * cin + 192) + (cin + 128) * cout)
-        roof = {'bound': 'mfma', 'achieved': dom['alg_tflops'], 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': dom['frac'], 'executed_mfma_frac': dom.get('executed_mfma_frac'), 'traffic': None,
+        roof = {'bound': 'mfma', 'achieved': dom['executed_tflops'], 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': dom['frac'], 'achieved_algorithmic': dom['alg_tflops'], 'frac_algorithmic': dom['frac_algorithmic'], 'traffic': None,
                 'kernel': 'IRN: ' + dom['class'] + ' -- average over all its launches of a step (both levels)',
                 'avg_ms': dom['ms_per_step'] / max(dom['launches_per_step'], 1),
                 'avg_ms_source': 'HIP events on the launch stream, single-stream steps run right after the timed region',

@@ -67,7 +67,7 @@ class FrameStore:
         count = int(names[-1][6:11]) + 1
         # the reference opens files by index (io.imread of frame_{x:05d}.png, data.py:33-38) and so fails on the first gap;
         # a resident store must not paper over one with zero frames either
-        gaps = sorted(set(range(int(names[0][6:11]), count)) - {int(n[6:11]) for n in names})
+        gaps = sorted(set(range(count)) - {int(n[6:11]) for n in names})          # the reference indexes from frame_00000.png
         if gaps:
             raise FileNotFoundError(f'{lr_dir}: LR frame(s) missing: ' + ', '.join(f'frame_{t:05d}.png' for t in gaps[:8]))
         hr, lr = None, None

@@ -29,11 +29,15 @@
 extern "C" {
 #endif
 
-#define SININN_ABI_VERSION 3
+#define SININN_ABI_VERSION 4
 #define SININN_HIDDEN 256 /* hidden width of subnet_conv / subnet_conv_1x1, archs.py:12,16 */
 
 int sininn_version(void);
 const char* sininn_last_error(void);
+/* sizeof() of descriptor struct `which` as THIS library was compiled: 0 sininn_conv_args, 1 sininn_wgrad_item,
+ * 2 sininn_dense_args, 3 sininn_glow_args, 4 sininn_subnet, 5 sininn_pack_desc; 0 for an unknown index.  A binding written in
+ * another language (the ctypes mirrors in sin-inn_amd/_lib.py) checks its own layout against it at load time (ABI v4). */
+size_t sininn_sizeof(int which);
 
 /* ------------------------------------------------------------------------------------------------
  * Weight packing.  Source: torch Conv2d weight, OIHW fp32 [N][Cin][k][k] (archs.py:12-13,16-17).
@@ -172,6 +176,10 @@ int sininn_wgrad(const float* in, int in_stride, int Cin, const float* dout, int
  * grid, so each needs far fewer split-K slabs than on its own (3-6x less slab traffic); results are bitwise
  * reproducible like sininn_wgrad's.  3x3: Winograd F(3x3,2x2) kernel, 64 x 32 output tiles; 1x1: 32 x 32 tiles. */
 typedef struct sininn_wgrad_item {
+  size_t struct_bytes;                             /* ABI v4: must be sizeof(sininn_wgrad_item).  The descriptor has grown
+                                                      optional fields twice; a caller built against another revision, or one
+                                                      that fills a stack item field by field and misses a new field, is
+                                                      refused instead of launching with garbage ("the round-2 abort") */
   const float* in;   int in_stride;   int Cin;     /* conv input  [M][in_stride], Cin % 4 == 0                      */
   const float* dout; int dout_stride; int N;       /* output gradient [M][dout_stride], N % 4 == 0                  */
   float* gw; float* gb;                            /* OIHW weight gradient (+=), bias gradient (+=, may be NULL)    */
@@ -226,6 +234,7 @@ int sininn_irn_coupling_bwd(const float* dy, int dy_stride, const float* vy, int
  * The five weight gradients run as one grouped launch pair on wgrad_stream.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct sininn_dense_args {
+  size_t struct_bytes;                             /* ABI v4: must be sizeof(sininn_dense_args)                            */
   int B, H, W, cin, cout, mode, winograd;
   float clamp;
   const float* x; int x_stride;
@@ -240,6 +249,11 @@ typedef struct sininn_dense_args {
   float* dh; float* dv;                            /* modes 2, 3: [M][cout] each                                          */
   float* gw[5]; float* gb[5];
   void* workspace; size_t workspace_bytes;         /* sininn_dense_workspace_bytes                                        */
+  /* ABI v4: extents (in floats) of every buffer the executor writes or reads at a size it derives itself; a call whose
+   * buffers are smaller than the launch sequence needs is refused (sininn_last_error) before anything is launched.
+   * M = B*H*W, bw = pad8(cin) + 128.  Required: buf >= M*bw, out >= M*cout; backward: dout >= M*cout, dF >= M*bw,
+   * dD >= M*pad8(cout) when used, dh / dv >= M*cout (modes 2, 3), aux2 >= M*cout (modes 2, 3).                         */
+  size_t buf_floats, out_floats, aux2_floats, dout_floats, dF_floats, dD_floats, dh_floats, dv_floats;
 } sininn_dense_args;
 size_t sininn_dense_workspace_bytes(int B, int H, int W, int cin, int cout);
 int sininn_dense_forward(const sininn_dense_args* args, void* stream);

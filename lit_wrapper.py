@@ -50,11 +50,13 @@ def _cat_channels(a, b):
     return torch.cat((a.permute(0, 2, 3, 1), b.permute(0, 2, 3, 1)), dim=3).permute(0, 3, 1, 2)
 
 
-def _weighted_sum(*terms):
+def _weighted_sum(like, *terms):
     """sum_i w_i * term_i() over the terms whose weight is non-zero.  The reference evaluates every term and multiplies by
     its weight, also when that is 0 (loss.mmd at the default flags, lit_wrapper.py:47,55); a term with
     weight 0 contributes exactly 0 to the loss and to every gradient, so it is not launched here, and a weight of 1 is
-    not multiplied in (both bit-identical for finite values)."""
+    not multiplied in (both bit-identical for FINITE values; known divergence: where the reference's skipped term is
+    non-finite its 0 * inf = NaN poisons the logged loss and the gradients, here it does not).  With every weight 0 the
+    result is a zero scalar on `like`'s device (no host/GPU hop in the step)."""
     total = None
     for weight, term in terms:
         if weight == 0:
@@ -63,7 +65,7 @@ def _weighted_sum(*terms):
         if weight != 1:
             value = weight * value
         total = value if total is None else total + value
-    return total if total is not None else torch.zeros(())
+    return total if total is not None else like.new_zeros(())
 
 
 class _FrameWriter:
@@ -192,14 +194,14 @@ class SingleVideoINN(pl.LightningModule):
         with torch.cuda.stream(second):
             # reverse pass: (LR | z) -> HR
             hr_hat = self.inn(lr_z, rev=True)
-            bwd_loss = _weighted_sum((o.lambda_bwd_rec, lambda: loss.reconstruction(hr_hat, hr)),
+            bwd_loss = _weighted_sum(hr, (o.lambda_bwd_rec, lambda: loss.reconstruction(hr_hat, hr)),
                                      (o.lambda_bwd_mmd, lambda: loss.mmd(hr_hat, hr, rev=True)))
             if bwd_loss.requires_grad:
                 self.manual_backward(bwd_loss)
 
         # forward pass: HR -> (LR | z)
         lr_z_hat = self.inn(hr)
-        fwd_loss = _weighted_sum((o.lambda_fwd_rec, lambda: loss.reconstruction(lr_z_hat[:, :o.lr_dims], lr)),
+        fwd_loss = _weighted_sum(hr, (o.lambda_fwd_rec, lambda: loss.reconstruction(lr_z_hat[:, :o.lr_dims], lr)),
                                  (o.lambda_fwd_mmd, lambda: loss.mmd(lr_z_hat, lr_z)),
                                  (o.lambda_latent_nll, lambda: loss.latent_nll(lr_z_hat[:, o.lr_dims:])))
         if fwd_loss.requires_grad:
@@ -227,7 +229,7 @@ class SingleVideoINN(pl.LightningModule):
                 tcr_loss = tcr_loss.detach()
 
         optim.step()
-        self.log('train', (fwd_loss.detach() + bwd_loss.detach().to(fwd_loss.device) + tcr_loss))
+        self.log('train', (fwd_loss.detach() + bwd_loss.detach() + tcr_loss))
         if ring is not None:
             ev = torch.cuda.Event()
             ev.record()                                # on the main stream, behind the optimiser step

@@ -58,6 +58,8 @@ _OPTIONS = [
                              help='test: float->uint8 conversion; wrap = the reference ToPILImage wrap-around')),
     (('--save_images',), dict(default=None, help='test: write PNG frames to this directory instead of the ffmpeg pipe')),
     (('--allow_partial_load',), dict(action='store_true', help='test: load a checkpoint whose keys do not all match')),
+    (('--trust_checkpoint',), dict(action='store_true', help='load --resume_state with the full unpickler (it can run code from '
+                                                             'the file); default: tensors, primitives and argparse.Namespace only')),
     (('--synthetic',), dict(type=int, nargs=3, default=None, metavar=('T', 'H', 'W'),
                             help='use a synthetic uint8 clip of T frames of HxW instead of --dataset')),
 ]
@@ -125,14 +127,14 @@ def main(argv=None):
         logger.log_hyperparams(argparse.Namespace(**{k: v for k, v in vars(args).items() if k != 'frame_store'}))
         trainer = Trainer(check_val_every_n_epoch=args.print_iter, default_root_dir=exp_dir, gpus=args.gpu_ids,
                           logger=logger, max_epochs=args.epochs, resume_from_checkpoint=args.resume_state,
-                          callbacks=[ModelCheckpoint(period=args.save_iter)])
+                          callbacks=[ModelCheckpoint(period=args.save_iter)], trust_checkpoint=args.trust_checkpoint)
         trainer.fit(model, LitTrainLoader(train_data, val_data, args.batch_size))
     else:
         exp_dir = os.path.join(args.working_dir, args.operation, args.scene)
         os.makedirs(exp_dir, exist_ok=True)
         video_path = os.path.join(exp_dir, f'{args.architecture}_{args.suffix}_t{args.temp}.avi')
         device = torch.device('cuda', args.gpu_ids[0])
-        checkpoint = load_checkpoint(args.resume_state, map_location=device)
+        checkpoint = load_checkpoint(args.resume_state, map_location=device, trust=args.trust_checkpoint)
         load_weights(model, checkpoint['state_dict'], args.allow_partial_load)
         model.to(device)
         if args.save_images:

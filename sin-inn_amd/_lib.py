@@ -56,21 +56,34 @@ class GlowArgs(C.Structure):
 
 class WgradItem(C.Structure):
     """Mirror of sininn_wgrad_item."""
-    _fields_ = [('inp', c_f), ('in_stride', C.c_int), ('Cin', C.c_int), ('dout', c_f), ('dout_stride', C.c_int),
+    _fields_ = [('struct_bytes', C.c_size_t),
+                ('inp', c_f), ('in_stride', C.c_int), ('Cin', C.c_int), ('dout', c_f), ('dout_stride', C.c_int),
                 ('N', C.c_int), ('gw', c_f), ('gb', c_f), ('in_bf16', C.c_int), ('dout_bf16', C.c_int),
                 ('in_group_stride', C.c_int), ('dout_group_stride', C.c_int), ('gap_begin', C.c_int), ('gap_len', C.c_int)]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_bytes = C.sizeof(WgradItem)
 
 
 class DenseArgs(C.Structure):
     """Mirror of sininn_dense_args."""
-    _fields_ = [('B', C.c_int), ('H', C.c_int), ('W', C.c_int), ('cin', C.c_int), ('cout', C.c_int), ('mode', C.c_int),
+    _fields_ = [('struct_bytes', C.c_size_t),
+                ('B', C.c_int), ('H', C.c_int), ('W', C.c_int), ('cin', C.c_int), ('cout', C.c_int), ('mode', C.c_int),
                 ('winograd', C.c_int), ('clamp', C.c_float),
                 ('x', c_f), ('x_stride', C.c_int), ('aux1', c_f), ('aux1_stride', C.c_int), ('aux2', c_f),
                 ('buf', c_f), ('out', c_f),
                 ('w_fwd', c_f * 5), ('b_fwd', c_f * 5), ('w_dgrad', c_f * 5),
                 ('dout', c_f), ('dF', c_f), ('dD', c_f), ('dh', c_f), ('dv', c_f),
                 ('gw', c_f * 5), ('gb', c_f * 5),
-                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t),
+                ('buf_floats', C.c_size_t), ('out_floats', C.c_size_t), ('aux2_floats', C.c_size_t),
+                ('dout_floats', C.c_size_t), ('dF_floats', C.c_size_t), ('dD_floats', C.c_size_t),
+                ('dh_floats', C.c_size_t), ('dv_floats', C.c_size_t)]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_bytes = C.sizeof(DenseArgs)
 
 
 class PackDesc(C.Structure):
@@ -85,6 +98,7 @@ CONV_RELU, CONV_COUPLE_FWD, CONV_COUPLE_INV, CONV_MASK, CONV_ADD, CONV_LINEAR = 
 _SIGS = {
     'sininn_version': (C.c_int, []),
     'sininn_last_error': (C.c_char_p, []),
+    'sininn_sizeof': (C.c_size_t, [C.c_int]),
     'sininn_pack_conv_weights': (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, c_i, C.c_int, c_f, c_f, C.c_int, c_f, C.c_void_p]),
     'sininn_pack_conv_weights_bf16': (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, c_i, C.c_int, C.c_void_p, c_f, C.c_int,
                                                C.c_void_p, C.c_void_p]),
@@ -176,8 +190,12 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(handle, name)          # AttributeError if the ABI lost a symbol
             fn.restype, fn.argtypes = res, args
-        if handle.sininn_version() != 3:
+        if handle.sininn_version() != 4:
             raise ImportError('libsininn.so ABI version mismatch')
+        for which, mirror in enumerate((ConvArgs, WgradItem, DenseArgs, GlowArgs, SubnetArgs, PackDesc)):
+            if handle.sininn_sizeof(which) != C.sizeof(mirror):
+                raise ImportError(f'{mirror.__name__}: the ctypes mirror has {C.sizeof(mirror)} bytes, libsininn.so was built '
+                                  f'with {handle.sininn_sizeof(which)} (include/sininn.h changed without _lib.py)')
         _lib = handle
     return _lib
 

@@ -121,6 +121,17 @@ extern "C" {
 
 int sininn_version(void) { return SININN_ABI_VERSION; }
 const char* sininn_last_error(void) { return g_err; }
+size_t sininn_sizeof(int which) {
+  switch (which) {
+    case 0: return sizeof(sininn_conv_args);
+    case 1: return sizeof(sininn_wgrad_item);
+    case 2: return sizeof(sininn_dense_args);
+    case 3: return sizeof(sininn_glow_args);
+    case 4: return sizeof(sininn_subnet);
+    case 5: return sizeof(sininn_pack_desc);
+    default: return 0;
+  }
+}
 
 int sininn_pack_conv_weights(const float* w_oihw, const float* bias, int N, int Cin, int ksize, const int* colmap,
                              int Np, float* w_fwd, float* b_fwd, int Cdp, float* w_dgrad, void* stream) {

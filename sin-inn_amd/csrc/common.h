@@ -33,6 +33,14 @@ void set_error(const char* fmt, ...);
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// The ONE way library code creates a weight-gradient descriptor: every field zero, the size tag set.  (Round 2's abort came
+// from a stack item that was filled field by field after the struct had grown -- DESIGN 8; wgrad_group refuses untagged items.)
+static inline sininn_wgrad_item wgrad_item_init() {
+  sininn_wgrad_item it = {};
+  it.struct_bytes = sizeof(sininn_wgrad_item);
+  return it;
+}
+
 // GLOW soft clamp (FrEIA GLOWCouplingBlock.log_e): literal 0.636, not 2/pi.
 __device__ __forceinline__ float glow_log_e(float s, float clamp) { return clamp * 0.636f * atanf(s / clamp); }
 __device__ __forceinline__ float glow_dlog_e(float s, float clamp) {

@@ -39,7 +39,7 @@ static inline int pad32(int n) { return (n + 31) / 32 * 32; }
 static void dense_items(const sininn_dense_args* a, sininn_wgrad_item it[5]) {
   const int cinp = pad8(a->cin), bw = cinp + 4 * GC, coutp = pad8(a->cout);
   for (int i = 0; i < 5; ++i) {
-    it[i] = sininn_wgrad_item{};
+    it[i] = wgrad_item_init();
     const int k = cinp + GC * i;
     it[i].in = a->buf; it[i].in_stride = bw; it[i].Cin = k;
     if (i < 4) { it[i].dout = a->dF ? a->dF + k : nullptr; it[i].dout_stride = bw; it[i].N = GC; }
@@ -54,11 +54,23 @@ size_t dense_workspace_bytes(int B, int H, int W, int cin, int cout) {
   a.B = B; a.H = H; a.W = W; a.cin = cin; a.cout = cout;
   sininn_wgrad_item it[5];
   dense_items(&a, it);
-  return wgrad_group_workspace_bytes(it, 5, B, H, W, 3);
+  // worst case over the live subsets (a frozen conv drops out of the group; fewer output tiles -> more pixel splits each)
+  size_t w = 0;
+  for (int mask = 1; mask < 32; ++mask) {
+    sininn_wgrad_item sub[5];
+    int n = 0;
+    for (int i = 0; i < 5; ++i)
+      if (mask & (1 << i)) sub[n++] = it[i];
+    const size_t bytes = wgrad_group_workspace_bytes(sub, n, B, H, W, 3);
+    w = bytes > w ? bytes : w;
+  }
+  return w;
 }
 
 static int check(const sininn_dense_args* a, const char* who) {
   SININN_CHECK(a != nullptr, "%s: null args", who);
+  SININN_CHECK(a->struct_bytes == sizeof(sininn_dense_args), "%s: struct_bytes = %zu, this library's sininn_dense_args has %zu (ABI %d)",
+               who, a->struct_bytes, sizeof(sininn_dense_args), SININN_ABI_VERSION);
   SININN_CHECK(a->B > 0 && a->H > 0 && a->W > 0, "%s: bad shape", who);
   SININN_CHECK(a->cin > 0 && a->cin % 4 == 0 && a->cout > 0 && a->cout % 4 == 0, "%s: channel counts must be multiples of 4", who);
   SININN_CHECK(a->mode >= 0 && a->mode <= 3, "%s: mode %d", who, a->mode);
@@ -66,6 +78,26 @@ static int check(const sininn_dense_args* a, const char* who) {
   for (int i = 0; i < 5; ++i) SININN_CHECK(a->w_fwd[i] && a->b_fwd[i], "%s: missing packed weights", who);
   SININN_CHECK(a->mode == 0 || a->aux1, "%s: mode %d needs aux1", who, a->mode);
   SININN_CHECK(a->mode < 2 || (a->aux2 && a->clamp > 0.f), "%s: IRN tail needs aux2 and clamp", who);
+  // extents (ABI v4): every buffer the launch sequence addresses at a size it derives from (B, H, W, cin, cout)
+  const size_t M = (size_t)a->B * a->H * a->W, bw = (size_t)pad8(a->cin) + 4 * GC;
+  SININN_CHECK(a->buf_floats >= M * bw, "%s: buf holds %zu floats, the feature buffer needs M * (pad8(cin) + 128) = %zu", who,
+               a->buf_floats, M * bw);
+  SININN_CHECK(a->out_floats >= M * a->cout, "%s: out holds %zu floats, needs M * cout = %zu", who, a->out_floats, M * a->cout);
+  SININN_CHECK(a->mode < 2 || a->aux2_floats >= M * a->cout, "%s: aux2 holds %zu floats, needs M * cout = %zu", who,
+               a->aux2_floats, M * a->cout);
+  return 0;
+}
+
+static int check_backward_extents(const sininn_dense_args* a) {
+  const size_t M = (size_t)a->B * a->H * a->W, bw = (size_t)pad8(a->cin) + 4 * GC, cout = a->cout, coutp = pad8(a->cout);
+  SININN_CHECK(a->dout_floats >= M * cout, "dense_backward: dout holds %zu floats, needs M * cout = %zu", a->dout_floats, M * cout);
+  SININN_CHECK(a->dF_floats >= M * bw, "dense_backward: dF holds %zu floats, needs M * (pad8(cin) + 128) = %zu", a->dF_floats, M * bw);
+  SININN_CHECK(!a->dD || a->dD_floats >= M * coutp, "dense_backward: dD holds %zu floats, needs M * pad8(cout) = %zu", a->dD_floats,
+               M * coutp);
+  if (a->mode >= 2) {
+    SININN_CHECK(a->dh_floats >= M * cout && a->dv_floats >= M * cout, "dense_backward: dh / dv hold %zu / %zu floats, need M * cout = %zu",
+                 a->dh_floats, a->dv_floats, M * cout);
+  }
   return 0;
 }
 
@@ -111,6 +143,7 @@ int dense_backward(const sininn_dense_args* a, hipStream_t st, hipStream_t wst) 
   const bool irn = a->mode >= 2;
   SININN_CHECK(!irn || (a->dD && a->dh && a->dv), "dense_backward: IRN tail needs dD, dh, dv");
   SININN_CHECK(coutp == cout || a->dD, "dense_backward: cout %% 8 != 0 needs dD");
+  if (int rc = check_backward_extents(a)) return rc;
   // ---- tail: gradient w.r.t. conv5's output (K = coutp channels for its data-gradient conv) --------------------------
   const float* dD = a->dout;                    // [M][coutp]
   int dD_stride = cout;

@@ -224,17 +224,27 @@ static Scratch scratch_layout(void* basep, int B, int H, int W, int C, int ksize
   for (size_t c : cands) w = c > w ? c : w;
   {  // grouped weight gradients: the four convs' slabs live side by side
     const int cond_b = co_a;
-    sininn_wgrad_item it[4] = {};
+    sininn_wgrad_item it[4] = {wgrad_item_init(), wgrad_item_init(), wgrad_item_init(), wgrad_item_init()};
     it[0].Cin = SININN_HIDDEN; it[0].N = 2 * co_b;
     it[1].Cin = cond_b;        it[1].N = SININN_HIDDEN;
     it[2].Cin = SININN_HIDDEN; it[2].N = 2 * co_a;
     it[3].Cin = cond_a;        it[3].N = SININN_HIDDEN;
-    const size_t gbytes = wgrad_group_workspace_bytes(it, 4, B, H, W, ksize);
-    w = gbytes > w ? gbytes : w;
-    // mixed-precision path: 64 x 64 tiles on the bf16 matrix pipe (conv2: h is bf16, conv1: dh is bf16)
-    it[0].in_bf16 = it[2].in_bf16 = 1; it[1].dout_bf16 = it[3].dout_bf16 = 1;
-    const size_t bbytes = wgrad_group_workspace_bytes(it, 4, B, H, W, ksize);
-    w = bbytes > w ? bbytes : w;
+    // Worst case over every sub-group that can be launched: a smaller group (per-half mode, a frozen conv whose gw is NULL)
+    // gets MORE pixel splits per problem (S = 512 / output tiles) and can need more slab bytes than the full group
+    // (8.52 MB against 8.47 MB for a 1x1 bf16 block at C = 48).  15 subsets x 2 precisions of host arithmetic.
+    for (int pass = 0; pass < 2; ++pass) {
+      if (pass == 1) {  // mixed-precision path: 64 x 64 tiles on the bf16 matrix pipe (conv2: h is bf16, conv1: dh is bf16)
+        it[0].in_bf16 = it[2].in_bf16 = 1; it[1].dout_bf16 = it[3].dout_bf16 = 1;
+      }
+      for (int mask = 1; mask < 16; ++mask) {
+        sininn_wgrad_item sub[4];
+        int n = 0;
+        for (int i = 0; i < 4; ++i)
+          if (mask & (1 << i)) sub[n++] = it[i];
+        const size_t bytes = wgrad_group_workspace_bytes(sub, n, B, H, W, ksize);
+        w = bytes > w ? bytes : w;
+      }
+    }
   }
   s.ws = base + o;
   s.ws_bytes = w;
@@ -312,7 +322,8 @@ int glow_forward(const sininn_glow_args* a, hipStream_t st) {
     hipEvent_t e0, e1;
     unsigned long long* stamp = nullptr;
     const bool timed = g_prof_h != 0 && a->ksize == 3 && a->H == g_prof_h && prof_pair(&e0, &e1, &stamp);
-    c2.stamp = timed ? stamp : nullptr;
+    c2.stamp = (timed && a->dtype == 0) ? stamp : nullptr;   // entry / exit window stamps: fp32 kernels only (the bf16 conv
+                                                             // kernel reads `stamp` as its 8-word phase accumulator)
     if (timed) (void)hipEventRecord(e0, st);
     {
       ClassScope sc(PC_COUPLE, a->ksize, conv_flops(M, a->ksize, SININN_HIDDEN, 2 * h.co), st);
@@ -351,7 +362,7 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
   auto add_item = [&](const float* in, int in_stride, int cin, const float* dout, int dout_stride, int n, float* gw, float* gb,
                       int in_b, int dout_b, int in_gs, int dout_gs) {
     sininn_wgrad_item& it = items[n_items++];
-    it = sininn_wgrad_item{};                  // optional fields (gap_*) default to 0
+    it = wgrad_item_init();                    // every optional field (gap_*, group strides, dtype flags) defaults to 0
     it.in = in; it.in_stride = in_stride; it.Cin = cin; it.dout = dout; it.dout_stride = dout_stride; it.N = n; it.gw = gw; it.gb = gb;
     it.in_bf16 = in_b; it.dout_bf16 = dout_b; it.in_group_stride = in_gs; it.dout_group_stride = dout_gs;
   };

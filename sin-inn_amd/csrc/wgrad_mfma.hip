@@ -1067,6 +1067,17 @@ static int plan_group(const sininn_wgrad_item* items, int n, int B, int H, int W
   SININN_CHECK(items && n >= 1 && n <= WG_MAXP, "wgrad_group: 1..%d problems per group", WG_MAXP);
   SININN_CHECK(ksize == 1 || ksize == 3, "wgrad_group: ksize %d not in {1,3}", ksize);
   SININN_CHECK(B > 0 && H > 0 && W > 0, "wgrad_group: bad shape");
+  for (int i = 0; i < n; ++i) {
+    const sininn_wgrad_item& it = items[i];
+    SININN_CHECK(it.struct_bytes == sizeof(sininn_wgrad_item),
+                 "wgrad_group: problem %d: struct_bytes = %zu, this library's sininn_wgrad_item has %zu (ABI %d): zero the "
+                 "descriptor and set struct_bytes = sizeof(sininn_wgrad_item)", i, it.struct_bytes, sizeof(sininn_wgrad_item),
+                 SININN_ABI_VERSION);
+    SININN_CHECK(it.gap_len == 0 || (it.gap_len > 0 && it.gap_begin >= 0 && it.gap_begin + it.gap_len <= it.Cin),
+                 "wgrad_group: bad channel gap [%d, +%d) for Cin=%d in problem %d", it.gap_begin, it.gap_len, it.Cin, i);
+    SININN_CHECK((it.in_bf16 == 0 || it.in_bf16 == 1) && (it.dout_bf16 == 0 || it.dout_bf16 == 1),
+                 "wgrad_group: dtype flags must be 0 / 1 (problem %d)", i);
+  }
   // a group whose every problem has a bf16 operand runs on the bf16 matrix pipe (one operand is stored as bf16 already,
   // the other is rounded while it is staged); anything else accumulates exact fp32 products on the f32 pipe
   bool all_mixed = g_wgrad_bf16_mfma;

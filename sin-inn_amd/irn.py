@@ -152,13 +152,14 @@ class _DenseFn(torch.autograd.Function):
         out = torch.empty((b, h, w, cout), device=dev, dtype=torch.float32)
         a = _dense_args(block, packs, b, h, w, mode, clamp)
         a.x, a.x_stride, a.buf, a.out = xd.data_ptr(), xs, buf.data_ptr(), out.data_ptr()
+        a.buf_floats, a.out_floats = buf.numel(), out.numel()
         a1 = a2 = None
         if mode != 'linear':
             a1, s1 = _pixel_view(aux1.detach())
             a.aux1, a.aux1_stride = a1.data_ptr(), s1
         if mode in ('irn_fwd', 'irn_inv'):
             a2 = aux2.detach().contiguous()
-            a.aux2 = a2.data_ptr()
+            a.aux2, a.aux2_floats = a2.data_ptr(), a2.numel()
         check(_lib.lib().sininn_dense_forward(a, ops._stream()))
         if any(ctx.needs_input_grad):
             ctx.block, ctx.mode, ctx.clamp, ctx.shape = block, mode, clamp, (b, h, w, cin)
@@ -182,18 +183,20 @@ class _DenseFn(torch.autograd.Function):
         a = _dense_args(block, packs, b, h, w, mode, clamp)
         a.x, a.x_stride = xd.data_ptr(), xd.stride(2)
         a.buf, a.out, a.dout = buf.data_ptr(), out.data_ptr(), dout.data_ptr()
+        a.buf_floats, a.out_floats, a.dout_floats = buf.numel(), out.numel(), dout.numel()
         dF = torch.empty((m, bw), device=dev, dtype=torch.float32)        # fully written by conv5's data gradient
-        a.dF = dF.data_ptr()
+        a.dF, a.dF_floats = dF.data_ptr(), dF.numel()
         dD = dh = dv = None
         if irn or coutp != cout:
             dD = torch.empty((m, coutp), device=dev, dtype=torch.float32)
-            a.dD = dD.data_ptr()
+            a.dD, a.dD_floats = dD.data_ptr(), dD.numel()
         if mode != 'linear':
             a.aux1, a.aux1_stride = a1.data_ptr(), a1.stride(2)
         if irn:
             dh = torch.empty((m, cout), device=dev, dtype=torch.float32)
             dv = torch.empty((b, h, w, cout), device=dev, dtype=torch.float32)
             a.aux2, a.dh, a.dv = a2.data_ptr(), dh.data_ptr(), dv.data_ptr()
+            a.aux2_floats, a.dh_floats, a.dv_floats = a2.numel(), dh.numel(), dv.numel()
         for i, cv in enumerate(convs):
             if cv.weight.requires_grad:
                 a.gw[i], a.gb[i] = _grad_buf(cv.weight).data_ptr(), _grad_buf(cv.bias).data_ptr()

@@ -146,21 +146,25 @@ def _plain(v):
     return _DROP
 
 
-def load_checkpoint(path, map_location=None):
-    """torch.load for checkpoints of this trainer (tensors + primitives: loads with weights_only=True) and for
-    Lightning checkpoints written by the reference (they pickle an argparse.Namespace under 'hyper_parameters',
-    main.py:127): those need the full unpickler, which is what the reference itself uses."""
-    import pickle
-    try:
-        return torch.load(path, map_location=map_location, weights_only=True)
-    except pickle.UnpicklingError:
+def load_checkpoint(path, map_location=None, trust=False):
+    """torch.load for checkpoints of this trainer (tensors + primitives) and for Lightning checkpoints written by the
+    reference, which pickle an ``argparse.Namespace`` under 'hyper_parameters' (main.py:127).  Always the restricted
+    unpickler (``weights_only=True``) with exactly that one class allow-listed: a file that needs anything else is refused
+    with the unpickler's own message.  ``trust=True`` (CLI ``--trust_checkpoint``) is the explicit opt-in to the full
+    unpickler -- which can run arbitrary code from the file -- and logs a warning before it does."""
+    import argparse
+    import logging
+    if trust:
+        logging.warning(f'{path}: loading with the FULL unpickler (--trust_checkpoint): code inside the file can run')
         return torch.load(path, map_location=map_location, weights_only=False)
+    with torch.serialization.safe_globals([argparse.Namespace]):
+        return torch.load(path, map_location=map_location, weights_only=True)
 
 
 class Trainer:
     def __init__(self, gpus=None, max_epochs=1000, check_val_every_n_epoch=1, default_root_dir='.', logger=None,
                  resume_from_checkpoint=None, callbacks=(), auto_lr_find=False, auto_scale_batch_size=False,
-                 log_every_n_steps=50, **_):
+                 log_every_n_steps=50, trust_checkpoint=False, **_):
         # auto_lr_find / auto_scale_batch_size are inert in the reference as well (trainer.tune() is never
         # called, main.py:108-109)
         self.gpus = list(gpus) if isinstance(gpus, (list, tuple)) else ([gpus] if gpus is not None else [0])
@@ -168,6 +172,7 @@ class Trainer:
         self.root, self.logger, self.resume = default_root_dir, logger, resume_from_checkpoint
         self.ckpt = next((c for c in callbacks if isinstance(c, ModelCheckpoint)), None)
         self.log_every = log_every_n_steps
+        self.trust_checkpoint = bool(trust_checkpoint)
         self.optimizer = None
         self.current_epoch, self.global_step = 0, 0
 
@@ -193,7 +198,7 @@ class Trainer:
         model.trainer = self
         self.optimizer = _OptimizerProxy(model.configure_optimizers())
         if self.resume:
-            ck = load_checkpoint(self.resume, map_location=device)
+            ck = load_checkpoint(self.resume, map_location=device, trust=getattr(self, 'trust_checkpoint', False))
             model.load_state_dict(ck['state_dict'])
             if ck.get('optimizer_states'):
                 self.optimizer.load_state_dict(ck['optimizer_states'][0])

@@ -114,12 +114,14 @@ class _PackCache:
             if same_shape:
                 hit.key = key
             else:
-                if hit is not None and not bf16:
+                if hit is not None:
                     _PACK_REGISTRY.discard(hit)
                 hit = _PackEntry(conv, colmap, key, packs)
                 self.store[(id(conv), bf16)] = hit
-                if not bf16:            # the batched refresh of the optimiser step covers the fp32 packs; bf16 packs are
-                    _PACK_REGISTRY.add(hit)   # refreshed by the first (main-stream) prepare_packs() of the next step
+                # every pack, fp32 (one batched launch) and bf16 (in-place repack per conv), is refreshed INSIDE the optimiser
+                # step on the stream that runs it: after a step no pass can miss the cache and repack on its own stream while
+                # another stream reads the same buffer
+                _PACK_REGISTRY.add(hit)
         return hit.packs
 
 
@@ -151,6 +153,13 @@ class _PackRegistry:
         live = [(e, c) for e, c in pairs if c is not None and c.weight.is_cuda]
         if len(live) != len(self.entries):
             self.entries, self.table = [e for e, _ in live], None
+        # mixed-precision packs: repacked in place, one (tiny) launch pair per conv -- the launches the next pass's cache
+        # miss would have issued, moved onto the optimiser's stream
+        for e, c in live:
+            if e.key[7]:
+                ops.pack_conv_bf16(c.weight.detach(), c.bias.detach(), e.colmap, e.key[4], out=e.packs)
+                e.key = _PackCache._key(c, *e.key[4:])
+        live = [(e, c) for e, c in live if not e.key[7]]
         if not live:
             return
         ptrs = tuple(c.weight.data_ptr() for _, c in live)

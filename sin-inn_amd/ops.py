@@ -176,6 +176,7 @@ def wgrad_group(problems, b, h, w, ksize):
     lib = _lib.lib()
     arr = (_lib.WgradItem * len(problems))()
     for it, prob in zip(arr, problems):
+        it.struct_bytes = C.sizeof(_lib.WgradItem)       # array elements are zero-filled, not constructed
         in_t, in_off, in_stride, cin, dout, dout_off, dout_stride, n, gw, gb = prob[:10]
         in_b, dout_b = (bool(prob[10]), bool(prob[11])) if len(prob) > 10 else (False, False)
         assert gw.is_contiguous() and (gb is None or gb.is_contiguous())

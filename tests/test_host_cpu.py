@@ -22,7 +22,7 @@ def test_abi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(handle, name), f'{name} declared in include/sininn.h but not exported'
     assert declared <= set(_lib.EXPORTED) | {'sininn_conv_args'}
-    assert handle.sininn_version() == 3
+    assert handle.sininn_version() == 4
 
 
 def test_cpu_tensors_are_refused_loudly():
@@ -210,6 +210,13 @@ def test_checkpoint_holds_tensors_and_primitives_only(tmp_path):
     ref_path = str(tmp_path / 'ref.ckpt')
     torch.save({'state_dict': m.state_dict(), 'hyper_parameters': {'opt': argparse.Namespace(scale=4)}, 'epoch': 1}, ref_path)
     assert pl.load_checkpoint(ref_path)['hyper_parameters']['opt'].scale == 4
+    # anything beyond tensors / primitives / argparse.Namespace is refused unless the caller opts in explicitly
+    import pickle
+    evil = str(tmp_path / 'evil.ckpt')
+    torch.save({'state_dict': m.state_dict(), 'hyper_parameters': {'opt': types.SimpleNamespace(scale=4)}}, evil)
+    with pytest.raises(pickle.UnpicklingError):
+        pl.load_checkpoint(evil)
+    assert pl.load_checkpoint(evil, trust=True)['hyper_parameters']['opt'].scale == 4
 
 
 def test_test_mode_loads_strictly_and_tolerates_only_freia_bookkeeping():
@@ -261,3 +268,73 @@ def test_frame_store_from_directory_layout_and_missing_frames(tmp_path):
     _write_png_tree(str(tmp_path / 'gap'), 'clip', 30, 16, 16, skip_lr={12})
     with pytest.raises(FileNotFoundError):
         data.FrameStore.from_directory(str(tmp_path / 'gap'), 'clip')
+
+
+def test_descriptor_guards_refuse_before_any_launch():
+    """ABI v4 guards against the cause of round 2's abort: a descriptor that was not zeroed + size-tagged, a channel
+    gap outside the operand, or a DenseBlock buffer smaller than the launch sequence needs is refused with an error message
+    BEFORE anything is launched (so this runs without a GPU; the pointers are never dereferenced)."""
+    import ctypes as C
+    import sin_inn_amd
+    from sin_inn_amd import _lib
+    lib = _lib.lib()
+    for which, mirror in enumerate((_lib.ConvArgs, _lib.WgradItem, _lib.DenseArgs, _lib.GlowArgs, _lib.SubnetArgs, _lib.PackDesc)):
+        assert lib.sininn_sizeof(which) == C.sizeof(mirror)
+    fake = 0x7f0000000000                         # 16-byte aligned, never dereferenced on the host
+    arr = (_lib.WgradItem * 2)()
+    for it in arr:
+        it.inp, it.dout, it.gw = fake, fake, fake
+        it.in_stride, it.Cin, it.dout_stride, it.N = 64, 64, 32, 32
+    # 1. untagged items (what a caller built against the v3 header, or a field-by-field fill of a grown struct, hands over)
+    assert lib.sininn_wgrad_group_workspace_bytes(arr, 2, 1, 16, 16, 3) == 0
+    assert b'struct_bytes' in lib.sininn_last_error()
+    assert lib.sininn_wgrad_group(arr, 2, 1, 16, 16, 3, fake, 1 << 30, None) != 0
+    for it in arr:
+        it.struct_bytes = C.sizeof(_lib.WgradItem)
+    assert lib.sininn_wgrad_group_workspace_bytes(arr, 2, 1, 16, 16, 3) > 0
+    # 2. garbage in the optional fields (the uninitialised gap_begin / gap_len of the abort)
+    arr[1].gap_begin, arr[1].gap_len = 60, 0x40000000
+    assert lib.sininn_wgrad_group(arr, 2, 1, 16, 16, 3, fake, 1 << 30, None) != 0
+    assert b'channel gap' in lib.sininn_last_error()
+    arr[1].gap_begin, arr[1].gap_len = -8, 8
+    assert lib.sininn_wgrad_group(arr, 2, 1, 16, 16, 3, fake, 1 << 30, None) != 0
+    arr[1].gap_begin, arr[1].gap_len = 0, 0
+    arr[0].in_bf16 = 7
+    assert lib.sininn_wgrad_group(arr, 2, 1, 16, 16, 3, fake, 1 << 30, None) != 0
+    assert b'dtype flags' in lib.sininn_last_error()
+    # 3. DenseBlock executor: undersized buffers
+    m, cin, cout = 2 * 8 * 8, 12, 20
+    bw = 16 + 128
+
+    def dense(**over):
+        a = _lib.DenseArgs(B=2, H=8, W=8, cin=cin, cout=cout, mode=2, winograd=1, clamp=1.0)
+        a.x, a.x_stride, a.aux1, a.aux1_stride, a.aux2, a.buf, a.out = fake, cin, fake, cout, fake, fake, fake
+        for i in range(5):
+            a.w_fwd[i] = a.b_fwd[i] = a.w_dgrad[i] = fake
+        a.buf_floats, a.out_floats, a.aux2_floats = m * bw, m * cout, m * cout
+        a.dout, a.dF, a.dD, a.dh, a.dv, a.workspace = fake, fake, fake, fake, fake, fake
+        a.dout_floats, a.dF_floats, a.dD_floats, a.dh_floats, a.dv_floats = m * cout, m * bw, m * 24, m * cout, m * cout
+        a.workspace_bytes = 1 << 30
+        for k, v in over.items():
+            setattr(a, k, v)
+        return a
+    for fn, over, word in ((lib.sininn_dense_forward, dict(buf_floats=m * bw - 1), b'buf holds'),
+                           (lib.sininn_dense_forward, dict(out_floats=m * cout - 4), b'out holds'),
+                           (lib.sininn_dense_forward, dict(aux2_floats=0), b'aux2 holds'),
+                           (lib.sininn_dense_forward, dict(struct_bytes=C.sizeof(_lib.DenseArgs) - 64), b'struct_bytes'),
+                           (lib.sininn_dense_backward, dict(dF_floats=m * (bw - 8)), b'dF holds'),
+                           (lib.sininn_dense_backward, dict(dD_floats=m * cout), b'dD holds'),     # needs pad8(cout) = 24 columns
+                           (lib.sininn_dense_backward, dict(dh_floats=m), b'dh / dv hold'),
+                           (lib.sininn_dense_backward, dict(dout_floats=m), b'dout holds')):
+        a = dense(**over)
+        rc = fn(a, None) if fn is lib.sininn_dense_forward else fn(a, None, None)
+        assert rc != 0 and word in lib.sininn_last_error(), (over, lib.sininn_last_error())
+
+
+def test_frame_store_refuses_a_clip_that_does_not_start_at_frame_0(tmp_path):
+    """the reference indexes frame_{x:05d}.png from 0 (data.py:33-38): LR frames missing BEFORE the first present index are a
+    gap too (they would otherwise sit in neighbouring frames' LR windows as all-zero planes)"""
+    import data
+    _write_png_tree(str(tmp_path / 'late'), 'clip', 30, 16, 16, skip_lr={0, 1})
+    with pytest.raises(FileNotFoundError, match='frame_00000.png'):
+        data.FrameStore.from_directory(str(tmp_path / 'late'), 'clip')
