@@ -324,6 +324,12 @@ size_t sininn_glow_saved_floats_dtype(int B, int H, int W, int C, int dtype);   
 size_t sininn_glow_scratch_bytes(int B, int H, int W, int C, int ksize);
 int sininn_glow_forward(const sininn_glow_args* args, void* stream);
 int sininn_glow_backward(const sininn_glow_args* args, void* stream, void* wgrad_stream);
+/* Parity tooling (ABI v4): the ReLU gates the forward pass of a block took, gates[m][j] = (hidden[m][j] > 0) as bytes
+ * [B*H*W][256], for the subnet executed first (which = 0: s2 when rev == 0, s1 when rev == 1) or second (which = 1), decoded
+ * from `saved` in whatever layout / dtype the executor stored it.  args: the descriptor of the forward call (B, H, W, C, ksize,
+ * rev, dtype, s1 / s2 .winograd, saved).  With these gates forced, a float64 evaluation of the network is a smooth function
+ * and can be compared with the HIP path without the discrete noise of units that sit within rounding distance of 0. */
+int sininn_glow_hidden_gates(const sininn_glow_args* args, int which, uint8_t* gates, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Index maps: FrEIA IRevNetDownsampling (archs.py:28-31,35-38) and PermuteRandom (archs.py:65-68),
@@ -395,6 +401,15 @@ int sininn_flow_warp_l1(const float* img, const float* flow, const float* target
 int sininn_flow_warp_l1_bwd(const float* img, const float* flow, const float* target, const float* warped,
                             const float* gwarped, const float* gmetric, int B, int C, int H, int W,
                             float* gimg, float* gflow, void* stream);
+/* The same two kernels in the arithmetic BASELINE configs[3] names ("pair_flow warp + INN at 512x512, bf16"): img, target,
+ * warped and gwarped are bf16 in HBM (half the bytes of this HBM-bound pair); the bilinear weights, the interpolation, the
+ * metric (taken on the ROUNDED warped value, i.e. on what the consumer reads back) and every gradient accumulator
+ * (gimg, gflow) are fp32, flow and metric are fp32 tensors (ABI v4). */
+int sininn_flow_warp_l1_bf16(const void* img, const float* flow, const void* target, int B, int C, int H, int W,
+                             void* warped, float* metric, void* stream);
+int sininn_flow_warp_l1_bwd_bf16(const void* img, const float* flow, const void* target, const void* warped,
+                                 const void* gwarped, const float* gmetric, int B, int C, int H, int W,
+                                 float* gimg, float* gflow, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Frame-window sampler (data.py:31-45 + 112-115 on an HBM-resident uint8 clip):

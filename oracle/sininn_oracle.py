@@ -78,12 +78,18 @@ def bf16_round(t):
     return t + (t.to(torch.bfloat16).to(t.dtype) - t).detach()
 
 
-def run_subnet(seq, x, emulate_bf16=False):
+def run_subnet(seq, x, emulate_bf16=False, gate=None):
     """The conv subnet (archs.py:11-17).  emulate_bf16 models the mixed-precision HIP path: inputs, weights and the
-    hidden tensor are rounded to bf16, every product is accumulated in fp32, bias / ReLU / output stay fp32."""
+    hidden tensor are rounded to bf16, every product is accumulated in fp32, bias / ReLU / output stay fp32.
+    gate (checker feature, not in the reference): a (B,256,H,W) 0/1 mask that REPLACES the ReLU's own decision, h = conv1(x)
+    * gate -- with the gates another evaluation took, the network is a smooth function and two evaluations of it can be
+    compared without the discrete noise of units whose pre-activation lies within rounding distance of 0."""
+    c1, c2 = seq[0], seq[2]
+    if gate is not None:
+        assert not emulate_bf16
+        return c2(c1(x) * gate.to(x.dtype))
     if not emulate_bf16:
         return seq(x)
-    c1, c2 = seq[0], seq[2]
     h = F.relu(F.conv2d(bf16_round(x), bf16_round(c1.weight), c1.bias, padding=c1.padding))
     return F.conv2d(bf16_round(h), bf16_round(c2.weight), c2.bias, padding=c2.padding)
 
@@ -106,24 +112,28 @@ class GlowBlock(nn.Module):
         self.s2 = make_subnet(self.l2, 2 * self.l1, ksize)
         self.last_jac = None
         self.emulate_bf16 = False        # checker for the mixed-precision HIP path (not a reference feature)
+        self.forced_gates = None         # checker: {'s1': mask, 's2': mask} replaces the ReLU decisions (see run_subnet)
 
     def forward(self, x, rev=False):
         x1, x2 = x[:, :self.l1], x[:, self.l1:]
         bf = self.emulate_bf16
+        g1 = g2 = None
+        if self.forced_gates is not None:
+            g1, g2 = self.forced_gates['s1'], self.forced_gates['s2']
         if not rev:
-            r2 = run_subnet(self.s2, x2, bf)
+            r2 = run_subnet(self.s2, x2, bf, g2)
             s2, t2 = r2[:, :self.l1], r2[:, self.l1:]
             y1 = torch.exp(log_e(s2, self.clamp)) * x1 + t2
-            r1 = run_subnet(self.s1, y1, bf)
+            r1 = run_subnet(self.s1, y1, bf, g1)
             s1, t1 = r1[:, :self.l2], r1[:, self.l2:]
             y2 = torch.exp(log_e(s1, self.clamp)) * x2 + t1
             self.last_jac = (log_e(s1, self.clamp).sum(dim=(1, 2, 3))
                              + log_e(s2, self.clamp).sum(dim=(1, 2, 3)))
         else:
-            r1 = run_subnet(self.s1, x1, bf)
+            r1 = run_subnet(self.s1, x1, bf, g1)
             s1, t1 = r1[:, :self.l2], r1[:, self.l2:]
             y2 = (x2 - t1) / torch.exp(log_e(s1, self.clamp))
-            r2 = run_subnet(self.s2, y2, bf)
+            r2 = run_subnet(self.s2, y2, bf, g2)
             s2, t2 = r2[:, :self.l1], r2[:, self.l1:]
             y1 = (x1 - t2) / torch.exp(log_e(s2, self.clamp))
             self.last_jac = -(log_e(s1, self.clamp).sum(dim=(1, 2, 3))
@@ -238,12 +248,18 @@ class DenseBlockOracle(nn.Module):
         self.convs[4].weight.data *= 0
         self.convs[4].bias.data.zero_()
 
+        self.forced_gates = None         # checker: four (B,32,H,W) 0/1 masks replace the LeakyReLU decisions (run_subnet)
+
     def forward(self, x):
         feats = [x]
         for i, conv in enumerate(self.convs):
             y = conv(torch.cat(feats, 1))
             if i < 4:
-                y = F.leaky_relu(y, 0.2)
+                if self.forced_gates is not None:
+                    g = self.forced_gates[i].to(y.dtype)
+                    y = y * (0.2 + 0.8 * g)
+                else:
+                    y = F.leaky_relu(y, 0.2)
                 feats.append(y)
         return y
 

@@ -140,6 +140,7 @@ _SIGS = {
     'sininn_glow_scratch_bytes': (C.c_size_t, [C.c_int] * 5),
     'sininn_glow_forward': (C.c_int, [C.POINTER(GlowArgs), C.c_void_p]),
     'sininn_glow_backward': (C.c_int, [C.POINTER(GlowArgs), C.c_void_p, C.c_void_p]),
+    'sininn_glow_hidden_gates': (C.c_int, [C.POINTER(GlowArgs), C.c_int, C.c_void_p, C.c_void_p]),
     'sininn_conv_pair_k1_supported': (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs)]),
     'sininn_conv_pair_k1': (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs), C.c_void_p]),
     'sininn_dense_workspace_bytes': (C.c_size_t, [C.c_int] * 5),
@@ -166,6 +167,10 @@ _SIGS = {
     'sininn_flow_warp_l1': (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f, c_f, C.c_void_p]),
     'sininn_flow_warp_l1_bwd': (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f, c_f,
                                           C.c_void_p]),
+    'sininn_flow_warp_l1_bf16': (C.c_int, [C.c_void_p, c_f, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, c_f,
+                                           C.c_void_p]),
+    'sininn_flow_warp_l1_bwd_bf16': (C.c_int, [C.c_void_p, c_f, C.c_void_p, C.c_void_p, C.c_void_p, c_f, C.c_int, C.c_int, C.c_int,
+                                               C.c_int, c_f, c_f, C.c_void_p]),
     'sininn_sample_windows': (C.c_int, [C.c_void_p, C.c_void_p, c_i, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int, c_f, I64x4, c_f, I64x4, C.c_void_p]),
     'sininn_bayer_bin': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -55,6 +55,11 @@ int flow_warp_l1_launch(const float* img, const float* flow, const float* target
 int flow_warp_l1_bwd_launch(const float* img, const float* flow, const float* target, const float* warped,
                             const float* gwarped, const float* gmetric, int B, int C, int H, int W, float* gimg,
                             float* gflow, hipStream_t st);
+int flow_warp_l1_bf16_launch(const void* img, const float* flow, const void* target, int B, int C, int H, int W,
+                             void* warped, float* metric, hipStream_t st);
+int flow_warp_l1_bwd_bf16_launch(const void* img, const float* flow, const void* target, const void* warped,
+                                 const void* gwarped, const float* gmetric, int B, int C, int H, int W, float* gimg,
+                                 float* gflow, hipStream_t st);
 int sample_windows_launch(const uint8_t* hr_clip, const uint8_t* lr_clip, const int* idx, int n, int T, int H, int W,
                           int h, int w, int win, float* hr_out, const int64_t hs[4], float* lr_out,
                           const int64_t ls[4], hipStream_t st);
@@ -112,6 +117,7 @@ size_t glow_saved_floats(int B, int H, int W, int C, int dtype);
 size_t glow_scratch_bytes(int B, int H, int W, int C, int ksize);
 int glow_forward(const sininn_glow_args* a, hipStream_t st);
 int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst);
+int glow_hidden_gates(const sininn_glow_args* a, int which, unsigned char* gates, hipStream_t st);
 }  // namespace sininn
 
 using namespace sininn;
@@ -311,6 +317,15 @@ int sininn_flow_warp_l1_bwd(const float* img, const float* flow, const float* ta
   return flow_warp_l1_bwd_launch(img, flow, target, warped, gwarped, gmetric, B, C, H, W, gimg, gflow, ST(stream));
 }
 
+int sininn_flow_warp_l1_bf16(const void* img, const float* flow, const void* target, int B, int C, int H, int W, void* warped,
+                             float* metric, void* stream) {
+  return flow_warp_l1_bf16_launch(img, flow, target, B, C, H, W, warped, metric, ST(stream));
+}
+int sininn_flow_warp_l1_bwd_bf16(const void* img, const float* flow, const void* target, const void* warped, const void* gwarped,
+                                 const float* gmetric, int B, int C, int H, int W, float* gimg, float* gflow, void* stream) {
+  return flow_warp_l1_bwd_bf16_launch(img, flow, target, warped, gwarped, gmetric, B, C, H, W, gimg, gflow, ST(stream));
+}
+
 int sininn_sample_windows(const uint8_t* hr_clip, const uint8_t* lr_clip, const int* idx, int n, int T, int H, int W,
                           int h, int w, int win, float* hr_out, const int64_t hs[4], float* lr_out, const int64_t ls[4],
                           void* stream) {
@@ -344,6 +359,10 @@ int sininn_pack_conv_weights_bf16(const float* w_oihw, const float* bias, int N,
 
 void sininn_profile_classes_begin(void) { profile_classes_begin(); }
 int sininn_profile_classes_end(int n, double* ms, double* flops, int* launches) { return profile_classes_end(n, ms, flops, launches); }
+
+int sininn_glow_hidden_gates(const sininn_glow_args* args, int which, uint8_t* gates, void* stream) {
+  return glow_hidden_gates(args, which, gates, ST(stream));
+}
 
 size_t sininn_dense_workspace_bytes(int B, int H, int W, int cin, int cout) { return dense_workspace_bytes(B, H, W, cin, cout); }
 int sininn_dense_forward(const sininn_dense_args* args, void* stream) { return dense_forward(args, ST(stream)); }

@@ -515,9 +515,18 @@ int affine_warp_bwd_launch(const float* gout, const int64_t gs[4], const float* 
 //   source column of the same rows (true almost everywhere for a smooth flow), else loaded.
 // ------------------------------------------------------------------------------------------------
 constexpr int FW_MAXC = 8;
-__global__ void flow_warp_l1_kernel(const float* __restrict__ img, const float* __restrict__ flow,
-                                    const float* __restrict__ target, int B, int C, int H, int W,
-                                    float* __restrict__ warped, float* __restrict__ metric) {
+// image-like operands (img / target / warped / gwarped) are fp32 or bf16 (BASELINE configs[3]: the warp runs in the
+// bf16 arithmetic of that config: bf16 in HBM, fp32 interpolation, weights, metric and every gradient accumulator);
+// flow and metric stay fp32 (geometry / a 1-channel reduction)
+__device__ __forceinline__ float fw_ld(const float* p, int64_t i) { return p[i]; }
+__device__ __forceinline__ float fw_ld(const __bf16* p, int64_t i) { return (float)p[i]; }
+__device__ __forceinline__ void fw_st(float* p, int64_t i, float v) { p[i] = v; }
+__device__ __forceinline__ void fw_st(__bf16* p, int64_t i, float v) { p[i] = (__bf16)v; }
+
+template <typename T>
+__global__ void flow_warp_l1_kernel(const T* __restrict__ img, const float* __restrict__ flow,
+                                    const T* __restrict__ target, int B, int C, int H, int W,
+                                    T* __restrict__ warped, float* __restrict__ metric) {
   const int64_t HW = (int64_t)H * W;
   const int64_t total = (int64_t)B * HW;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // grid covers total rounded up to 64
@@ -538,38 +547,52 @@ __global__ void flow_warp_l1_kernel(const float* __restrict__ img, const float* 
   const bool share = (lane < 63) && (nb == b) && (nx0 == x0 + 1) && (ny0 == y0);
   float l1 = 0.f;
   for (int c = 0; c < C; ++c) {
-    const float* base = img + ((int64_t)b * C + c) * HW;
+    const T* base = img + ((int64_t)b * C + c) * HW;
     auto tap = [&](int yy, int xx) -> float {
-      return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? base[(int64_t)yy * W + xx] : 0.f;
+      return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? fw_ld(base, (int64_t)yy * W + xx) : 0.f;
     };
     const float t00 = tap(y0, x0), t10 = tap(y0 + 1, x0);
     const float n00 = __shfl_down(t00, 1), n10 = __shfl_down(t10, 1);
     const float t01 = share ? n00 : tap(y0, x0 + 1);
     const float t11 = share ? n10 : tap(y0 + 1, x0 + 1);
-    const float val = t00 * wy0 * wx0 + t01 * wy0 * wx1 + t10 * wy1 * wx0 + t11 * wy1 * wx1;
+    float val = t00 * wy0 * wx0 + t01 * wy0 * wx1 + t10 * wy1 * wx0 + t11 * wy1 * wx1;
     if (live) {
-      if (warped) warped[((int64_t)b * C + c) * HW + r] = val;
-      if (target) l1 += fabsf(target[((int64_t)b * C + c) * HW + r] - val);
+      if (warped) {
+        fw_st(warped, ((int64_t)b * C + c) * HW + r, val);
+        if constexpr (!std::is_same<T, float>::value) val = (float)(__bf16)val;   // the metric sees what was stored
+      }
+      if (target) l1 += fabsf(fw_ld(target, ((int64_t)b * C + c) * HW + r) - val);
     }
   }
   if (live && metric) metric[(int64_t)b * HW + r] = l1 / (float)C;
 }
 
-int flow_warp_l1_launch(const float* img, const float* flow, const float* target, int B, int C, int H, int W,
-                        float* warped, float* metric, hipStream_t st) {
+template <typename T>
+static int flow_warp_l1_launch_t(const T* img, const float* flow, const T* target, int B, int C, int H, int W,
+                                 T* warped, float* metric, hipStream_t st) {
   SININN_CHECK(img && flow && (warped || metric), "flow_warp_l1: null pointer");
   SININN_CHECK(!metric || target, "flow_warp_l1: metric needs target");
   SININN_CHECK(B > 0 && C > 0 && C <= FW_MAXC && H > 1 && W > 1, "flow_warp_l1: bad shape (C<=8, H,W>1)");
   const int64_t total = (int64_t)B * H * W;
-  hipLaunchKernelGGL(flow_warp_l1_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, img, flow, target, B,
+  hipLaunchKernelGGL(flow_warp_l1_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, img, flow, target, B,
                      C, H, W, warped, metric);
   SININN_LAUNCH_CHECK("flow_warp_l1");
   return 0;
 }
+int flow_warp_l1_launch(const float* img, const float* flow, const float* target, int B, int C, int H, int W,
+                        float* warped, float* metric, hipStream_t st) {
+  return flow_warp_l1_launch_t<float>(img, flow, target, B, C, H, W, warped, metric, st);
+}
+int flow_warp_l1_bf16_launch(const void* img, const float* flow, const void* target, int B, int C, int H, int W,
+                             void* warped, float* metric, hipStream_t st) {
+  return flow_warp_l1_launch_t<__bf16>(static_cast<const __bf16*>(img), flow, static_cast<const __bf16*>(target), B, C, H, W,
+                                       static_cast<__bf16*>(warped), metric, st);
+}
 
-__global__ void flow_warp_l1_bwd_kernel(const float* __restrict__ img, const float* __restrict__ flow,
-                                        const float* __restrict__ target, const float* __restrict__ warped,
-                                        const float* __restrict__ gwarped, const float* __restrict__ gmetric, int B,
+template <typename T>
+__global__ void flow_warp_l1_bwd_kernel(const T* __restrict__ img, const float* __restrict__ flow,
+                                        const T* __restrict__ target, const T* __restrict__ warped,
+                                        const T* __restrict__ gwarped, const float* __restrict__ gmetric, int B,
                                         int C, int H, int W, float* __restrict__ gimg, float* __restrict__ gflow) {
   const int64_t HW = (int64_t)H * W;
   const int64_t total = (int64_t)B * HW;
@@ -588,14 +611,14 @@ __global__ void flow_warp_l1_bwd_kernel(const float* __restrict__ img, const flo
   float gix = 0.f, giy = 0.f;
   for (int c = 0; c < C; ++c) {
     const int64_t o = ((int64_t)b * C + c) * HW;
-    float g = gwarped ? gwarped[o + r] : 0.f;
+    float g = gwarped ? fw_ld(gwarped, o + r) : 0.f;
     if (gmetric) {
-      const float d = target[o + r] - warped[o + r];
+      const float d = fw_ld(target, o + r) - fw_ld(warped, o + r);
       g += (d > 0.f) ? -gm : ((d < 0.f) ? gm : 0.f);
     }
-    const float* base = img + o;
+    const T* base = img + o;
     auto tap = [&](int yy, int xx) -> float {
-      return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? base[(int64_t)yy * W + xx] : 0.f;
+      return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? fw_ld(base, (int64_t)yy * W + xx) : 0.f;
     };
     const float t00 = tap(y0, x0), t01 = tap(y0, x0 + 1), t10 = tap(y0 + 1, x0), t11 = tap(y0 + 1, x0 + 1);
     gix += g * ((t01 - t00) * wy0 + (t11 - t10) * wy1);
@@ -619,9 +642,10 @@ __global__ void flow_warp_l1_bwd_kernel(const float* __restrict__ img, const flo
 // further away go to HBM atomics directly (plain per-tap global atomics made this kernel 17x slower than its flow-only
 // form: 1.3 ms at 16x3x512x512).
 constexpr int FB_TX = 32, FB_TY = 8, FB_R = 8, FB_WX = FB_TX + 2 * FB_R, FB_WY = FB_TY + 2 * FB_R;
+template <typename T>
 __global__ __launch_bounds__(FB_TX * FB_TY) void flow_warp_l1_bwd_tiled_kernel(
-    const float* __restrict__ img, const float* __restrict__ flow, const float* __restrict__ target,
-    const float* __restrict__ warped, const float* __restrict__ gwarped, const float* __restrict__ gmetric, int B, int C, int H,
+    const T* __restrict__ img, const float* __restrict__ flow, const T* __restrict__ target,
+    const T* __restrict__ warped, const T* __restrict__ gwarped, const float* __restrict__ gmetric, int B, int C, int H,
     int W, float* __restrict__ gimg, float* __restrict__ gflow) {
   constexpr int CC = 4;                                                  // channels per window pass
   __shared__ float win[CC][FB_WY][FB_WX];
@@ -653,14 +677,14 @@ __global__ __launch_bounds__(FB_TX * FB_TY) void flow_warp_l1_bwd_tiled_kernel(
     if (finite) {
       for (int c = 0; c < cc; ++c) {
         const int64_t o = ((int64_t)b * C + c0 + c) * HW;
-        float g = gwarped ? gwarped[o + r] : 0.f;
+        float g = gwarped ? fw_ld(gwarped, o + r) : 0.f;
         if (gmetric) {
-          const float d = target[o + r] - warped[o + r];
+          const float d = fw_ld(target, o + r) - fw_ld(warped, o + r);
           g += (d > 0.f) ? -gm : ((d < 0.f) ? gm : 0.f);
         }
-        const float* base = img + o;
+        const T* base = img + o;
         auto tap = [&](int yy, int xx) -> float {
-          return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? base[(int64_t)yy * W + xx] : 0.f;
+          return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? fw_ld(base, (int64_t)yy * W + xx) : 0.f;
         };
         const float t00 = tap(y0, x0), t01 = tap(y0, x0 + 1), t10 = tap(y0 + 1, x0), t11 = tap(y0 + 1, x0 + 1);
         gix += g * ((t01 - t00) * wy0 + (t11 - t10) * wy1);
@@ -693,23 +717,36 @@ __global__ __launch_bounds__(FB_TX * FB_TY) void flow_warp_l1_bwd_tiled_kernel(
   }
 }
 
-int flow_warp_l1_bwd_launch(const float* img, const float* flow, const float* target, const float* warped,
-                            const float* gwarped, const float* gmetric, int B, int C, int H, int W, float* gimg,
-                            float* gflow, hipStream_t st) {
+template <typename T>
+static int flow_warp_l1_bwd_launch_t(const T* img, const float* flow, const T* target, const T* warped,
+                                     const T* gwarped, const float* gmetric, int B, int C, int H, int W, float* gimg,
+                                     float* gflow, hipStream_t st) {
   SININN_CHECK(img && flow && (gwarped || gmetric) && (gimg || gflow), "flow_warp_l1_bwd: null pointer");
   SININN_CHECK(!gmetric || (target && warped), "flow_warp_l1_bwd: metric gradient needs target and warped");
   SININN_CHECK(B > 0 && C > 0 && C <= FW_MAXC && H > 1 && W > 1, "flow_warp_l1_bwd: bad shape");
   const int64_t total = (int64_t)B * H * W;
   if (gimg) {
     const int tiles = B * ((H + FB_TY - 1) / FB_TY) * ((W + FB_TX - 1) / FB_TX);
-    hipLaunchKernelGGL(flow_warp_l1_bwd_tiled_kernel, dim3((unsigned)tiles), dim3(FB_TX * FB_TY), 0, st, img, flow, target, warped,
+    hipLaunchKernelGGL(flow_warp_l1_bwd_tiled_kernel<T>, dim3((unsigned)tiles), dim3(FB_TX * FB_TY), 0, st, img, flow, target, warped,
                        gwarped, gmetric, B, C, H, W, gimg, gflow);
   } else {
-    hipLaunchKernelGGL(flow_warp_l1_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, img, flow,
+    hipLaunchKernelGGL(flow_warp_l1_bwd_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, img, flow,
                        target, warped, gwarped, gmetric, B, C, H, W, gimg, gflow);
   }
   SININN_LAUNCH_CHECK("flow_warp_l1_bwd");
   return 0;
+}
+int flow_warp_l1_bwd_launch(const float* img, const float* flow, const float* target, const float* warped,
+                            const float* gwarped, const float* gmetric, int B, int C, int H, int W, float* gimg,
+                            float* gflow, hipStream_t st) {
+  return flow_warp_l1_bwd_launch_t<float>(img, flow, target, warped, gwarped, gmetric, B, C, H, W, gimg, gflow, st);
+}
+int flow_warp_l1_bwd_bf16_launch(const void* img, const float* flow, const void* target, const void* warped,
+                                 const void* gwarped, const float* gmetric, int B, int C, int H, int W, float* gimg,
+                                 float* gflow, hipStream_t st) {
+  typedef const __bf16* P;
+  return flow_warp_l1_bwd_launch_t<__bf16>(static_cast<P>(img), flow, static_cast<P>(target), static_cast<P>(warped),
+                                           static_cast<P>(gwarped), gmetric, B, C, H, W, gimg, gflow, st);
 }
 
 // ------------------------------------------------------------------------------------------------

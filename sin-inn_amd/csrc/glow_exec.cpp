@@ -271,6 +271,38 @@ static int check_common(const sininn_glow_args* a, const char* who) {
 
 static int col_tile_of(int co) { return (co % 16 == 0) ? 32 : 16; }
 
+// ReLU gates of one subnet, as the forward pass took them: gates[m][j] = (h[m][j] > 0), read from `saved` with the layout /
+// dtype the executor chose (row-major fp32 or bf16, channel-group-major fp32).  Parity tooling: with these gates forced, a
+// float64 evaluation of the same network is a smooth function of the same inputs (tests/test_gpu_gates.py).
+__global__ void hidden_gates_kernel(const float* __restrict__ h, int64_t M, int group_major, int bf16, unsigned char* __restrict__ gates) {
+  const int64_t total = M * SININN_HIDDEN;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / SININN_HIDDEN;
+    const int j = (int)(i % SININN_HIDDEN);
+    float v;
+    if (bf16) v = (float)reinterpret_cast<const __bf16*>(h)[i];
+    else if (group_major) v = h[(int64_t)(j >> 3) * M * 8 + m * 8 + (j & 7)];
+    else v = h[i];
+    gates[i] = v > 0.f ? 1 : 0;
+  }
+}
+
+int glow_hidden_gates(const sininn_glow_args* a, int which, unsigned char* gates, hipStream_t st) {
+  SININN_CHECK(a && a->saved && gates && (which == 0 || which == 1), "glow_hidden_gates: bad arguments");
+  SININN_CHECK(a->B > 0 && a->H > 0 && a->W > 0 && a->C >= 16, "glow_hidden_gates: bad shape");
+  const size_t M = (size_t)a->B * a->H * a->W;
+  Half hv[2];
+  halves_of(a, hv);
+  Saved sv = saved_layout(a->saved, M, hv[0].co, hv[1].co, a->dtype == 1);
+  const float* h = which == 0 ? sv.h_a : sv.h_b;
+  const int gm = group_major_hidden(a, hv[which].net) ? 1 : 0;
+  const int64_t total = (int64_t)M * SININN_HIDDEN;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(hidden_gates_kernel, dim3(blocks), dim3(256), 0, st, h, (int64_t)M, gm, a->dtype == 1 ? 1 : 0, gates);
+  SININN_LAUNCH_CHECK("glow_hidden_gates");
+  return 0;
+}
+
 int glow_forward(const sininn_glow_args* a, hipStream_t st) {
   if (int rc = check_common(a, "glow_forward")) return rc;
   const size_t M = (size_t)a->B * a->H * a->W;

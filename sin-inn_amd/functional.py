@@ -134,16 +134,21 @@ class _FlowWarpL1(torch.autograd.Function):
         gm = gm.contiguous() if (gm is not None and target is not None) else None
         if gw is None and gm is None:
             return None, None, None
-        gimg = torch.zeros_like(img) if ctx.needs_input_grad[0] else None
+        # gradient accumulators are fp32 in both arithmetics (the image gradient is a sum of atomics); a bf16 image gets its
+        # gradient back in its own dtype, as autograd requires
+        gimg = torch.zeros(img.shape, device=img.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
         gflow = torch.empty_like(flow) if ctx.needs_input_grad[1] else None
         if gimg is None and gflow is None:
             return None, None, None
+        if gw is not None and gw.dtype != img.dtype:
+            gw = gw.to(img.dtype)
         ops.flow_warp_l1_bwd(img, flow, target, warped, gw, gm, gimg, gflow)
-        return gimg, gflow, None
+        return (gimg.to(img.dtype) if gimg is not None else None), gflow, None
 
 
 def flow_warp_l1(img, flow, target=None):
-    """Resample2d.forward (+ per-pixel channel-mean L1 against `target`): returns (warped, metric)."""
+    """Resample2d.forward (+ per-pixel channel-mean L1 against `target`): returns (warped, metric).  img / target fp32, or both
+    bf16 (the arithmetic of BASELINE configs[3]: bf16 images in HBM, fp32 flow / interpolation / metric / gradients)."""
     _FlowWarpL1.set_materialize_grads = False
     return _FlowWarpL1.apply(img, flow, target)
 

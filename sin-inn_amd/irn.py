@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from . import _lib, ops
 from ._lib import CONV_ADD, CONV_LINEAR, check
-from .modules import USE_SIDE_STREAM, USE_WINOGRAD, WEIGHTS_EPOCH, _grad_buf, _side_stream, import_nchw
+from .modules import GATE_TAP, USE_SIDE_STREAM, USE_WINOGRAD, WEIGHTS_EPOCH, _grad_buf, _side_stream, import_nchw
 
 CONV_LRELU, CONV_IRN_FWD, CONV_IRN_INV = 6, 7, 8
 GC = 32
@@ -164,6 +164,9 @@ class _DenseFn(torch.autograd.Function):
         if any(ctx.needs_input_grad):
             ctx.block, ctx.mode, ctx.clamp, ctx.shape = block, mode, clamp, (b, h, w, cin)
             ctx.save_for_backward(buf, out, a1 if a1 is not None else buf, a2 if a2 is not None else buf, xd)
+            if GATE_TAP[0] is not None:          # parity tooling: the LeakyReLU gates of conv1-4 (feature slots of buf are > 0)
+                feats = buf.view(b, h, w, bw)[..., cinp:]
+                GATE_TAP[0].append((block, None, [(feats[..., GC * i:GC * (i + 1)] > 0).permute(0, 3, 1, 2) for i in range(4)]))
         return out
 
     @staticmethod
@@ -342,5 +345,7 @@ class InvRescaleNet(nn.Module):
             if isinstance(op, HaarDownsampling):
                 out = op(out, rev)
             else:
-                out = op.apply_pixel_major(out.permute(0, 2, 3, 1), rev).permute(0, 3, 1, 2)
+                # import_nchw: zero-copy for the pixel-major tensors the ops hand each other, one layout pass for an
+                # NCHW-contiguous tensor from outside (e.g. a latent built with torch.cat / loaded from disk, rev=True)
+                out = op.apply_pixel_major(import_nchw(out), rev).permute(0, 3, 1, 2)
         return out

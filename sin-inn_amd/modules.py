@@ -182,6 +182,7 @@ _PACK_REGISTRY = _PackRegistry()
 # ------------------------------------------------------------------------------------------------
 _SIDE = {}
 USE_SIDE_STREAM = [True]
+GATE_TAP = [None]       # parity tooling: set to a list -> every differentiable GLOW / DenseBlock forward appends its gates
 
 
 def _side_stream(device):
@@ -270,6 +271,13 @@ class _GlowFn(torch.autograd.Function):
         if need_grad:
             ctx.block, ctx.rev, ctx.dst = block, rev, dst
             ctx.save_for_backward(x, out, saved)
+            if GATE_TAP[0] is not None:          # parity tooling: export the ReLU gates this pass took (tests/test_gpu_gates.py)
+                gates = {}
+                for which, name in enumerate(('s1', 's2') if rev else ('s2', 's1')):
+                    g = torch.empty((b, h, w, HIDDEN), device=dev, dtype=torch.uint8)
+                    _lib.check(lib.sininn_glow_hidden_gates(C.byref(a), which, C.c_void_p(g.data_ptr()), ops._stream()))
+                    gates[name] = g.permute(0, 3, 1, 2)
+                GATE_TAP[0].append((block, bool(rev), gates))
         ctx.set_materialize_grads(False)
         return out, logdet
 

@@ -287,17 +287,32 @@ def affine_warp_bwd(gout, theta, gimg):
 
 
 def flow_warp_l1(img, flow, target, warped, metric):
+    """img / target / warped: all fp32 or all bf16 (BASELINE configs[3] arithmetic); flow, metric fp32."""
     b, c, h, w = img.shape
     for t in (img, flow, target, warped, metric):
         assert t is None or t.is_contiguous()
+    if img.dtype == torch.bfloat16:
+        bf = torch.bfloat16
+        assert all(t is None or t.dtype == bf for t in (target, warped)), 'bf16 flow warp: img, target, warped must all be bf16'
+        check(_lib.lib().sininn_flow_warp_l1_bf16(ptr(img, dtype=bf), ptr(flow), ptr(target, dtype=bf), b, c, h, w,
+                                                  ptr(warped, dtype=bf), ptr(metric), _stream()))
+        return
     check(_lib.lib().sininn_flow_warp_l1(ptr(img), ptr(flow), ptr(target), b, c, h, w, ptr(warped), ptr(metric),
                                          _stream()))
 
 
 def flow_warp_l1_bwd(img, flow, target, warped, gwarped, gmetric, gimg, gflow):
+    """image-like operands (img, target, warped, gwarped) fp32 or bf16 like the forward; gimg / gflow / gmetric fp32."""
     b, c, h, w = img.shape
     for t in (img, flow, target, warped, gwarped, gmetric, gimg, gflow):
         assert t is None or t.is_contiguous()
+    if img.dtype == torch.bfloat16:
+        bf = torch.bfloat16
+        assert all(t is None or t.dtype == bf for t in (target, warped, gwarped))
+        check(_lib.lib().sininn_flow_warp_l1_bwd_bf16(ptr(img, dtype=bf), ptr(flow), ptr(target, dtype=bf), ptr(warped, dtype=bf),
+                                                      ptr(gwarped, dtype=bf), ptr(gmetric), b, c, h, w, ptr(gimg), ptr(gflow),
+                                                      _stream()))
+        return
     check(_lib.lib().sininn_flow_warp_l1_bwd(ptr(img), ptr(flow), ptr(target), ptr(warped), ptr(gwarped),
                                              ptr(gmetric), b, c, h, w, ptr(gimg), ptr(gflow), _stream()))
 

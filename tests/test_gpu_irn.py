@@ -9,7 +9,6 @@ import sin_inn_amd.modules
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4
-ARBITRATION_FACTOR = 3.0      # see tests/test_gpu_model.py
 T = torch.from_numpy
 
 
@@ -210,7 +209,8 @@ def test_irn_training_step_matches_oracle(lr_window):
     flat_g, flat_p = optim.flat_grads()[0].cpu(), optim.flat_params()[0].cpu()
     offs, off = {}, 0
     for n, p in model.named_parameters():
-        offs[n] = (off, p.numel()); off += p.numel()
+        if p.requires_grad:                          # the frozen Haar filters (archs.py:178-179) are not in the flat buffers
+            offs[n] = (off, p.numel()); off += p.numel()
     got, want = [], []
     for n, pc in ref.named_parameters():
         o, k = offs['inn.' + key(n)]
@@ -286,27 +286,8 @@ def test_irn_at_baseline_config_shape_matches_oracle():
     assert per[len(per) // 2] < 3e-4, per[len(per) // 2]
     assert per[len(per) * 9 // 10] < 5e-3, per[len(per) * 9 // 10]
     assert rel_l2(torch.cat(got), torch.cat(want)) < 1.5e-3, rel_l2(torch.cat(got), torch.cat(want))
-    # float64 arbitration of the kink argument: the float64 twin of the (pinned) oracle is the reference BOTH fp32 evaluations
-    # are measured against.  Per tensor the HIP gradient may be at most ARBITRATION_FACTOR x as far from it as the torch-CPU
-    # fp32 oracle is (Winograd convs round differently from MKLDNN's direct ones, so a somewhat different set of kinks flips),
-    # and the flat gradient likewise: a defect in a data-gradient or weight-gradient kernel would sit orders above that.
-    ref64 = O.IRNOracle(3, 84, scale=4, num_coupling=4).double()
-    ref64.load_state_dict({k: v.double() for k, v in ref.state_dict().items()})
-    x64 = x.double().requires_grad_(True)
-    (ref64(x64) * wgt.double()).sum().backward()
-    e_hip, e_cpu = rel_l2(xg.grad, x64.grad), rel_l2(xc.grad, x64.grad)
-    assert e_hip <= ARBITRATION_FACTOR * e_cpu + 2e-6, ('dx', e_hip, e_cpu)
-    g64 = [p.grad.reshape(-1) for p in ref64.parameters()]
-    report = []
-    for (n, _), a_hip, a32, a64 in zip(ref.named_parameters(), got, want, g64):
-        e_hip, e_cpu = rel_l2(a_hip, a64), rel_l2(a32, a64)
-        if e_hip > ARBITRATION_FACTOR * e_cpu + 2e-6:
-            report.append(f'{n}: HIP {e_hip:.2e} vs fp32-CPU {e_cpu:.2e}')
-    e_hip, e_cpu = rel_l2(torch.cat(got), torch.cat(g64)), rel_l2(torch.cat(want), torch.cat(g64))
-    print(f'[float64 arbitration, IRN] flat gradient rel-L2: HIP {e_hip:.2e}, torch-CPU fp32 {e_cpu:.2e}; '
-          f'{len(report)} of {len(g64)} tensors above {ARBITRATION_FACTOR} x')
-    assert not report, report
-    assert e_hip <= ARBITRATION_FACTOR * e_cpu + 2e-6, (e_hip, e_cpu)
+    # (the kink argument is TESTED in tests/test_gpu_gates.py: with the LeakyReLU gates the HIP pass took forced onto the
+    # float64 twin of the oracle, this shape agrees to 1e-4 in max-norm, every tensor)
 
 
 @pytest.mark.parametrize('arch', ['IRN', 'SRF'])
@@ -345,7 +326,7 @@ def test_saved_tensors_outlive_the_weight_gradient_stream(arch):
             del junk
         M.join_side_streams()
         torch.cuda.synchronize()
-        return [p.grad.clone() for p in net.parameters()]
+        return [p.grad.clone() for p in net.parameters() if p.requires_grad]
 
     try:
         base = run(False, False)
@@ -353,5 +334,5 @@ def test_saved_tensors_outlive_the_weight_gradient_stream(arch):
     finally:
         M.USE_SIDE_STREAM[0] = True
     assert all(torch.isfinite(g).all() for g in got)
-    for (n, _), a, b in zip(net.named_parameters(), got, base):
+    for n, a, b in zip([n for n, p in net.named_parameters() if p.requires_grad], got, base):
         assert torch.equal(a, b), n

@@ -8,10 +8,6 @@ import torch
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4
-# float64 arbitration (tests at BASELINE configs[1]'s own shape): per tensor, rel-L2 distance of the HIP gradient to the float64
-# oracle <= FACTOR x the torch-CPU fp32 oracle's own distance to it (+ a floor for tensors both evaluations get to ~1 ulp)
-ARBITRATION_FACTOR = 3.0
-ARBITRATION_FLOOR = 2e-6
 
 
 def relerr(a, b):
@@ -275,30 +271,8 @@ def test_baseline_config_shape_matches_oracle(batch):
         assert rel_l2(flat_g[off:off + n], p.grad.reshape(-1)) < 2e-4, name
         assert relerr(flat_g[off:off + n], p.grad.reshape(-1)) < 2e-3, name
         off += n
-    # float64 arbitration of the gate-flip argument above: the same step through the float64 twin of the oracle (same weights,
-    # frames and latents) is the reference both fp32 evaluations are measured against.  If the HIP path's distance to it is
-    # of the size of the torch-CPU fp32 oracle's own distance, per tensor, the looser max-norm bounds above are flips /
-    # rounding and not a defect in a data-gradient epilogue (a real 1e-3 defect would sit 10x above the CPU's distance).
-    ref64 = O.SRFlowOracle(3, 256, 256, scale=4, num_coupling=4).double()
-    ref64.load_state_dict({k: v.double() for k, v in ref.state_dict().items()})
-    f64, b64, _, _, _ = O.training_step(ref64, hr_c.double(), lr_c.double(), z.double(), lam, opt.lr_dims)
-    assert abs(float(model._logged['train']) / float(f64 + b64) - 1) < RTOL
-    g64 = [p.grad.reshape(-1) for p in ref64.parameters()]
-    g32 = [p.grad.reshape(-1) for p in ref.parameters()]
-    e_hip_flat = rel_l2(flat_g[:ref_g.numel()], torch.cat(g64))
-    e_cpu_flat = rel_l2(ref_g, torch.cat(g64))
-    report, off = [], 0
-    for (name, _), a32, a64 in zip(ref.named_parameters(), g32, g64):
-        n = a32.numel()
-        e_hip, e_cpu = rel_l2(flat_g[off:off + n], a64), rel_l2(a32, a64)
-        off += n
-        if e_hip > ARBITRATION_FACTOR * e_cpu + ARBITRATION_FLOOR:
-            report.append(f'{name}: HIP {e_hip:.2e} vs fp32-CPU {e_cpu:.2e}')
-    assert not report, report
-    assert e_hip_flat <= ARBITRATION_FACTOR * e_cpu_flat + ARBITRATION_FLOOR, (e_hip_flat, e_cpu_flat)
-    print(f'[float64 arbitration, batch {batch}] flat gradient rel-L2: HIP {e_hip_flat:.2e}, torch-CPU fp32 {e_cpu_flat:.2e}')
-    del g64
-    ref64.zero_grad(set_to_none=True)
+    # (the gate-flip argument is TESTED in tests/test_gpu_gates.py: with the gates the HIP pass took forced onto the float64
+    # twin of the oracle, the same shapes agree to the path's 1e-4 in max-norm)
     # input gradients of both directions at this shape (the data-gradient kernels of the first / last block)
     del model, optim
     net = archs.UncondSRFlow(3, 256, 256, opt)
@@ -312,10 +286,6 @@ def test_baseline_config_shape_matches_oracle(batch):
     # input gradients: a flipped gate changes dx in one 3x3 neighbourhood by a whole term -> L2 5e-4, max-norm 2e-2 (the
     # linear kernels themselves hold 1e-4 in max-norm at these shapes: test_conv_kernels_at_baseline_config_shapes)
     assert rel_l2(xg.grad, xc.grad) < 5e-4 and relerr(xg.grad, xc.grad) < 2e-2
-    x64 = hr_c.double().requires_grad_(True)
-    (ref64(x64) * wgt.double()).sum().backward()
-    e_hip, e_cpu = rel_l2(xg.grad, x64.grad), rel_l2(xc.grad, x64.grad)
-    assert e_hip <= ARBITRATION_FACTOR * e_cpu + ARBITRATION_FLOOR, ('dx forward', e_hip, e_cpu)
     zin = torch.cat((lr_c, z), 1)
     zg = zin.cuda().requires_grad_(True); zc = zin.clone().requires_grad_(True)
     w2 = torch.randn(batch, 3, 256, 256, generator=g)
@@ -323,10 +293,6 @@ def test_baseline_config_shape_matches_oracle(batch):
     assert relerr(hg, hc) < RTOL
     (hg * w2.cuda()).sum().backward(); (hc * w2).sum().backward()
     assert rel_l2(zg.grad, zc.grad) < 5e-4 and relerr(zg.grad, zc.grad) < 2e-2
-    z64 = zin.double().requires_grad_(True)
-    (ref64(z64, rev=True) * w2.double()).sum().backward()
-    e_hip, e_cpu = rel_l2(zg.grad, z64.grad), rel_l2(zc.grad, z64.grad)
-    assert e_hip <= ARBITRATION_FACTOR * e_cpu + ARBITRATION_FLOOR, ('dx reverse', e_hip, e_cpu)
     sin_inn_amd.modules.join_side_streams()
 
 

@@ -201,3 +201,47 @@ def test_bayer_bin_oracle_hand_case():
     assert lr.shape == (1, 2, 2, 4)
     assert lr[0, :, :, 0].tolist() == [[35, 55], [3, 5]]          # floor(mean); (1+2+5+6)/4=3.5 -> 3, (3+4+7+9)/4=5.75 -> 5
     assert int(lr[0, :, :, 1:].sum()) == 0
+
+
+def test_forced_gates_with_the_oracles_own_gates_change_nothing():
+    """checker feature used by tests/test_gpu_gates.py: forcing the gates an evaluation took itself reproduces it exactly
+    (outputs and gradients), for the GLOW subnets (ReLU) and the DenseBlock (LeakyReLU 0.2)."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import sininn_oracle as O
+    torch.manual_seed(0)
+    blk = O.GlowBlock(16, 3).double()
+    x = torch.randn(2, 16, 6, 7, dtype=torch.float64)
+    for rev in (False, True):
+        blk.forced_gates = None
+        xa = x.clone().requires_grad_(True)
+        ya = blk(xa, rev=rev)
+        ya.square().sum().backward()
+        x1, x2 = x[:, :8], x[:, 8:]
+        with torch.no_grad():       # inputs of the two subnets in this direction
+            if not rev:
+                in2 = x2; in1 = ya[:, :8]
+            else:
+                in1 = x1; in2 = ya[:, 8:]
+            gates = {'s1': blk.s1[0](in1) > 0, 's2': blk.s2[0](in2) > 0}
+        ga = [p.grad.clone() for p in blk.parameters()]
+        blk.zero_grad(); blk.forced_gates = gates
+        xb = x.clone().requires_grad_(True)
+        yb = blk(xb, rev=rev)
+        yb.square().sum().backward()
+        assert torch.allclose(ya, yb, rtol=0, atol=1e-12) and torch.allclose(xa.grad, xb.grad, rtol=0, atol=1e-10)
+        for a, p in zip(ga, blk.parameters()):
+            assert torch.allclose(a, p.grad, rtol=0, atol=1e-10)
+        blk.zero_grad()
+    dense = O.DenseBlockOracle(8, 4).double()
+    dense.convs[4].weight.data.normal_(0, 0.05)
+    x = torch.randn(2, 8, 5, 6, dtype=torch.float64, requires_grad=True)
+    ya = dense(x)
+    feats, gates = [x.detach()], []
+    with torch.no_grad():
+        for i in range(4):
+            pre = dense.convs[i](torch.cat(feats, 1))
+            gates.append(pre > 0)
+            feats.append(F.leaky_relu(pre, 0.2))
+    dense.forced_gates = gates
+    assert torch.allclose(ya, dense(x), rtol=0, atol=1e-12)
