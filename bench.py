@@ -258,6 +258,10 @@ def main():
     ap.add_argument('--wgrad16', type=int, default=0, help='diagnostic (sininn_wgrad_test_hooks): bit0 16x16x4 tiles, bit1 no Winograd wgrad, bit2 8-row tiles, bit3 8-wave k-split blocks, bit4 per-conv launches, bit5 per-half groups')
     ap.add_argument('--rehearse', action='store_true', help='CPU rehearsal of the multi-rank plumbing (gloo): rendezvous, '
                     'flat-gradient all-reduce, barrier + max-over-ranks timing, rank-0 JSON line; no kernels run, value is null')
+    ap.add_argument('--with-flow', action='store_true', help='BASELINE configs[3] as named ("pair_flow warp + INN at 512x512, bf16"): '
+                    'every step first warps the neighbouring frame of each sample by a resident flow field and takes the photometric '
+                    'metric against the sample (flow_warp_l1, bf16 images / fp32 flow, video-interpolation/trainer.py:61-62) and '
+                    'its gradient w.r.t. the flow, then runs the INN training step on the batch')
     ap.add_argument('--no-overlap', action='store_true', help='diagnostic: single stream (no pass / wgrad overlap)')
     ap.add_argument('--overlap', choices=['auto', 'full', 'wgrad', 'none'], default='auto',
                     help='full: forward / reverse pass chains on two streams + weight gradients on a third (default below 2 M level-0 '
@@ -332,10 +336,43 @@ def main():
     idx_all = torch.randint(lo, hi, (n_calls, b), generator=gen).to(device=dev, dtype=torch.int32)
     calls = [0]
 
+    flow_ev = []            # (start, mid, end) events around the warp's two kernels, single-stream phase only
+    flow_field = None
+    if args.with_flow:
+        from sin_inn_amd.functional import flow_warp_l1
+        # a smooth synthetic flow (what a flow network emits): low-frequency sines, up to ~4 pixels
+        yy, xx = torch.meshgrid(torch.arange(args.height, device=dev, dtype=torch.float32),
+                                torch.arange(args.width, device=dev, dtype=torch.float32), indexing='ij')
+        fx = 3.0 * torch.sin(yy / 37.0) + 1.5 * torch.cos(xx / 23.0)
+        fy = 2.5 * torch.cos(yy / 29.0 + xx / 41.0)
+        flow_field = torch.stack((fx, fy)).unsqueeze(0).repeat(b, 1, 1, 1).contiguous().requires_grad_(True)
+        img_dtype = torch.bfloat16 if args.precision == 'bf16' else torch.float32
+
+    def flow_part(hr, idx, record):
+        # pair_flow: the neighbouring frame of every sample, warped onto the sample by the flow; metric + d metric / d flow
+        hr2, _ = sample_windows(store.hr, store.lr, (idx + 1).clamp_(max=args.frames - args.lr_window - 1), args.lr_window)
+        XX
+        img = hr2.to(dtype=img_dtype, memory_format=torch.contiguous_format)
+        flow_field.grad = None
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if record else None
+        if record:
+            ev[0].record()
+        warped, metric = flow_warp_l1(img, flow_field, tgt)
+        if record:
+            ev[1].record()
+        metric.backward(torch.full_like(metric, 1.0 / metric.numel()))            # d mean(metric) / d flow (the image is data)
+        if record:
+            ev[2].record()
+            flow_ev.append(ev)
+
+    record_flow = [False]
+
     def step():
         idx = idx_all[calls[0] % n_calls]
         calls[0] += 1
         hr, lr = sample_windows(store.hr, store.lr, idx, args.lr_window)
+        if args.with_flow:
+            flow_part(hr, idx, record_flow[0])
         batch = {'hr': hr, 'lr': lr}
         model.training_step([batch, batch], 0)
 
@@ -375,16 +412,32 @@ def main():
         iso.start()
         _l.lib().sininn_profile_classes_begin()
         n_iso = min(3, args.steps)
+        record_flow[0] = True
         t1 = time.perf_counter()
         for _ in range(n_iso):
             step()
         torch.cuda.synchronize()
+        record_flow[0] = False
         iso_ms = (time.perf_counter() - t1) / n_iso * 1e3
         iso.stop()
         classes = class_roofline(args.precision, args.arch)
         for c in classes:
             c['ms_per_step'] = c.pop('ms') / n_iso
             c['launches_per_step'] = c.pop('launches') // n_iso
+        if flow_ev:
+            # HBM rows of the warp (north_star's second fused kernel).  Algorithmic bytes per pixel (e = bytes of an image
+            # element): forward reads img 3e + flow 8 + target 3e, writes warped 3e + metric 4; the flow-only backward reads
+            # img 3e (4 taps, neighbours from cache) + flow 8 + target 3e + warped 3e + gmetric 4 and writes gflow 8.
+            e = 2 if args.precision == 'bf16' else 4
+            px = float(b * args.height * args.width)
+            f_ms = sum(ev[0].elapsed_time(ev[1]) for ev in flow_ev) / len(flow_ev)
+            b_ms = sum(ev[1].elapsed_time(ev[2]) for ev in flow_ev) / len(flow_ev)
+            for name, ms_, byts in (('flow warp + photometric L1 forward (flow_warp_l1_kernel)', f_ms, px * (9 * e + 12)),
+                                    ('flow warp backward w.r.t. the flow (flow_warp_l1_bwd_kernel; + the 1/N fill)', b_ms, px * (9 * e + 20))):
+                gbs = byts / (ms_ * 1e-3) / 1e9
+                classes.append({'class': name, 'ms_per_step': ms_, 'launches_per_step': 1, 'bound': 'hbm', 'alg_bytes': byts,
+                                'achieved_gbs': gbs, 'peak_gbs': PEAK_HBM_GBS, 'frac': gbs / PEAK_HBM_GBS,
+                                'note': f'HIP events on the stream, image element {e} B'})
 
     if rank != 0:
         return
@@ -491,6 +544,9 @@ def main():
                       'baseline_config': args.config, 'height': args.height, 'width': args.width,
                       'global_batch': ws * b, 'num_coupling': args.num_coupling, 'architecture': args.arch, 'parallelism': f'dp{ws}'},
            'roofline': roof}
+    if args.with_flow:
+        out['config']['workload'] += '; preceded in every step by the pair_flow warp + photometric metric + flow gradient on the batch'
+        out['config']['with_flow'] = True
     if args.config != 1 or custom:
         out['metric'] = f'training frames/sec at {args.width}x{args.height} bs={b}' + (' (IRN architecture)' if irn else '')
     if not args.no_cpu_baseline and ws == 1:

@@ -30,9 +30,14 @@ def init_from_env(backend=None):
     os.environ.setdefault('MASTER_PORT', '29500')
     if backend is None:
         backend = os.environ.get('SININN_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+    kw = {}
     if backend == 'nccl':
         torch.cuda.set_device(local_device_index())
-    dist.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=ws)
+        try:        # RCCL's internal stream at high priority: the gradient all-reduce is the tail of every step
+            kw['pg_options'] = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        except (AttributeError, TypeError):
+            pass
+    dist.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=ws, **kw)
     return world()
 
 
@@ -46,12 +51,27 @@ def allreduce_mean_(flat_buffers):
         buf.div_(ws)
 
 
-def allreduce_sum_(flat_buffers):
+def allreduce_sum_(flat_buffers, after=None):
     """In-place SUM of each flat gradient buffer over the ranks; the 1/world factor is folded into the fused Adam launch
-    (sininn_adam_step's grad_scale) instead of a separate pass over the buffer."""
+    (sininn_adam_step's grad_scale) instead of a separate pass over the buffer.
+
+    after: the HIP stream whose queued work produces the buffers (the weight-gradient stream).  The collective is then
+    ordered behind THAT stream only -- it is issued with `after` as the current stream, so RCCL's own (high-priority)
+    communication stream waits for the last weight-gradient kernel and not for whatever else the caller's stream still has
+    in flight (tail of the data-gradient chains, loss logging) -- and the caller's current stream waits for the collective
+    (`work.wait()` is a stream wait, the host does not block).  Adam, launched next on the caller's stream, is thereby
+    ordered after the reduced gradients."""
     _, ws = world()
     if ws == 1:
         return
+    if after is not None and flat_buffers and flat_buffers[0].is_cuda:
+        if dist.get_backend() == 'nccl':
+            with torch.cuda.stream(after):
+                works = [dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True) for buf in flat_buffers]
+            for w in works:
+                w.wait()
+            return
+        torch.cuda.current_stream().wait_stream(after)     # gloo rehearsal on GPU tensors: plain stream order
     for buf in flat_buffers:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
 

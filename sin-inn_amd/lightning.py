@@ -75,11 +75,17 @@ class _OptimizerProxy:
     def step(self, *a, **kw):
         _, ws = sdist.world()
         if ws > 1:
-            if hasattr(self.optimizer, 'flat_grads'):
+            if hasattr(self.optimizer, 'flat_grad_buffers'):
                 # ONE collective on the flat buffer; the mean's 1/world rides on the Adam kernel's gradient scale.
                 # (No bucketing: the forward chain's backward walks the blocks last -> first and the reverse chain's
                 # first -> last, both accumulating into the same buffer, so no block's gradient is final before the tail
                 # of the step -- there is no window to overlap an earlier bucket with.)
+                # Ordered behind the weight-gradient stream alone (its last kernel is already queued: both chains have been
+                # issued), on RCCL's high-priority stream; this stream -- and with it the Adam launch -- waits for the result.
+                bufs, wstream = self.optimizer.flat_grad_buffers()
+                sdist.allreduce_sum_(bufs, after=wstream)
+                kw = dict(kw, grad_scale=kw.get('grad_scale', 1.0) / ws)
+            elif hasattr(self.optimizer, 'flat_grads'):
                 sdist.allreduce_sum_(self.optimizer.flat_grads())
                 kw = dict(kw, grad_scale=kw.get('grad_scale', 1.0) / ws)
             else:

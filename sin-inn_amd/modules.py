@@ -193,6 +193,12 @@ def _side_stream(device):
     return _SIDE[key]
 
 
+def side_stream_if_any(device):
+    """The weight-gradient stream of `device` if the executors are using one (every `+=` into a parameter gradient is then
+    issued on it and nowhere else), else None (weight gradients run on the callers' streams)."""
+    return _SIDE.get(str(device)) if USE_SIDE_STREAM[0] else None
+
+
 def join_side_streams():
     """Make the current stream wait for all outstanding weight-gradient kernels (call before reading .grad)."""
     for st in _SIDE.values():

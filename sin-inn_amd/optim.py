@@ -52,6 +52,12 @@ class FusedAdam(torch.optim.Optimizer):
         join_side_streams()                 # weight-gradient kernels run on a side stream
         return [fl['g'] for fl in self._flat]
 
+    def flat_grad_buffers(self):
+        """The flat gradient buffers WITHOUT joining the weight-gradient stream, and that stream (None if unused): for the
+        data-parallel all-reduce, which orders itself behind it (dist.allreduce_sum_(..., after=stream))."""
+        from .modules import side_stream_if_any
+        return [fl['g'] for fl in self._flat], side_stream_if_any(self._flat[0]['g'].device)
+
     def flat_params(self):
         return [fl['p'] for fl in self._flat]
 

@@ -88,6 +88,24 @@ def main():
     fw = torch.randn(2, 2, 13, 18, generator=g) * 1.5
     bw = -fw + 0.6 * torch.randn(2, 2, 13, 18, generator=g)
     out.update(f6_fw=fw, f6_bw=bw, f6_brox=ref_occ.occlusion_brox(fw, bw, 0.5).to(torch.uint8))
+    # F6b: the same operator on operands that are exactly representable in bf16 (the arithmetic BASELINE configs[3] names for
+    # the warp: bf16 images in HBM, fp32 interpolation).  The reference evaluates in fp32 on those values; the HIP bf16 kernels
+    # must reproduce it up to the rounding of their bf16 OUTPUT (appended after every other draw: earlier arrays are unchanged).
+    def bf(t):
+        return t.to(torch.bfloat16).float()
+    img_b = bf(torch.rand(2, 3, 21, 26, generator=g)).requires_grad_(True)
+    tgt_b = bf(torch.rand(2, 3, 21, 26, generator=g))
+    flow_b = torch.randn(2, 2, 21, 26, generator=g) * 2.0
+    flow_b[0, :, -4:] *= 6
+    flow_b = flow_b.requires_grad_(True)
+    warped_b = resample(img_b, flow_b)
+    warped_q = warped_b + (bf(warped_b) - warped_b).detach()           # what a bf16 consumer reads back (straight-through)
+    metric_b = torch.nn.functional.l1_loss(tgt_b, warped_q, reduction='none').mean(1, True)
+    gw_b = bf(torch.randn(2, 3, 21, 26, generator=g))
+    gm_b = torch.randn(2, 1, 21, 26, generator=g)
+    ((warped_b * gw_b).sum() + (metric_b * gm_b).sum()).backward()
+    out.update(f6b_img=img_b.detach(), f6b_tgt=tgt_b, f6b_flow=flow_b.detach(), f6b_warped=warped_b.detach(),
+               f6b_metric=metric_b.detach(), f6b_gw=gw_b, f6b_gm=gm_b, f6b_gimg=img_b.grad.clone(), f6b_gflow=flow_b.grad.clone())
     np.savez_compressed(os.path.join(HERE, 'golden_flow.npz'),
                         **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in out.items()})
     print('wrote golden_flow.npz with', len(out), 'arrays')

@@ -39,19 +39,22 @@ idx_all = torch.tensor([2, 3, 5, 7])
 mine = idx_all[rank::ws] if ws > 1 else idx_all
 zmine = zs[rank::ws] if ws > 1 else zs
 lit_wrapper._latent = lambda b, zd, h, w, device, temp=1.0: zmine.to(device)
-for step in range(2):
+import time
+steps, delay = int(os.environ.get('DP_STEPS', '2')), float(os.environ.get('DP_DELAY', '0'))
+for step in range(steps):
+    time.sleep(delay * (rank if step %% 2 == 0 else ws - 1 - rank))     # unequal host delays: ranks reach the collective apart
     hr, lr = sample_windows(store.hr.cuda(), store.lr.cuda(), mine.cuda(), 1)
     model.training_step([{'hr': hr, 'lr': lr}, {'hr': hr, 'lr': lr}], 0)
 flat = optim.flat_params()[0].detach().cpu()
-torch.save(flat, os.path.join(%(out)r, f'params_ws{ws}_rank{rank}.pt'))
+torch.save(flat, os.path.join(%(out)r, f'params_ws{ws}_rank{rank}_s{steps}.pt'))
 print('rank', rank, 'of', ws, 'done')
 '''
 
 
-def _run(tmp_path, nproc, port):
+def _run(tmp_path, nproc, port, steps=2, delay=0.0):
     script = tmp_path / f'dp{nproc}.py'
     script.write_text(_DP_SCRIPT % dict(root=ROOT, out=str(tmp_path)))
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0', DP_STEPS=str(steps), DP_DELAY=str(delay))
     if nproc == 1:
         cmd = [sys.executable, str(script)]
     else:
@@ -64,15 +67,25 @@ def _run(tmp_path, nproc, port):
 def test_two_rank_data_parallel_equals_single_process_on_the_global_batch(tmp_path):
     _run(tmp_path, 2, free_port())
     _run(tmp_path, 1, 0)
-    r0 = torch.load(tmp_path / 'params_ws2_rank0.pt')
-    r1 = torch.load(tmp_path / 'params_ws2_rank1.pt')
-    single = torch.load(tmp_path / 'params_ws1_rank0.pt')
+    r0 = torch.load(tmp_path / 'params_ws2_rank0_s2.pt')
+    r1 = torch.load(tmp_path / 'params_ws2_rank1_s2.pt')
+    single = torch.load(tmp_path / 'params_ws1_rank0_s2.pt')
     assert torch.equal(r0, r1)                                   # replicas stay bit-identical
     # mean of per-rank mean-losses == global-batch mean -> same update as one process on all 4 samples
     err = float((r0 - single).abs().max())
     assert err <= 2.5e-4, err                                    # 2 Adam steps of lr 1e-4 (sign-like on noise-level grads)
     big = (single - single.mean()).abs() > 0
     assert float((r0 - single).abs().mean()) < 2e-6
+
+
+def test_replicas_stay_bit_identical_under_unequal_host_delays(tmp_path):
+    """5 steps, the ranks delayed against each other before every step (alternating which one is late): the gradient
+    all-reduce is ordered behind the weight-gradient stream and Adam behind the all-reduce by stream waits alone, so however
+    far apart the hosts are the replicas' weights stay bitwise equal."""
+    _run(tmp_path, 2, free_port(), steps=5, delay=0.05)
+    r0 = torch.load(tmp_path / 'params_ws2_rank0_s5.pt')
+    r1 = torch.load(tmp_path / 'params_ws2_rank1_s5.pt')
+    assert torch.isfinite(r0).all() and torch.equal(r0, r1)
 
 
 def test_infer_writes_frames(tmp_path):

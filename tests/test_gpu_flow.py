@@ -190,6 +190,36 @@ def test_flow_warp_l1_matches_reference_fixture(gold):
     assert relerr(zero, gold['f6_zero_flow_warped']) < RTOL
 
 
+def test_flow_warp_l1_bf16_matches_reference_fixture(gold):
+    """F6b: the flow-warp + photometric-L1 kernels with bf16 I/O (BASELINE configs[3]: "pair_flow warp ... bf16") against the
+    reference's own fp32 evaluation on bf16-representable operands.  Stated budget of this arithmetic: the warped image is
+    stored as bf16 -> one bf16 ulp (2^-8 relative) per value; the metric is taken on the stored value; gradients accumulate in
+    fp32 from bf16 operands, the L1 sign of a residual smaller than its own rounding may flip -> 2e-2 L2."""
+    from sin_inn_amd.functional import flow_warp_l1
+    bf = torch.bfloat16
+    img = gold['f6b_img'].cuda().to(bf).requires_grad_(True)
+    flow = gold['f6b_flow'].cuda().requires_grad_(True)
+    tgt = gold['f6b_tgt'].cuda().to(bf)
+    assert torch.equal(img.detach().float().cpu(), gold['f6b_img'])                     # operands are exactly representable
+    warped, metric = flow_warp_l1(img, flow, tgt)
+    assert warped.dtype == bf and metric.dtype == torch.float32
+    want_w = gold['f6b_warped']
+    ulp = want_w.abs().clamp_min(2.0 ** -126) * 2.0 ** -8
+    assert bool(((warped.float().cpu() - want_w).abs() <= ulp + 1e-7).all())           # within one bf16 ulp, every pixel
+    # the fixture's metric is taken on round_bf16(reference warped); a warped value that rounds the other way moves it by an ulp
+    assert relerr(metric, gold['f6b_metric']) < 2.0 ** -7
+    ((warped.float() * gold['f6b_gw'].cuda()).sum() + (metric * gold['f6b_gm'].cuda()).sum()).backward()
+    rel_l2 = lambda a, b: float((a.double().cpu() - b.double()).norm() / b.double().norm())
+    assert img.grad.dtype == bf and rel_l2(img.grad.float(), gold['f6b_gimg']) < 2e-2
+    assert rel_l2(flow.grad, gold['f6b_gflow']) < 2e-2
+    # flow-only backward (what trainer.py:61-62 needs: the image is data) through the other kernel
+    img2 = gold['f6b_img'].cuda().to(bf)
+    flow2 = gold['f6b_flow'].cuda().requires_grad_(True)
+    w2, m2 = flow_warp_l1(img2, flow2, tgt)
+    ((w2.float() * gold['f6b_gw'].cuda()).sum() + (m2 * gold['f6b_gm'].cuda()).sum()).backward()
+    assert rel_l2(flow2.grad, gold['f6b_gflow']) < 2e-2
+
+
 def test_occlusion_brox_matches_reference_fixture(gold):
     from sin_inn_amd.flowloss import occlusion_brox
     from oracle import sininn_oracle as O

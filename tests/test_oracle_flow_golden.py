@@ -103,6 +103,21 @@ def test_resample2d_and_metric_match_reference(gold):
     assert not torch.allclose(zero, gold['f6_img'], atol=1e-3)           # quirk C-18 is in the fixture
 
 
+def test_flow_warp_oracle_on_bf16_representable_operands_f6b(gold):
+    """F6b: the same operator on bf16-representable images, the metric taken on the warped value rounded to bf16 (what the
+    mixed-precision kernels store): oracle == the reference's own evaluation."""
+    from oracle import sininn_oracle as O
+    img = gold['f6b_img'].clone().requires_grad_(True)
+    flow = gold['f6b_flow'].clone().requires_grad_(True)
+    warped = O.flow_warp(img, flow)
+    metric = O.photometric_l1(gold['f6b_tgt'], O.bf16_round(warped))
+    assert torch.allclose(warped, gold['f6b_warped'], rtol=1e-6, atol=1e-6)
+    assert torch.allclose(metric, gold['f6b_metric'], rtol=1e-6, atol=1e-6)
+    ((warped * gold['f6b_gw']).sum() + (metric * gold['f6b_gm']).sum()).backward()
+    assert torch.allclose(img.grad, gold['f6b_gimg'], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(flow.grad, gold['f6b_gflow'], rtol=1e-5, atol=1e-5)
+
+
 def test_occlusion_brox_matches_reference(gold):
     want = gold['f6_brox'].bool()
     got = FO.occlusion_brox(gold['f6_fw'], gold['f6_bw'], 0.5)
