@@ -262,6 +262,8 @@ def main():
                     'every step first warps the neighbouring frame of each sample by a resident flow field and takes the photometric '
                     'metric against the sample (flow_warp_l1, bf16 images / fp32 flow, video-interpolation/trainer.py:61-62) and '
                     'its gradient w.r.t. the flow, then runs the INN training step on the batch')
+    ap.add_argument('--graph', choices=['on', 'off'], default='off', help='replay the pass chains of a step as one hipGraph '
+                    '(lit_wrapper: captured after 3 eager steps; a refused capture falls back to eager launches)')
     ap.add_argument('--no-overlap', action='store_true', help='diagnostic: single stream (no pass / wgrad overlap)')
     ap.add_argument('--overlap', choices=['auto', 'full', 'wgrad', 'none'], default='auto',
                     help='full: forward / reverse pass chains on two streams + weight gradients on a third (default below 2 M level-0 '
@@ -305,6 +307,9 @@ def main():
     opt = make_opt(args.num_coupling, args.lr_window)
     opt.precision = args.precision
     opt.architecture = args.arch
+    opt.hip_graph = args.graph == 'on'
+    if opt.hip_graph:
+        args.warmup = max(args.warmup, 5)        # 3 eager steps + the capturing one + a replay before the timed region
     irn = args.arch == 'IRN'
     if irn:
         assert args.precision == 'fp32', 'the IRN path is fp32 only'
@@ -351,7 +356,7 @@ def main():
     def flow_part(hr, idx, record):
         # pair_flow: the neighbouring frame of every sample, warped onto the sample by the flow; metric + d metric / d flow
         hr2, _ = sample_windows(store.hr, store.lr, (idx + 1).clamp_(max=args.frames - args.lr_window - 1), args.lr_window)
-        XX
+        tgt = hr.to(dtype=img_dtype, memory_format=torch.contiguous_format)       # planar (B,3,H,W): Resample2d's layout, one pass
         img = hr2.to(dtype=img_dtype, memory_format=torch.contiguous_format)
         flow_field.grad = None
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if record else None
@@ -406,6 +411,7 @@ def main():
     if True:                                                # every rank runs them: the optimiser step holds a collective
         _m.USE_SIDE_STREAM[0] = False
         model.overlap_passes = False
+        model.opt.hip_graph = False                         # the per-class event brackets live in the executors' launch path
         iso = KernelTimer(lh, dev)
         step()                                              # settle on one stream
         barrier()
@@ -544,6 +550,7 @@ def main():
                       'baseline_config': args.config, 'height': args.height, 'width': args.width,
                       'global_batch': ws * b, 'num_coupling': args.num_coupling, 'architecture': args.arch, 'parallelism': f'dp{ws}'},
            'roofline': roof}
+    out['config']['hip_graph'] = bool(args.graph == 'on' and any('graph' in v for v in model.__dict__.get('_graphs', {}).values()))
     if args.with_flow:
         out['config']['workload'] += '; preceded in every step by the pair_flow warp + photometric metric + flow gradient on the batch'
         out['config']['with_flow'] = True

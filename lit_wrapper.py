@@ -164,12 +164,34 @@ class SingleVideoINN(pl.LightningModule):
             ring.pop(0).synchronize()                 # the step `depth` back has finished
         return ring
 
-    def training_step(self, batch, batch_idx):
+    # ---- hipGraph replay of the two pass chains -----------------------------------------------------------------------
+    # One training step issues ~450 launches from Python autograd + the C++ block executors: 5.4-5.7 ms of host time, the
+    # floor that the mixed-precision path at 256x256, IRN at small batches and -- under data parallel -- every rank's
+    # host jitter in front of the collective sit on.  With `hip_graph` on (opt.hip_graph / SININN_GRAPH=1) the step's GPU
+    # work from zeroing the gradients to the last weight-gradient kernel (both pass chains on their two streams + the
+    # weight-gradient stream, forked and joined with events) is captured ONCE per (shapes, precision) after
+    # GRAPH_WARMUP eager steps and replayed afterwards; the batch is copied into static input buffers in front of it.
+    # Eager (never captured): the data-parallel all-reduce, the fused Adam launch and the pack refresh.  Not captured at
+    # all: steps with TCR iterations or MMD terms (host-side randoms / a 16 x 16 Gram finish) -- they run eagerly as before.
+    GRAPH_WARMUP = 3
+
+    def _graph_wanted(self, batch):
         o = self.opt
-        optim = self.optimizers()
-        ring = self._throttle(batch[0]['hr']) if batch[0]['hr'].is_cuda else None
-        optim.zero_grad()
-        hr, lr = batch[0]['hr'], batch[0]['lr']
+        on = getattr(o, 'hip_graph', None)
+        if on is None:
+            on = os.environ.get('SININN_GRAPH', '0') == '1'
+        return bool(on) and batch[0]['hr'].is_cuda and o.lambda_bwd_tcr == 0 and o.lambda_fwd_mmd == 0 and o.lambda_bwd_mmd == 0 \
+            and not getattr(self, '_graph_broken', False)
+
+    def _passes(self, hr, lr, batch, optim, join=True):
+        """zero the gradients; forward pass + loss + backward, reverse pass + loss + backward (two streams when safe),
+        TCR iterations.  Returns the logged loss (a device scalar)."""
+        o = self.opt
+        if join:
+            optim.zero_grad()
+        else:                                          # inside a capture: the weight-gradient stream was joined before it
+            for g in optim.flat_grads_nojoin():
+                g.zero_()
         b, _, h, w = lr.shape
         z = _latent(b, o.z_dims, h, w, hr.device)
         lr_z = _cat_channels(lr, z)
@@ -227,9 +249,62 @@ class SingleVideoINN(pl.LightningModule):
                 tcr_loss = o.lambda_bwd_tcr / iters * loss.reconstruction(tcr_hr_hat, hr_hat_tcr)
                 self.manual_backward(tcr_loss)
                 tcr_loss = tcr_loss.detach()
+        return fwd_loss.detach() + bwd_loss.detach() + tcr_loss
 
+    def _graph_step(self, batch, optim):
+        """Replay (or, once, capture) the pass chains for this batch; returns the loss scalar or None if the step must run
+        eagerly (warm-up, capture refused by the runtime)."""
+        from sin_inn_amd.modules import join_side_streams, side_stream_if_any
+        hr, lr = batch[0]['hr'], batch[0]['lr']
+        from sin_inn_amd.modules import USE_SIDE_STREAM
+        key = (tuple(hr.shape), tuple(lr.shape), tuple(hr.stride()), tuple(lr.stride()), getattr(self.opt, 'precision', 'fp32'),
+               self.overlap_passes, USE_SIDE_STREAM[0])
+        st = self.__dict__.setdefault('_graphs', {}).setdefault(key, {'seen': 0})
+        st['seen'] += 1
+        if 'graph' not in st:
+            if st['seen'] <= self.GRAPH_WARMUP:
+                return None                            # allocator, packs, lazily built maps and events settle eagerly first
+            s_hr, s_lr = torch.empty_strided(hr.shape, hr.stride(), device=hr.device), \
+                torch.empty_strided(lr.shape, lr.stride(), device=lr.device)
+            s_hr.copy_(hr); s_lr.copy_(lr)
+            join_side_streams()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g, capture_error_mode='relaxed'):
+                    out = self._passes(s_hr, s_lr, [{'hr': s_hr, 'lr': s_lr}], optim, join=False)
+                    side = side_stream_if_any(hr.device)
+                    if side is not None:               # the weight-gradient stream forked inside the capture: join it back
+                        torch.cuda.current_stream().wait_stream(side)
+                    out = out.clone()
+            except Exception as e:                     # noqa: BLE001 -- a runtime that refuses the capture must not stop training
+                logging.warning(f'hipGraph capture refused ({type(e).__name__}: {e}); this model continues eagerly')
+                self._graph_broken = True
+                torch.cuda.synchronize()
+                return None
+            st.update(graph=g, hr=s_hr, lr=s_lr, loss=out)
+            logging.info(f'captured the pass chains of a training step as one hipGraph for batch {tuple(hr.shape)}')
+        else:
+            st['hr'].copy_(hr, non_blocking=True); st['lr'].copy_(lr, non_blocking=True)
+            join_side_streams()
+        st['graph'].replay()
+        side = side_stream_if_any(hr.device)
+        if side is not None:
+            # the eager weight-gradient stream saw none of the replayed kernels: order it behind the replay, so that whatever
+            # orders itself behind IT (the data-parallel all-reduce, dist.allreduce_sum_(after=...)) is behind the gradients
+            side.wait_stream(torch.cuda.current_stream())
+        return st['loss']
+
+    def training_step(self, batch, batch_idx):
+        optim = self.optimizers()
+        ring = self._throttle(batch[0]['hr']) if batch[0]['hr'].is_cuda else None
+        total = None
+        if self._graph_wanted(batch) and hasattr(optim, 'flat_grads_nojoin'):
+            total = self._graph_step(batch, optim)
+        if total is None:
+            total = self._passes(batch[0]['hr'], batch[0]['lr'], batch, optim)
         optim.step()
-        self.log('train', (fwd_loss.detach() + bwd_loss.detach() + tcr_loss))
+        self.log('train', total)
         if ring is not None:
             ev = torch.cuda.Event()
             ev.record()                                # on the main stream, behind the optimiser step

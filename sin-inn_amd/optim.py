@@ -52,6 +52,10 @@ class FusedAdam(torch.optim.Optimizer):
         join_side_streams()                 # weight-gradient kernels run on a side stream
         return [fl['g'] for fl in self._flat]
 
+    def flat_grads_nojoin(self):
+        """the flat gradient buffers, no stream join (inside a graph capture the caller has joined already)"""
+        return [fl['g'] for fl in self._flat]
+
     def flat_grad_buffers(self):
         """The flat gradient buffers WITHOUT joining the weight-gradient stream, and that stream (None if unused): for the
         data-parallel all-reduce, which orders itself behind it (dist.allreduce_sum_(..., after=stream))."""

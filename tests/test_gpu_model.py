@@ -416,6 +416,50 @@ def test_training_is_bitwise_reproducible(arch):
     assert abs(l1 - l2) <= 1e-5 * abs(l1)
 
 
+@pytest.mark.parametrize('arch,precision', [('SRF', 'fp32'), ('SRF', 'bf16'), ('IRN', 'fp32')])
+def test_graph_replay_equals_eager_bitwise(arch, precision):
+    """opt.hip_graph: after GRAPH_WARMUP eager steps the pass chains (two pass streams + the weight-gradient stream) are
+    captured as one hipGraph and replayed.  Same kernels, same launch order per stream, same slab-reduce order: six steps
+    with the graph (3 eager, 1 capture + replay, 2 replays) must leave bitwise the weights six eager steps leave, and the
+    logged loss of every step must agree."""
+    import lit_wrapper
+    from data import FrameStore
+    from sin_inn_amd.functional import sample_windows
+
+    def run(graph):
+        torch.manual_seed(5)
+        opt = make_opt(num_coupling=2, lr_window=2, architecture=arch, precision=precision, hip_graph=graph)
+        model = lit_wrapper.SingleVideoINN(3, 64, 64, opt).cuda()
+        optim = model.attach_optimizer()
+        store = FrameStore.synthetic(12, 64, 64).to('cuda')
+        g = torch.Generator().manual_seed(7)
+        zs = [torch.randn(4, 8, 8, opt.z_dims, generator=g).cuda().permute(0, 3, 1, 2) for _ in range(6)]
+        zbuf = torch.empty_like(zs[0])                 # ONE device buffer: a captured step reads the latent from it
+        real = lit_wrapper._latent
+        lit_wrapper._latent = lambda b, zd, h, w, device, temp=1.0: zbuf
+        losses = []
+        try:
+            for i in range(6):
+                idx = torch.randint(2, 10, (4,), generator=g).cuda()
+                hr, lr = sample_windows(store.hr, store.lr, idx, 2)
+                zbuf.copy_(zs[i])
+                model.training_step([{'hr': hr, 'lr': lr}, {'hr': hr, 'lr': lr}], 0)
+                losses.append(float(model._logged['train']))
+        finally:
+            lit_wrapper._latent = real
+        torch.cuda.synchronize()
+        captured = any('graph' in v for v in model.__dict__.get('_graphs', {}).values())
+        return optim.flat_params()[0].clone(), losses, captured
+
+    p_eager, l_eager, cap_e = run(False)
+    p_graph, l_graph, cap_g = run(True)
+    assert not cap_e and cap_g, 'the graph run must actually have captured (a refused capture falls back to eager silently)'
+    assert torch.isfinite(p_graph).all()
+    assert torch.equal(p_eager, p_graph)
+    for a, b in zip(l_eager, l_graph):
+        assert abs(a - b) <= 1e-5 * abs(a)             # the loss scalar is reduced with float atomics
+
+
 def test_training_steps_run_ahead_is_bounded():
     """No call inside a training step synchronises host and GPU (the loader uploads indices pinned + non_blocking), so the
     step itself bounds how far the host may run ahead: at most MAX_STEPS_IN_FLIGHT end-of-step events are outstanding --
