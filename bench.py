@@ -344,7 +344,7 @@ def main():
     flow_ev = []            # (start, mid, end) events around the warp's two kernels, single-stream phase only
     flow_field = None
     if args.with_flow:
-        from sin_inn_amd.functional import flow_warp_l1
+        from sin_inn_amd.functional import flow_warp_l1, sample_pairs
         # a smooth synthetic flow (what a flow network emits): low-frequency sines, up to ~4 pixels
         yy, xx = torch.meshgrid(torch.arange(args.height, device=dev, dtype=torch.float32),
                                 torch.arange(args.width, device=dev, dtype=torch.float32), indexing='ij')
@@ -355,9 +355,7 @@ def main():
 
     def flow_part(hr, idx, record):
         # pair_flow: the neighbouring frame of every sample, warped onto the sample by the flow; metric + d metric / d flow
-        hr2, _ = sample_windows(store.hr, store.lr, (idx + 1).clamp_(max=args.frames - args.lr_window - 1), args.lr_window)
-        tgt = hr.to(dtype=img_dtype, memory_format=torch.contiguous_format)       # planar (B,3,H,W): Resample2d's layout, one pass
-        img = hr2.to(dtype=img_dtype, memory_format=torch.contiguous_format)
+        tgt, img = sample_pairs(store.hr, idx, gap=1, dtype=img_dtype)     # (sample, its neighbour) planar, straight from the u8 clip
         flow_field.grad = None
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if record else None
         if record:

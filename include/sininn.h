@@ -161,6 +161,15 @@ int sininn_conv(const sininn_conv_args* args, void* stream);
 int sininn_conv_pair_k1_supported(const sininn_conv_args* first, const sininn_conv_args* second);
 int sininn_conv_pair_k1(const sininn_conv_args* first, const sininn_conv_args* second, void* stream);
 
+/* The 3x3 twin for passes that keep nothing for a backward (ABI v4): the WHOLE 3x3 conv subnet (subnet_conv, archs.py:11-13) +
+ * affine coupling + log-det of a GLOW half-coupling (archs.py:56-64) in one launch on the mixed-precision path.  `first`:
+ * ksize 3, bf16 weights, fp32 input, mode RELU, 256 output channels, out == NULL (the hidden tile lives in LDS only);
+ * `second`: ksize 3, bf16 weights, Cin 256, mode COUPLE_FWD / COUPLE_INV (same kernel for both directions), Np in {16, 32,
+ * 48, 64, 96, 192}.  Same values as the two sininn_conv launches with a bf16 hidden tensor (one rounding of h to bf16) up to
+ * fp32 summation order.  sininn_glow_forward uses it for dtype == 1, ksize == 3, no_save != 0. */
+int sininn_conv_sub3_supported(const sininn_conv_args* first, const sininn_conv_args* second);
+int sininn_conv_sub3(const sininn_conv_args* first, const sininn_conv_args* second, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Weight gradient: dW[n][c][tap] += sum_pixels dout[pix][n] * in[pix+tap][c], db[n] += sum dout.
  * Split over pixel ranges into slabs in `workspace`, then reduced into OIHW gradients (+=).
@@ -295,7 +304,8 @@ typedef struct sininn_glow_args {
                                             the coupling arithmetic, log-det and all gradients w.r.t. parameters stay fp32 */
   int no_save;                           /* forward: nothing will be differentiated (torch.no_grad passes: validation /
                                             inference, lit_wrapper.py:79-128) -- the saved s and, where the subnet runs as one
-                                            launch (1x1: sininn_conv_pair_k1), the hidden tensor are not written to HBM   */
+                                            launch (1x1: sininn_conv_pair_k1; 3x3 with dtype 1: sininn_conv_sub3), the hidden
+                                            tensor are not written to HBM                                                  */
 } sininn_glow_args;
 
 /* Live timing for bench.py: between begin and end, every forward 3x3 coupling conv (conv2 + affine epilogue) of the
@@ -420,6 +430,12 @@ int sininn_flow_warp_l1_bwd_bf16(const void* img, const float* flow, const void*
 int sininn_sample_windows(const uint8_t* hr_clip, const uint8_t* lr_clip, const int* idx, int n,
                           int T, int H, int W, int h, int w, int win,
                           float* hr_out, const int64_t hs[4], float* lr_out, const int64_t ls[4], void* stream);
+
+/* Frame-pair sampler of the flow path (video-interpolation/trainer.py:49-62 consumes (frame1, frame2) of one clip as planar
+ * (B,3,H,W) tensors): out0[s] = clip[idx[s]] / 255, out1[s] = clip[idx[s] + gap] / 255 (frame index clamped to the clip), planar,
+ * fp32 (bf16 == 0) or bf16 (the arithmetic of BASELINE configs[3]).  clip (T,H,W,3) u8, H*W % 4 == 0.  ABI v4. */
+int sininn_sample_pairs(const uint8_t* hr_clip, const int* idx, int n, int T, int H, int W, int gap,
+                        void* out0, void* out1, int bf16, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * On-device LR synthesis (datasets/prepare.py:35-82,147-165): RGGB sampling + scale x scale binning per Bayer plane

@@ -142,6 +142,8 @@ _SIGS = {
     'sininn_glow_backward': (C.c_int, [C.POINTER(GlowArgs), C.c_void_p, C.c_void_p]),
     'sininn_glow_hidden_gates': (C.c_int, [C.POINTER(GlowArgs), C.c_int, C.c_void_p, C.c_void_p]),
     'sininn_conv_pair_k1_supported': (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs)]),
+    'sininn_conv_sub3_supported': (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs)]),
+    'sininn_conv_sub3': (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs), C.c_void_p]),
     'sininn_conv_pair_k1': (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs), C.c_void_p]),
     'sininn_dense_workspace_bytes': (C.c_size_t, [C.c_int] * 5),
     'sininn_dense_forward': (C.c_int, [C.POINTER(DenseArgs), C.c_void_p]),
@@ -173,6 +175,8 @@ _SIGS = {
                                                C.c_int, c_f, c_f, C.c_void_p]),
     'sininn_sample_windows': (C.c_int, [C.c_void_p, C.c_void_p, c_i, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int, c_f, I64x4, c_f, I64x4, C.c_void_p]),
+    'sininn_sample_pairs': (C.c_int, [C.c_void_p, c_i, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                      C.c_void_p]),
     'sininn_bayer_bin': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'sininn_bayer_demosaic': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'sininn_frames_to_u8': (C.c_int, [c_f, I64x4, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

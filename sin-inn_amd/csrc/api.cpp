@@ -18,6 +18,9 @@ int conv_launch(const sininn_conv_args* a, hipStream_t st);
 int conv_pair_k1_supported(const sininn_conv_args* f, const sininn_conv_args* s);
 int conv_pair_k1_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st);
 void conv_pair_k1_enable(int on);
+int conv_sub3_bf16_supported(const sininn_conv_args* f, const sininn_conv_args* s);
+int conv_sub3_bf16_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st);
+void sub3_fusion_set(int on);
 void conv_set_test_hooks(int force_cfg, int force_ck);
 void wgrad_set_force16(int on);
 size_t wgrad_workspace_bytes(int N, int Cin, int ksize, int B, int H, int W);
@@ -111,6 +114,8 @@ int pack_work_items(const sininn_pack_desc* d);
 int pack_batch_launch(const sininn_pack_desc* descs, int n, int total, hipStream_t st);
 int pack_winograd_launch(const float* w, int N, int Cin, const int* colmap, int Np, float* u_fwd, int Cdp,
                          float* u_dgrad, hipStream_t st);
+int sample_pairs_planar_launch(const uint8_t* clip, const int* idx, int n, int T, int H, int W, int gap, void* out0, void* out1,
+                               int bf16, hipStream_t st);
 int bayer_demosaic_launch(const uint8_t* hr, uint8_t* rgb, int T, int H, int W, int scale, int reduce_sum, hipStream_t st);
 int bayer_bin_launch(const uint8_t* hr, uint8_t* lr, int T, int H, int W, int scale, int reduce_sum, hipStream_t st);
 size_t glow_saved_floats(int B, int H, int W, int C, int dtype);
@@ -218,7 +223,13 @@ int sininn_conv_pair_k1(const sininn_conv_args* first, const sininn_conv_args* s
 /* test hook (not part of the documented surface): force tile configuration / channel chunk */
 void sininn_conv_test_hooks(int force_cfg, int force_ck) { conv_set_test_hooks(force_cfg, force_ck); }
 void sininn_wgrad_test_hooks(int force16) { wgrad_set_force16(force16); }
-void sininn_pair_k1_test_hook(int on) { conv_pair_k1_enable(on); }
+void sininn_pair_k1_test_hook(int on) { conv_pair_k1_enable(on & 1); sub3_fusion_set((on & 2) ? 0 : 1); }   // bit 1: no fused 3x3 subnet
+int sininn_conv_sub3_supported(const sininn_conv_args* first, const sininn_conv_args* second) {
+  return conv_sub3_bf16_supported(first, second);
+}
+int sininn_conv_sub3(const sininn_conv_args* first, const sininn_conv_args* second, void* stream) {
+  return conv_sub3_bf16_launch(first, second, ST(stream));
+}
 
 size_t sininn_wgrad_workspace_bytes(int N, int Cin, int ksize, int B, int H, int W) {
   return wgrad_workspace_bytes(N, Cin, ksize, B, H, W);
@@ -332,6 +343,10 @@ int sininn_sample_windows(const uint8_t* hr_clip, const uint8_t* lr_clip, const 
   return sample_windows_launch(hr_clip, lr_clip, idx, n, T, H, W, h, w, win, hr_out, hs, lr_out, ls, ST(stream));
 }
 
+int sininn_sample_pairs(const uint8_t* hr_clip, const int* idx, int n, int T, int H, int W, int gap, void* out0, void* out1,
+                        int bf16, void* stream) {
+  return sample_pairs_planar_launch(hr_clip, idx, n, T, H, W, gap, out0, out1, bf16, ST(stream));
+}
 int sininn_bayer_demosaic(const uint8_t* hr, uint8_t* rgb, int T, int H, int W, int scale, int reduce_sum, void* stream) {
   return bayer_demosaic_launch(hr, rgb, T, H, W, scale, reduce_sum, ST(stream));
 }

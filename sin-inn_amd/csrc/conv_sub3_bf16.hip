@@ -1,0 +1,257 @@
+// The whole 3x3 conv subnet of a GLOW half-coupling (subnet_conv, archs.py:11-13, wired at archs.py:56-64) and the affine
+// coupling + log-det in ONE launch, for passes that keep nothing for a backward (torch.no_grad: validation / inference,
+// lit_wrapper.py:79-128; sininn_glow_args.no_save) on the mixed-precision path:
+//     h      = bf16(relu(conv3x3(x, W1) + b1))      hidden tile, 256 channels, lives in LDS only
+//     (s, t) = conv3x3(h, W2) + b2                   fp32 accumulation
+//     y      = e(s) v + t  |  (v - t) / e(s)         fp32 coupling epilogue (forward / inverse direction), log-det reduction
+// north_star: "fuses the 3x3 conv subnet, scale/shift and logdet reduction into one kernel with LDS-staged input tiles ...;
+// the inverse pass reuses the same LDS tile" -- the inverse direction is the same kernel with the other epilogue.
+//
+// Block = 4 x 16 output pixels, 256 threads.  The input tile (8 x 20 pixels: halo 2) is staged once, fp32 -> bf16.  Stage 1
+// computes the hidden tile the outputs need, 6 x 18 pixels (halo 1; 108 pixels in four 32-row MFMA tiles, the conv1 work of
+// 1.7 output tiles), wave w owning hidden channels [64 w, 64 w + 64); hidden pixels outside the image are ZERO (they are the
+// second conv's padding, not conv1 of padded input).  Stage 2 walks 9 taps x 256 channels over that tile with the
+// (row tile, 32-column tile) pairs dealt round-robin to the waves, then the shared fp32 epilogue of every conv kernel.
+// Both weight packs stream from L2 as MFMA B operands through a register ring (they are 0.1 - 1.3 MB per subnet).
+// What it saves against the two-launch path: the hidden tensor's HBM write + halo re-read (2 B x 256 ch x pixels, twice) and
+// one launch per half-coupling; what it costs: conv1 on 1.7x the pixels (+23 % MFMA work per subnet).
+#include "conv_bf16_types.h"
+
+namespace sininn {
+
+struct Sub3Dev { ConvDevB a, b; };
+
+constexpr int S3_HID = 256;
+constexpr int S3_HSB = S3_HID * 2 + 16;      // bytes per pixel row of the hidden tile (16 mod 256: conflict-free ds_read_b128)
+constexpr int S3_TH = 4, S3_P = S3_TH * 16, S3_MT2 = S3_P / 32;
+constexpr int S3_HH = S3_TH + 2, S3_HW = 18, S3_HP = S3_HH * S3_HW, S3_MT1 = (S3_HP + 31) / 32;
+constexpr int S3_IH = S3_TH + 4, S3_IW = 20, S3_IP = S3_IH * S3_IW;
+
+template <int BN2, int HT>
+__global__ __launch_bounds__(256, 2) void conv_sub3_bf16_kernel(Sub3Dev q) {
+  constexpr int NT2 = (BN2 + 31) / 32, TILES2 = S3_MT2 * NT2, NI = (TILES2 + 3) / 4, TS = BN2 + 4;
+  const ConvDev& pa = q.a.c;
+  const ConvDev& pb = q.b.c;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_s3[];
+  const int Kp1 = q.a.Kp, XSB = Kp1 * 2 + 16;
+  constexpr int HS_BYTES = S3_HP * S3_HSB, T_BYTES = S3_P * TS * 4;
+  unsigned char* const hs = smem_s3;                                     // [HP][S3_HSB] bf16; later T[P][TS] fp32
+  unsigned char* const xs = smem_s3 + (HS_BYTES > T_BYTES ? HS_BYTES : T_BYTES);   // [IP][XSB] bf16
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5;
+  int bid = blockIdx.x;
+  const int tx = bid % pb.tiles_x; bid /= pb.tiles_x;
+  const int ty = bid % pb.tiles_y;
+  const int b = bid / pb.tiles_y;
+  const int y0 = ty * S3_TH, x0 = tx * 16;
+
+  // ---- stage 0: fp32 input tile (halo 2) -> bf16 in LDS, zero outside the image and beyond Cin ----------------------------
+  {
+    const float* in = static_cast<const float*>(q.a.in);
+    const int q4 = Kp1 / 4;
+    for (int f = tid; f < S3_IP * q4; f += 256) {
+      const int pl = f / q4, c = (f - pl * q4) * 4;
+      const int gy = y0 - 2 + pl / S3_IW, gx = x0 - 2 + pl % S3_IW;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gy >= 0 && gy < pa.H && gx >= 0 && gx < pa.W && c < pa.Cin)      // Cin % 4 == 0 (host check)
+        v = *reinterpret_cast<const f32x4*>(in + ((size_t)(b * pa.H + gy) * pa.W + gx) * pa.in_stride + c);
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[j];
+      *reinterpret_cast<bf16x4*>(xs + pl * XSB + c * 2) = o;
+    }
+  }
+  __syncthreads();
+
+  // ---- stage 1: hidden[HP][256] = relu(conv3x3(in) + b1) on the 6 x 18 hidden pixels the outputs read ----------------------
+  {
+    f32x16 acc[S3_MT1][2];
+#pragma unroll
+    for (int m = 0; m < S3_MT1; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+    int aoff[S3_MT1];                                   // byte offset of this lane's A row (hidden pixel) in the input tile
+#pragma unroll
+    for (int m = 0; m < S3_MT1; ++m) {
+      int p = m * 32 + r;
+      p = p < S3_HP ? p : S3_HP - 1;                    // rows beyond the tile: any valid address, results discarded
+      aoff[m] = ((p / S3_HW) * S3_IW + (p % S3_HW)) * XSB + 16 * h;
+    }
+    const __bf16* wrow = q.a.w + (size_t)(wave * 64 + r) * Kp1 + 8 * h;
+    const int nsteps = Kp1 / 16, J = 9 * nsteps;
+    constexpr int RING = 4;                             // weights requested three k-steps ahead
+    bf16x8 bfr[RING][2];
+    auto load_b = [&](int j, bf16x8 (&dst)[2]) {
+      const int tap = j / nsteps, s = j - tap * nsteps;
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+        dst[n] = *reinterpret_cast<const bf16x8*>(wrow + ((size_t)tap * S3_HID + n * 32) * Kp1 + 16 * s);
+    };
+#pragma unroll
+    for (int j = 0; j < RING - 1; ++j)
+      if (j < J) load_b(j, bfr[j]);
+    for (int j0 = 0; j0 < J; j0 += RING) {
+#pragma unroll
+      for (int u = 0; u < RING; ++u) {
+        const int j = j0 + u;
+        if (j < J) {
+          if (j + RING - 1 < J) load_b(j + RING - 1, bfr[(u + RING - 1) % RING]);
+          const int tap = j / nsteps, s = j - tap * nsteps;
+          const int toff = ((tap / 3) * S3_IW + (tap % 3)) * XSB + 32 * s;
+          bf16x8 af[S3_MT1];
+#pragma unroll
+          for (int m = 0; m < S3_MT1; ++m) af[m] = *reinterpret_cast<const bf16x8*>(xs + aoff[m] + toff);
+#pragma unroll
+          for (int m = 0; m < S3_MT1; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[u][n], acc[m][n], 0, 0, 0);
+        }
+      }
+    }
+    // D: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5); bias + ReLU in fp32, ONE rounding to bf16 (as in the
+    // two-launch path); a hidden pixel outside the image is the second conv's zero padding
+    const float bias0 = pa.bias[wave * 64 + r], bias1 = pa.bias[wave * 64 + 32 + r];
+#pragma unroll
+    for (int m = 0; m < S3_MT1; ++m)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int p = m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (p < S3_HP) {
+          const int gy = y0 - 1 + p / S3_HW, gx = x0 - 1 + p % S3_HW;
+          const bool inimg = gy >= 0 && gy < pa.H && gx >= 0 && gx < pa.W;
+          const float v0 = inimg ? fmaxf(acc[m][0][e] + bias0, 0.f) : 0.f;
+          const float v1 = inimg ? fmaxf(acc[m][1][e] + bias1, 0.f) : 0.f;
+          *reinterpret_cast<__bf16*>(hs + p * S3_HSB + (wave * 64 + r) * 2) = (__bf16)v0;
+          *reinterpret_cast<__bf16*>(hs + p * S3_HSB + (wave * 64 + 32 + r) * 2) = (__bf16)v1;
+        }
+      }
+  }
+  __syncthreads();
+
+  // ---- stage 2: out[P][BN2] = conv3x3(hidden) ; (row tile, 32-column tile) pairs round-robin over the waves ----------------
+  f32x16 acc2[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc2[i][e] = 0.f;
+  {
+    constexpr int NSTEPS = S3_HID / 16, J = 9 * NSTEPS, RING = 4;
+    int aoff2[NI];
+    size_t boff[NI];
+    bool live[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int t = wave + 4 * i, mt = t % S3_MT2, nt = t / S3_MT2;
+      const int qpix = mt * 32 + r;                                    // output pixel of this lane's A row
+      aoff2[i] = ((qpix >> 4) * S3_HW + (qpix & 15)) * S3_HSB + 16 * h;
+      const int colr = nt * 32 + r;
+      live[i] = t < TILES2 && colr < pb.Np;
+      boff[i] = (size_t)(live[i] ? colr : 0) * S3_HID + 8 * h;
+    }
+    bf16x8 bfr[RING][NI];
+    auto load_b = [&](int j, bf16x8 (&dst)[NI]) {
+      const int tap = j >> 4, s = j & 15;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        dst[i] = live[i] ? *reinterpret_cast<const bf16x8*>(q.b.w + (size_t)tap * pb.Np * S3_HID + boff[i] + 16 * s) : z;
+      }
+    };
+#pragma unroll
+    for (int j = 0; j < RING - 1; ++j) load_b(j, bfr[j]);
+#pragma unroll 1
+    for (int j0 = 0; j0 < J; j0 += RING) {
+#pragma unroll
+      for (int u = 0; u < RING; ++u) {
+        const int j = j0 + u;
+        if (j + RING - 1 < J) load_b(j + RING - 1, bfr[(u + RING - 1) % RING]);
+        const int tap = j >> 4, s = j & 15;
+        const int toff = ((tap / 3) * S3_HW + (tap % 3)) * S3_HSB + 32 * s;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          if (wave + 4 * i < TILES2) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(hs + aoff2[i] + toff);
+            acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[u][i], acc2[i], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();                                   // every wave is done reading the hidden tile
+  float* const T = reinterpret_cast<float*>(smem_s3);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int t = wave + 4 * i, mt = t % S3_MT2, nt = t / S3_MT2;
+    const int col = nt * 32 + r;
+    if (t < TILES2 && col < BN2) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) T[(mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * TS + col] = acc2[i][e];
+    }
+  }
+  __syncthreads();
+  __shared__ float red[4];
+  conv_epilogue_tile<S3_TH, BN2, HT, 256>(pb, T, b, y0, x0, 0, tid, red);
+}
+
+template <int BN2, int HT>
+static int sub3_launch(Sub3Dev& q, hipStream_t st) {
+  q.a.c.tiles_x = q.b.c.tiles_x = (q.b.c.W + 15) / 16;
+  q.a.c.tiles_y = q.b.c.tiles_y = (q.b.c.H + S3_TH - 1) / S3_TH;
+  const size_t hs_bytes = (size_t)S3_HP * S3_HSB, t_bytes = (size_t)S3_P * (BN2 + 4) * 4;
+  const size_t lds = (hs_bytes > t_bytes ? hs_bytes : t_bytes) + (size_t)S3_IP * (q.a.Kp * 2 + 16);
+  SININN_CHECK(lds <= 160 * 1024, "conv_sub3_bf16: LDS tiles too large");
+  auto k = conv_sub3_bf16_kernel<BN2, HT>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("conv_sub3_bf16: cannot raise LDS limit to %zu", lds); return 1; }
+  }
+  hipLaunchKernelGGL(k, dim3(q.b.c.tiles_x * q.b.c.tiles_y * q.b.c.B), dim3(256), lds, st, q);
+  SININN_LAUNCH_CHECK("conv_sub3_bf16");
+  return 0;
+}
+
+static int g_sub3_enabled = 1;                         // test hook (sininn_pair_k1_test_hook bit 1 clears it): A/B against two launches
+bool sub3_fusion_enabled() { return g_sub3_enabled != 0; }
+void sub3_fusion_set(int on) { g_sub3_enabled = on; }
+
+// 1 when (first, second) is a 3x3 subnet this kernel runs: first = fp32 input -> 256 hidden channels (RELU, bf16 weights, no
+// hidden store: first->out == NULL), second = hidden -> fp32 coupling epilogue (COUPLE_FWD / COUPLE_INV, bf16 weights)
+int conv_sub3_bf16_supported(const sininn_conv_args* f, const sininn_conv_args* s) {
+  if (!f || !s || !f->w_bf16 || !s->w_bf16) return 0;
+  if (f->ksize != 3 || s->ksize != 3 || f->winograd || s->winograd) return 0;
+  if (f->in_bf16 || !f->out_bf16 || !s->in_bf16 || s->out_bf16) return 0;
+  if (f->mode != SININN_CONV_RELU || f->out != nullptr) return 0;
+  if (f->in_group_stride > 0 || f->out_group_stride > 0 || s->in_group_stride > 0 || s->out_group_stride > 0) return 0;
+  if (f->Np != S3_HID || f->N != S3_HID || s->Cin != S3_HID) return 0;
+  if (f->Cin % 8 != 0 || f->Cin > 192) return 0;
+  if (f->B != s->B || f->H != s->H || f->W != s->W) return 0;
+  if (!(s->mode == SININN_CONV_COUPLE_FWD || s->mode == SININN_CONV_COUPLE_INV)) return 0;
+  if (s->col_tile == 32) return s->Np == 64 || s->Np == 192 || s->Np == 96 || s->Np == 32;
+  return s->Np == 16 || s->Np == 32 || s->Np == 48 || s->Np == 64 || s->Np == 96 || s->Np == 192;
+}
+
+int conv_sub3_bf16_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st) {
+  SININN_CHECK(conv_sub3_bf16_supported(f, s), "conv_sub3_bf16: unsupported subnet (3x3, bf16 weights, fp32 input, no hidden store, coupling epilogue)");
+  Sub3Dev q;
+  sininn_conv_args fa = *f;
+  alignas(16) __bf16 dummy[8] = {};                    // conv_bf16_prepare insists on an output / input pointer; neither is
+  fa.out = reinterpret_cast<float*>(dummy); fa.out_stride = S3_HID;     // dereferenced: the hidden tile lives in LDS
+  if (int rc = conv_bf16_prepare(&fa, q.a)) return rc;
+  q.a.out_b = nullptr;
+  sininn_conv_args sa = *s;
+  sa.in = f->in; sa.in_stride = S3_HID;
+  if (int rc = conv_bf16_prepare(&sa, q.b)) return rc;
+  const bool ht16 = s->col_tile == 32;
+#define SUB3_CASE(BN) case BN: return ht16 ? sub3_launch<BN, 16>(q, st) : sub3_launch<BN, 8>(q, st)
+  switch (s->Np) {
+    SUB3_CASE(16); SUB3_CASE(32); SUB3_CASE(48); SUB3_CASE(64); SUB3_CASE(96); SUB3_CASE(192);
+    default: set_error("conv_sub3_bf16: unsupported Np=%d", s->Np); return 1;
+  }
+#undef SUB3_CASE
+}
+
+}  // namespace sininn

@@ -15,6 +15,9 @@ namespace sininn {
 int conv_launch(const sininn_conv_args* a, hipStream_t st);
 int conv_pair_k1_supported(const sininn_conv_args* f, const sininn_conv_args* s);
 int conv_pair_k1_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st);
+int conv_sub3_bf16_supported(const sininn_conv_args* f, const sininn_conv_args* s);
+int conv_sub3_bf16_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st);
+bool sub3_fusion_enabled();
 size_t wgrad_workspace_bytes(int N, int Cin, int ksize, int B, int H, int W);
 int wgrad_launch(const float* in, int in_stride, int Cin, const float* dout, int dout_stride, int N, int B, int H, int W,
                  int ksize, float* gw, float* gb, void* ws, size_t ws_bytes, hipStream_t st);
@@ -340,6 +343,17 @@ int glow_forward(const sininn_glow_args* a, hipStream_t st) {
     if (bf16) { c2.winograd = 0; c2.w_bf16 = 1; c2.in_bf16 = 1; }                       // h bf16 -> fp32 coupling epilogue
     if (gm) { c2.in_stride = 8; c2.in_group_stride = (int)(M * 8); }
     if (a->no_save) c2.sbuf = nullptr;               // s is kept for the backward pass only
+    // 3x3 subnets of a no-grad pass on the mixed-precision path: conv1 -> conv2 -> coupling + log-det in ONE launch, the hidden
+    // tile never leaves LDS (conv_sub3_bf16.hip; north_star's single fused coupling kernel)
+    if (a->no_save && bf16 && a->ksize == 3 && sub3_fusion_enabled()) {
+      sininn_conv_args f1 = c1;
+      f1.out = nullptr;
+      if (conv_sub3_bf16_supported(&f1, &c2)) {
+        ClassScope sc(PC_COUPLE, a->ksize, conv_flops(M, a->ksize, c1.Cin, SININN_HIDDEN) + conv_flops(M, a->ksize, SININN_HIDDEN, 2 * h.co), st);
+        if (int rc = conv_sub3_bf16_launch(&f1, &c2, st)) return rc;
+        continue;
+      }
+    }
     // 1x1 subnets (fp32): both convs in one launch, the hidden tile stays in LDS between them (conv_pair_k1.hip)
     if (conv_pair_k1_supported(&c1, &c2)) {
       if (a->no_save) c1.out = nullptr;              // ... and then the hidden tensor never reaches HBM

@@ -211,6 +211,55 @@ bool sample_windows_dense_try(const uint8_t* hr_clip, const uint8_t* lr_clip, co
   return true;
 }
 
+// Frame-pair sampler of the flow path (video-interpolation/: the trainer consumes (frame1, frame2) pairs of one clip as planar
+// (B,3,H,W) tensors, trainer.py:49-62): out[s][c][y][x] = clip[idx[s] + offset][y][x][c] / 255 for BOTH frames of a pair
+// (offset 0 -> out0, offset `gap` -> out1) straight from the resident uint8 clip, as fp32 or bf16 (BASELINE configs[3]).  One
+// thread per 4 consecutive pixels of a row: 12 contiguous clip bytes in (three dwords), one 16- / 8-byte store per plane out.
+template <typename T>
+__global__ void sample_pairs_planar_kernel(const uint8_t* __restrict__ clip, const int* __restrict__ idx, int n, int Tn, int64_t HW,
+                                           int gap, T* __restrict__ out0, T* __restrict__ out1) {
+  const int64_t quads = HW / 4;                                             // host: H*W % 4 == 0
+  const int64_t total = (int64_t)n * 2 * quads;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t qd = i % quads;
+    const int which = (int)((i / quads) & 1);
+    const int s = (int)(i / (2 * quads));
+    int t = idx[s] + (which ? gap : 0);
+    t = t < 0 ? 0 : (t >= Tn ? Tn - 1 : t);
+    const unsigned* src = reinterpret_cast<const unsigned*>(clip + ((int64_t)t * HW + qd * 4) * 3);
+    const unsigned w0 = src[0], w1 = src[1], w2 = src[2];
+    unsigned char by[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { by[k] = (w0 >> (8 * k)) & 255u; by[4 + k] = (w1 >> (8 * k)) & 255u; by[8 + k] = (w2 >> (8 * k)) & 255u; }
+    T* dst = (which ? out1 : out0) + (int64_t)s * 3 * HW + qd * 4;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      T v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = (T)((float)by[3 * k + c] / 255.f);
+      if constexpr (sizeof(T) == 4) *reinterpret_cast<f32x4*>(dst + c * HW) = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+      else *reinterpret_cast<uint2*>(dst + c * HW) = *reinterpret_cast<const uint2*>(v);
+    }
+  }
+}
+
+int sample_pairs_planar_launch(const uint8_t* clip, const int* idx, int n, int T, int H, int W, int gap, void* out0, void* out1,
+                               int bf16, hipStream_t st) {
+  SININN_CHECK(clip && idx && out0 && out1 && n > 0 && T > 0 && H > 0 && W > 0, "sample_pairs: bad arguments");
+  const int64_t HW = (int64_t)H * W;
+  SININN_CHECK(HW % 4 == 0 && aligned16(clip) && aligned16(out0) && aligned16(out1), "sample_pairs: H*W %% 4 == 0 and 16-byte aligned buffers");
+  const int64_t total = (int64_t)n * 2 * (HW / 4);
+  const int64_t blocks = (total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384;
+  if (bf16)
+    hipLaunchKernelGGL(sample_pairs_planar_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, st, clip, idx, n, T, HW, gap,
+                       static_cast<__bf16*>(out0), static_cast<__bf16*>(out1));
+  else
+    hipLaunchKernelGGL(sample_pairs_planar_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, clip, idx, n, T, HW, gap,
+                       static_cast<float*>(out0), static_cast<float*>(out1));
+  SININN_LAUNCH_CHECK("sample_pairs");
+  return 0;
+}
+
 // out[m][c] = c < C ? in[m][c] : 0 for c < Cpad (C, Cpad multiples of 4): a channel slice into a padded buffer
 __global__ void copy_channels_kernel(const float* __restrict__ in, int in_stride, float* __restrict__ out, int out_stride,
                                      int64_t M, int C4, int Cpad4) {

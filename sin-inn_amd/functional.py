@@ -153,6 +153,23 @@ def flow_warp_l1(img, flow, target=None):
     return _FlowWarpL1.apply(img, flow, target)
 
 
+def sample_pairs(hr_clip, idx, gap=1, dtype=torch.float32):
+    """Frame pairs of the flow path (video-interpolation/trainer.py:49-62) from the resident uint8 clip (T,H,W,3): returns
+    (clip[idx] / 255, clip[idx + gap] / 255) as planar (n,3,H,W) tensors, fp32 or bf16."""
+    from . import _lib
+    assert hr_clip.dtype == torch.uint8 and hr_clip.dim() == 4 and hr_clip.shape[-1] == 3 and hr_clip.is_contiguous()
+    assert dtype in (torch.float32, torch.bfloat16) and idx.dtype == torch.int32
+    if not hr_clip.is_cuda:
+        raise NotImplementedError('sin-inn_amd ops run on the GPU only (got a CPU tensor)')
+    t, h, w, _ = hr_clip.shape
+    n = idx.numel()
+    a = torch.empty((n, 3, h, w), device=hr_clip.device, dtype=dtype)
+    b = torch.empty_like(a)
+    _lib.check(_lib.lib().sininn_sample_pairs(hr_clip.data_ptr(), idx.data_ptr(), n, t, h, w, int(gap), a.data_ptr(), b.data_ptr(),
+                                              int(dtype == torch.bfloat16), ops._stream()))
+    return a, b
+
+
 def sample_windows(hr_clip, lr_clip, idx, lr_window):
     """data.py:31-45 on an HBM-resident uint8 clip.  Returns hr (n,3,H,W) and lr (n,(2w+1)*4,h,w), both stored
     pixel-major (channels_last views)."""

@@ -275,3 +275,89 @@ def test_bf16_backward_at_config4_shape():
     assert rel_l2(zg.grad, zc.grad) < 5e-2
     for (n, pg), (_, pc) in zip(net.named_parameters(), emu.named_parameters()):
         assert rel_l2(pg.grad, pc.grad) < 5e-2, (n, rel_l2(pg.grad, pc.grad))
+
+
+@pytest.mark.parametrize('rev', [False, True])
+@pytest.mark.parametrize('channels,hw', [(48, (13, 21)), (192, (6, 18)), (48, (64, 64)), (192, (9, 33)), (96, (4, 16))])
+def test_fused_3x3_subnet_matches_the_two_launch_path(rev, channels, hw):
+    """north_star's single fused coupling kernel (conv_sub3_bf16.hip, sininn_conv_sub3): in a no-grad pass on the mixed-
+    precision path a 3x3 subnet + affine coupling + log-det is ONE launch with the hidden tile in LDS.  Against the same block
+    through the two-launch path (bf16 hidden tensor in HBM): the hidden values are rounded to bf16 once in both, from fp32 sums
+    accumulated in another order -> a value next to a rounding boundary lands one bf16 ulp apart in a few channels (budget
+    3e-3 of the max-norm, as for the fused 1x1 pair); ragged image sizes (tiles cut by the border in x and y), both coupling
+    widths (24 | 24: 16-column interleave, 96 | 96: 32-column), both directions; and against the oracle's bf16 emulation."""
+    import archs
+    import sin_inn_amd as S
+    from sin_inn_amd import _lib
+    from oracle import sininn_oracle as O
+    torch.manual_seed(channels + hw[0])
+    h, w = hw
+    blk = S.GLOWCouplingBlock([(channels, h, w)], subnet_constructor=archs.subnet_conv, clamp=1.2)
+    emu = O.GlowBlock(channels, 3, 1.2)
+    emu.load_state_dict({k: v.clone() for k, v in blk.state_dict().items()})
+    emu.emulate_bf16 = True
+    for net in (blk, emu):
+        for p in net.parameters():
+            p.data.mul_(3.0)
+    blk.cuda()
+    blk.precision = 'bf16'
+    x = torch.randn(2, channels, h, w)
+    res = []
+    try:
+        for hook in (1, 3):                      # 1: fused 3x3 subnet (default); 3: bit 1 set -> two launches
+            _lib.lib().sininn_pair_k1_test_hook(hook)
+            with torch.no_grad():
+                y = blk([x.cuda()], rev=rev)[0]
+            res.append((y.clone(), blk.last_jac.clone()))
+    finally:
+        _lib.lib().sininn_pair_k1_test_hook(1)
+    (y_f, ld_f), (y_2, ld_2) = res
+    assert relerr(y_f, y_2) < 3e-3 and relerr(ld_f, ld_2) < 3e-3
+    with torch.no_grad():
+        y_e = emu(x, rev=rev)
+    assert relerr(y_f, y_e) < 2e-2 and rel_l2(y_f, y_e) < 3e-3
+    assert relerr(ld_f, emu.last_jac) < 2e-2
+    # the differentiable pass (two launches, hidden tensor saved) and the fused no-grad pass agree too
+    yg = blk([x.cuda().requires_grad_(True)], rev=rev)[0]
+    assert relerr(y_f, yg) < 3e-3
+
+
+def test_fused_3x3_subnet_through_the_c_abi():
+    """sininn_conv_sub3 with raw descriptors against sininn_conv(first) + sininn_conv(second) on the same packs."""
+    import ctypes as C
+    import sin_inn_amd
+    from sin_inn_amd import ops, _lib
+    torch.manual_seed(3)
+    lib = _lib.lib()
+    b, h, w, cin, co = 2, 11, 37, 24, 24
+    dev = torch.device('cuda')
+    c1 = torch.nn.Conv2d(cin, 256, 3, padding=1).cuda()
+    c2 = torch.nn.Conv2d(256, 2 * co, 3, padding=1).cuda()
+    cmap = ops.coupling_colmap(co, dev)
+    w1, b1, _ = ops.pack_conv_bf16(c1.weight.detach().contiguous(), c1.bias.detach().contiguous(), None, False)
+    w2, b2, _ = ops.pack_conv_bf16(c2.weight.detach().contiguous(), c2.bias.detach().contiguous(), cmap, False)
+    x = torch.randn(b, h, w, cin, device=dev)
+    v = torch.randn(b, h, w, co, device=dev)
+    outs = []
+    for fused in (True, False):
+        hid = torch.empty(b, h, w, 256, device=dev, dtype=torch.bfloat16)
+        out = torch.zeros(b, h, w, co, device=dev)
+        ld = torch.zeros(b, device=dev)
+        f = _lib.ConvArgs(inp=x.data_ptr(), in_stride=cin, Cin=cin, w=w1.data_ptr(), bias=b1.data_ptr(), Np=256, B=b, H=h, W=w,
+                          ksize=3, mode=_lib.CONV_RELU, out=None if fused else hid.data_ptr(), out_stride=256, N=256,
+                          w_bf16=1, in_bf16=0, out_bf16=1)
+        s = _lib.ConvArgs(inp=hid.data_ptr(), in_stride=256, Cin=256, w=w2.data_ptr(), bias=b2.data_ptr(), Np=2 * co, B=b, H=h, W=w,
+                          ksize=3, mode=_lib.CONV_COUPLE_FWD, out=out.data_ptr(), out_stride=co, N=co, v=v.data_ptr(), v_stride=co,
+                          logdet=ld.data_ptr(), Co=co, clamp=1.2, col_tile=ops.coupling_tile(co), w_bf16=1, in_bf16=1)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if fused:
+            assert lib.sininn_conv_sub3_supported(C.byref(f), C.byref(s)) == 1
+            _lib.check(lib.sininn_conv_sub3(C.byref(f), C.byref(s), st))
+        else:
+            _lib.check(lib.sininn_conv(C.byref(f), st))
+            _lib.check(lib.sininn_conv(C.byref(s), st))
+        outs.append((out, ld))
+    assert relerr(outs[0][0], outs[1][0]) < 3e-3 and relerr(outs[0][1], outs[1][1]) < 3e-3
+    # a first conv that stores its hidden tensor is not this kernel's case
+    f.out = outs[0][0].data_ptr()
+    assert lib.sininn_conv_sub3_supported(C.byref(f), C.byref(s)) == 0

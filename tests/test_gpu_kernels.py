@@ -551,3 +551,19 @@ def test_conv_pair_c_abi_matches_two_launches(env, co, hw):
               N=256, B=b, H=h, W=w, ksize=3)
     s1 = args(in_=ops.ptr(x), in_stride=256, Cin=256, w=ops.ptr(w2), Np=2 * co, mode=_lib.CONV_LINEAR, B=b, H=h, W=w, ksize=1)
     assert lib.sininn_conv_pair_k1_supported(C.byref(f3), C.byref(s1)) == 0
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_sample_pairs_planar_is_bit_exact(dtype):
+    """frame-pair sampler of the flow path: (clip[idx], clip[idx + gap]) / 255 as planar (n,3,H,W), fp32 bit-exact with the
+    reference's FloatTensor / 255 (true division), bf16 = the correctly rounded value of that; indices past the clip clamp."""
+    from sin_inn_amd.functional import sample_pairs
+    g = torch.Generator().manual_seed(3)
+    clip = torch.randint(0, 256, (9, 12, 20, 3), generator=g, dtype=torch.uint8)
+    idx = torch.tensor([0, 4, 7, 8, 3], dtype=torch.int32)
+    for gap in (1, 2):
+        a, b = sample_pairs(clip.cuda(), idx.cuda(), gap=gap, dtype=dtype)
+        want_a = (clip[idx.long()].float() / 255.).permute(0, 3, 1, 2)
+        want_b = (clip[(idx.long() + gap).clamp(max=8)].float() / 255.).permute(0, 3, 1, 2)
+        assert a.dtype == dtype and a.is_contiguous() and a.shape == (5, 3, 12, 20)
+        assert torch.equal(a.cpu(), want_a.to(dtype)) and torch.equal(b.cpu(), want_b.to(dtype))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates every measured artifact under profiles/ for the current build (run on the GPU box through gpurun; the raw
 # rocprofv3 output directories are summarised on the box and deleted, only the small summaries travel back):
-#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r02'
+#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r03'
 # then copy gpurun_out/<tag>_refresh/* into profiles/.
 set -u
 TAG=${1:-rXX}
@@ -28,6 +28,21 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/fetch" -- python3 bench.py
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/write" -- python3 bench.py --no-overlap --steps 2 --warmup 1 --no-cpu-baseline > "$O/write.log" 2>&1 || exit 1
 python tools/pmc_traffic.py "$O/fetch" "$O/write" "wino_kernel<2, 8, 2>" 131072 > "$O/traffic_dominant.json"
 rm -rf "$O/fetch" "$O/write"
+
+step "configs[3] / configs[4] (mixed precision): single-stream kernel traces + PMC traffic of their dominant kernel"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace3" -- python3 bench.py --config 3 --steps 4 --warmup 2 --no-cpu-baseline --no-overlap > "$O/trace3.log" 2>&1 || exit 1
+python tools/prof_by_grid.py "$O/trace3" > "$O/${TAG}_cfg3_single_stream_by_grid.csv"
+rm -rf "$O/trace3"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace4" -- python3 bench.py --config 4 --steps 2 --warmup 2 --no-cpu-baseline --no-overlap > "$O/trace4.log" 2>&1 || exit 1
+python tools/prof_by_grid.py "$O/trace4" > "$O/${TAG}_cfg4_single_stream_by_grid.csv"
+cp "$(find "$O/trace4" -name '*kernel_stats.csv' | head -1)" "$O/${TAG}_cfg4_kernel_stats.csv"
+rm -rf "$O/trace4"
+for CFG in 3 4; do
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/fetch$CFG" -- python3 bench.py --config $CFG --no-overlap --steps 1 --warmup 1 --no-cpu-baseline > "$O/fetch$CFG.log" 2>&1 || exit 1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/write$CFG" -- python3 bench.py --config $CFG --no-overlap --steps 1 --warmup 1 --no-cpu-baseline > "$O/write$CFG.log" 2>&1 || exit 1
+  python tools/pmc_traffic.py "$O/fetch$CFG" "$O/write$CFG" "conv_bf16_kernel<3, 32, 8, true" auto > "$O/traffic_dominant_cfg$CFG.json"
+  rm -rf "$O/fetch$CFG" "$O/write$CFG"
+done
 
 step "bench lines (configs[3] / [4] are better re-measured in a call of their own: right after the profiler passes they read 8-25 % slow)"
 python bench.py --steps 20 --warmup 5 > "$O/${TAG}_bench_cfg1.json" 2> "$O/bench_cfg1.err" || exit 1
