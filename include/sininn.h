@@ -75,6 +75,11 @@ typedef struct sininn_pack_desc {
   const float* w; const float* bias; int N, Cin, ksize; const int* colmap; int Np;
   float* w_fwd; float* b_fwd; int Cdp; float* w_dgrad; int wino_fwd, wino_dgrad;
   int work_begin;
+  /* ABI v4, zero = as before.  N / Cin above are the PACKED dimensions; the source weight may be smaller: src_n outputs
+   * (0 = N; packed outputs beyond it are zero) and Cin - gap_len input channels, the packed input channels [gap_begin,
+   * gap_begin + gap_len) being zero padding it does not have (IRN DenseBlock: channel_in padded to a multiple of 8 inside
+   * the feature buffer, archs.py:74-98).  Lets every pack of an IRN model join the one batched refresh launch. */
+  int src_n, gap_begin, gap_len;
 } sininn_pack_desc;
 int sininn_pack_work_items(const sininn_pack_desc* host_desc);
 int sininn_pack_batch(const sininn_pack_desc* descs, int n, int total_work, void* stream);

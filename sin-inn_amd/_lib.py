@@ -90,7 +90,8 @@ class PackDesc(C.Structure):
     """Mirror of sininn_pack_desc."""
     _fields_ = [('w', c_f), ('bias', c_f), ('N', C.c_int), ('Cin', C.c_int), ('ksize', C.c_int), ('colmap', c_i),
                 ('Np', C.c_int), ('w_fwd', c_f), ('b_fwd', c_f), ('Cdp', C.c_int), ('w_dgrad', c_f),
-                ('wino_fwd', C.c_int), ('wino_dgrad', C.c_int), ('work_begin', C.c_int)]
+                ('wino_fwd', C.c_int), ('wino_dgrad', C.c_int), ('work_begin', C.c_int),
+                ('src_n', C.c_int), ('gap_begin', C.c_int), ('gap_len', C.c_int)]
 
 
 CONV_RELU, CONV_COUPLE_FWD, CONV_COUPLE_INV, CONV_MASK, CONV_ADD, CONV_LINEAR = range(6)

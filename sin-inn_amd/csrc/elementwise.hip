@@ -1124,6 +1124,19 @@ int pack_work_items(const sininn_pack_desc* d) {
   return nf + nd + nb;
 }
 
+// source element of packed (output nn, input channel c, tap t): the descriptor's N / Cin are the PACKED dimensions; the
+// source weight has src_n <= N outputs (0 = N) and Cin - gap_len input channels, the packed channels [gap_begin, gap_begin +
+// gap_len) being zero padding with no counterpart in it (IRN DenseBlock feature buffer, cin padded to a multiple of 8)
+__device__ __forceinline__ float pack_src(const sininn_pack_desc& d, int nn, int c, int t, int taps) {
+  int sc = c;
+  if (d.gap_len > 0) {
+    if (c >= d.gap_begin + d.gap_len) sc = c - d.gap_len;
+    else if (c >= d.gap_begin) return 0.f;
+  }
+  if (nn >= (d.src_n > 0 ? d.src_n : d.N)) return 0.f;
+  return d.w[((size_t)nn * (d.Cin - d.gap_len) + sc) * taps + t];
+}
+
 __global__ void pack_batch_kernel(const sininn_pack_desc* __restrict__ descs, int n, int total) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
@@ -1144,14 +1157,14 @@ __global__ void pack_batch_kernel(const sininn_pack_desc* __restrict__ descs, in
       const int nn = d.colmap ? d.colmap[q] : q;
       const bool ok = nn >= 0 && nn < d.N;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) g[t] = ok ? d.w[((size_t)nn * d.Cin + c) * 9 + t] : 0.f;
+      for (int t = 0; t < 9; ++t) g[t] = ok ? pack_src(d, nn, c, t, 9) : 0.f;
       wino_filter(g, u);
 #pragma unroll
       for (int pz = 0; pz < 16; ++pz) d.w_fwd[(((size_t)pz * (d.Cin / 8) + c / 8) * d.Np + q) * 8 + (c & 7)] = u[pz];
     } else {
       const int c = k % d.Cin, q = (k / d.Cin) % d.Np, t = k / (d.Cin * d.Np);
       const int nn = d.colmap ? d.colmap[q] : q;
-      d.w_fwd[k] = (nn >= 0 && nn < d.N) ? d.w[((size_t)nn * d.Cin + c) * taps + t] : 0.f;
+      d.w_fwd[k] = (nn >= 0 && nn < d.N) ? pack_src(d, nn, c, t, taps) : 0.f;
     }
     return;
   }
@@ -1161,20 +1174,20 @@ __global__ void pack_batch_kernel(const sininn_pack_desc* __restrict__ descs, in
       const int nn = k % d.N, c = k / d.N;
       const bool ok = c < d.Cin;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) g[t] = ok ? d.w[((size_t)nn * d.Cin + c) * 9 + (8 - t)] : 0.f;
+      for (int t = 0; t < 9; ++t) g[t] = ok ? pack_src(d, nn, c, 8 - t, 9) : 0.f;
       wino_filter(g, u);
 #pragma unroll
       for (int pz = 0; pz < 16; ++pz) d.w_dgrad[(((size_t)pz * (d.N / 8) + nn / 8) * d.Cdp + c) * 8 + (nn & 7)] = u[pz];
     } else {
       const int nn = k % d.N, c = (k / d.N) % d.Cdp, t = k / (d.N * d.Cdp);
-      d.w_dgrad[k] = (c < d.Cin) ? d.w[((size_t)nn * d.Cin + c) * taps + (taps - 1 - t)] : 0.f;
+      d.w_dgrad[k] = (c < d.Cin) ? pack_src(d, nn, c, taps - 1 - t, taps) : 0.f;
     }
     return;
   }
   k -= nd;
   if (k < nb) {
     const int nn = d.colmap ? d.colmap[k] : k;
-    d.b_fwd[k] = (d.bias && nn >= 0 && nn < d.N) ? d.bias[nn] : 0.f;
+    d.b_fwd[k] = (d.bias && nn >= 0 && nn < (d.src_n > 0 ? d.src_n : d.N)) ? d.bias[nn] : 0.f;
   }
 }
 

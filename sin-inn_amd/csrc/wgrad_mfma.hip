@@ -330,14 +330,18 @@ __global__ __launch_bounds__(256, 2) void wgrad32_kernel(WgradDev p) {
 //   cols = c, k = 4 Winograd tiles.  Block = 64 n x 32 c, waves 2 x 2, wave tile 32 n x 16 c x 16 positions
 //   (128 accumulator VGPRs); pixel tiles of 8x16 (32 Winograd tiles = 8 k-steps) are walked split-K style.
 // ------------------------------------------------------------------------------------------------
-template <int TH, int UNR, int KH>
+// WIDE_C: block = 32 n x 64 c (waves 1 x 4) instead of 64 n x 32 c (waves 2 x 2), for problems with at most 32 output
+// channels (the four growth convs of an IRN DenseBlock, N = 32: in a 64-row block the two waves of the upper row half have
+// no live row tile at all and only transform inputs for nothing -- half the block's matrix-pipe slots)
+template <int TH, int UNR, int KH, bool WIDE_C = false>
 __device__ __forceinline__ void wgrad_wino_body(const WgradDev& p, const int split, const int n0, const int c0, const int zblock) {
   // KH = 2: eight waves; the two wave quads take alternate halves of every pixel tile's k-steps and are summed through
   // LDS at the end -> one slab per CU instead of two (half the split-K slab traffic), one staged tile per 8 waves.
   constexpr int NTHR = 256 * KH;
   constexpr int IW = 18, IH = TH + 2, NPIX_IN = IH * IW, NPIX = TH * 16;
-  constexpr int BNW = 64, BCW = 32;
+  constexpr int BNW = WIDE_C ? 32 : 64, BCW = WIDE_C ? 64 : 32;
   constexpr int SD = BNW + 8, SI = BCW + 8;            // 2*SD == 2*SI == 16 (mod 32): the 4 k-lanes hit disjoint banks
+  static_assert(!(WIDE_C && KH != 1), "the 32 x 64 block shape exists for four-wave blocks only");
   constexpr int D_F4 = (NPIX * BNW / 4 + NTHR - 1) / NTHR;
   constexpr int I_F4 = (NPIX_IN * BCW / 4 + NTHR - 1) / NTHR;
   constexpr int KSTEPS = TH / KH;                      // k-steps of a tile per wave
@@ -352,7 +356,7 @@ __device__ __forceinline__ void wgrad_wino_body(const WgradDev& p, const int spl
   const int tid = threadIdx.x;
   const int wave = (tid >> 6) & 3, kh = tid >> 8, lane = tid & 63;
   const int li = lane & 15, kq = lane >> 4;
-  const int wr = wave & 1, wc = wave >> 1;
+  const int wr = WIDE_C ? 0 : (wave & 1), wc = WIDE_C ? wave : (wave >> 1);
 
   f32x4 acc[16][2];
 #pragma unroll
@@ -618,6 +622,7 @@ struct WgradProb {
   int gap_begin, gap_len;  // operand channels [gap_begin, gap_begin + gap_len) are padding with no counterpart in the weight:
                            // they are skipped and later channels shift down (IRN DenseBlock feature buffer, cin padded to 8)
   int S, nblk, cblk;
+  int wide_c;            // Winograd kernel: this problem's blocks are 32 n x 64 c (N <= 32) instead of 64 n x 32 c
   int block_begin;       // first block of this problem in the grouped gradient grid
   int red_begin;         // first block of this problem in the grouped reduce grid
 };
@@ -637,7 +642,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_group_kernel(WgradGroup g) 
   const WgradProb& q = g.p[pi];
   const int lb = blockIdx.x - q.block_begin;
   const int split = lb % q.S, nb = (lb / q.S) % q.nblk, cb = lb / (q.S * q.nblk);
-  wgrad_wino_body<TH, UNR, 1>(q.d, split, nb * 64, cb * 32, cb);
+  if (q.wide_c) wgrad_wino_body<TH, UNR, 1, true>(q.d, split, nb * 32, cb * 64, cb);
+  else wgrad_wino_body<TH, UNR, 1>(q.d, split, nb * 64, cb * 32, cb);
 }
 
 template <int KS>
@@ -711,9 +717,10 @@ static bool g_wgrad_wino = true;       // Winograd weight gradient for 3x3 (test
 static bool g_wgrad_wino_th8 = false;  // test hook bit 2: 8-row pixel tiles in the Winograd weight gradient
 static bool g_wgrad_wino_kh2 = false;  // test hook bit 3: 8-wave blocks with an in-block k split (half the slabs; same kernel
                                        // time, but 3 % slower end to end when other streams' kernels co-run) -- off
+void wgrad_set_wide_c(int on);
 static int g_wgrad_group_mode = 1;     // 1: whole block (4 convs), 2: per half-coupling (2 convs); test hook bit 5 selects 2
 static bool g_wgrad_grouped = true;    // test hook bit 4 clears: the block executor issues one launch pair per conv (round-1 path)
-void wgrad_set_force16(int on) { g_wgrad_force16 = (on & 1) != 0; g_wgrad_wino = (on & 2) == 0; g_wgrad_wino_th8 = (on & 4) != 0; g_wgrad_wino_kh2 = (on & 8) != 0; g_wgrad_grouped = (on & 16) == 0; g_wgrad_group_mode = (on & 32) ? 2 : 1; wgrad_set_bf16_mfma((on & 64) == 0); }
+void wgrad_set_force16(int on) { g_wgrad_force16 = (on & 1) != 0; g_wgrad_wino = (on & 2) == 0; g_wgrad_wino_th8 = (on & 4) != 0; g_wgrad_wino_kh2 = (on & 8) != 0; g_wgrad_grouped = (on & 16) == 0; g_wgrad_group_mode = (on & 32) ? 2 : 1; wgrad_set_bf16_mfma((on & 64) == 0); wgrad_set_wide_c((on & 128) == 0); }
 bool wgrad_grouping_enabled() { return g_wgrad_grouped && g_wgrad_wino && !g_wgrad_force16; }
 int wgrad_group_mode() { return g_wgrad_group_mode; }
 
@@ -1060,8 +1067,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_group_kernel(WgradGroup g) 
 // ---- grouped launch (host) ---------------------------------------------------------------------------------------
 struct WgradGroupPlan { WgradGroup g; int grad_blocks, red_blocks; size_t bytes; bool wino; int th; bool mfma_bf16; };
 
+static bool g_wgrad_wide_c = true;      // test hook bit 7 clears: N <= 32 problems use the 64 x 32 block shape like everything else
 static bool g_wgrad_bf16_mfma = true;   // test hook bit 6 clears: bf16-operand problems accumulate on the f32 pipe (Winograd)
 void wgrad_set_bf16_mfma(int on) { g_wgrad_bf16_mfma = on != 0; }
+void wgrad_set_wide_c(int on) { g_wgrad_wide_c = on != 0; }
 
 static int plan_group(const sininn_wgrad_item* items, int n, int B, int H, int W, int ksize, float* ws, WgradGroupPlan& pl) {
   SININN_CHECK(items && n >= 1 && n <= WG_MAXP, "wgrad_group: 1..%d problems per group", WG_MAXP);
@@ -1094,7 +1103,9 @@ static int plan_group(const sininn_wgrad_item* items, int n, int B, int H, int W
   for (int i = 0; i < n; ++i) {
     const sininn_wgrad_item& it = items[i];
     SININN_CHECK(it.Cin > 0 && it.Cin % 4 == 0 && it.N > 0 && it.N % 4 == 0, "wgrad_group: Cin=%d and N=%d must be multiples of 4", it.Cin, it.N);
-    out_tiles += ((it.N + bnw - 1) / bnw) * ((it.Cin + bcw - 1) / bcw);
+    const bool wide_c = pl.wino && it.N <= 32 && g_wgrad_wide_c;
+    const int bn_i = wide_c ? 32 : bnw, bc_i = wide_c ? 64 : bcw;
+    out_tiles += ((it.N + bn_i - 1) / bn_i) * ((it.Cin + bc_i - 1) / bc_i);
   }
   // two blocks per CU; all problems of a group see the same pixels, so one split count serves them all
   int S = 512 / out_tiles;
@@ -1109,11 +1120,13 @@ static int plan_group(const sininn_wgrad_item* items, int n, int B, int H, int W
   for (int i = 0; i < n; ++i) {
     const sininn_wgrad_item& it = items[i];
     WgradProb& q = pl.g.p[i];
-    q.nblk = (it.N + bnw - 1) / bnw; q.cblk = (it.Cin + bcw - 1) / bcw; q.S = S;
+    q.wide_c = (pl.wino && it.N <= 32 && g_wgrad_wide_c) ? 1 : 0;
+    const int bn_i = q.wide_c ? 32 : bnw, bc_i = q.wide_c ? 64 : bcw;
+    q.nblk = (it.N + bn_i - 1) / bn_i; q.cblk = (it.Cin + bc_i - 1) / bc_i; q.S = S;
     WgradDev& d = q.d;
     d.in = it.in; d.in_stride = it.in_stride; d.Cin = it.Cin; d.dout = it.dout; d.dout_stride = it.dout_stride; d.N = it.N;
     d.B = B; d.H = H; d.W = W; d.tiles_x = tiles_x; d.tiles_y = tiles_y; d.ntiles = ntiles; d.tiles_per_split = tps;
-    d.Nr = q.nblk * bnw; d.Cc = q.cblk * bcw;
+    d.Nr = q.nblk * bn_i; d.Cc = q.cblk * bc_i;
     d.in_bf16 = it.in_bf16; d.dout_bf16 = it.dout_bf16;
     d.in_gs = it.in_group_stride > 0 ? (size_t)it.in_group_stride : 0;
     d.dout_gs = it.dout_group_stride > 0 ? (size_t)it.dout_group_stride : 0;

@@ -91,34 +91,45 @@ def _pad8(n):
 
 
 class _DensePacks:
-    """Packed weights of the five convs for the padded feature-buffer channel order [x | pad | f1 | f2 | f3 | f4]."""
+    """Packed weights of the five convs for the padded feature-buffer channel order [x | pad | f1 | f2 | f3 | f4].
+
+    The buffers are persistent and REGISTERED with the model-wide pack registry (sin_inn_amd.modules): the optimiser step
+    refreshes every pack of the model -- GLOW and DenseBlock alike -- in one batched launch.  The channel padding (channel_in
+    -> a multiple of 8 inside the feature buffer, conv5's outputs -> a multiple of 8) is expressed in the pack descriptor
+    (sininn_pack_desc.src_n / gap_begin / gap_len), not by materialising a padded copy of the weight: round 2 re-packed all
+    120 convs of an IRN model from Python every step (zero-filled padded weight + two slice copies + two pack launches per
+    conv, ~700 tiny launches per step on the main stream in front of the pass chains)."""
 
     def __init__(self):
-        self.key, self.packs = None, None
+        self.entries = None
 
     def get(self, block):
+        from .modules import _PACK_REGISTRY, _PackCache, _PackEntry
         convs = block.convs()
-        key = tuple((c.weight.data_ptr(), c.weight._version, c.bias._version) for c in convs) + (WEIGHTS_EPOCH[0], USE_WINOGRAD[0])
-        if key != self.key:
+        wino = bool(USE_WINOGRAD[0])
+        keys = [_PackCache._key(cv, True, wino, wino, False) for cv in convs]
+        if self.entries is None or any(e.key[0] != k[0] or e.key[4:] != k[4:] for e, k in zip(self.entries, keys)):
+            # first use, another device / storage, or the Winograd switch flipped: (re)allocate and (re)register
+            for e in self.entries or ():
+                _PACK_REGISTRY.discard(e)
             cin, cinp = block.channel_in, block.cinp
-            packs = []
+            self.entries = []
             for i, cv in enumerate(convs):
-                w = cv.weight.detach()
-                bias = cv.bias.detach()
-                nout = _pad8(w.shape[0])                       # conv5: its data-gradient conv has K = cout
-                if cinp != cin or nout != w.shape[0]:
-                    wp = torch.zeros((nout, cinp + GC * i, 3, 3), device=w.device, dtype=torch.float32)
-                    wp[:w.shape[0], :cin] = w[:, :cin]
-                    if i:
-                        wp[:w.shape[0], cinp:] = w[:, cin:]
-                    bp = torch.zeros(nout, device=w.device, dtype=torch.float32)
-                    bp[:w.shape[0]] = bias
-                    w, bias = wp, bp
-                # all five convs are 3x3: Winograd F(2x2,3x3) packs for the forward and the data-gradient conv
-                packs.append(ops.pack_conv(w.contiguous(), bias.contiguous(), None, True, wino_fwd=USE_WINOGRAD[0],
-                                           wino_dgrad=USE_WINOGRAD[0]))
-            self.key, self.packs = key, packs
-        return self.packs
+                n = cv.weight.shape[0]
+                pad = (_pad8(n), cinp + GC * i, cin, cinp - cin)
+                packs = ops.alloc_packs(pad[0], pad[1], 3, None, True, wino, wino, cv.weight.device)
+                e = _PackEntry(cv, None, None, packs)
+                e.pad = pad
+                self.entries.append(e)
+                _PACK_REGISTRY.add(e)
+        if any(e.key != k for e, k in zip(self.entries, keys)):
+            # stale (new block, weights changed outside the optimiser): refresh these five with one batched launch
+            descs = [ops.pack_desc(cv.weight.detach(), cv.bias.detach(), None, e.packs, wino, wino, e.pad)
+                     for e, cv in zip(self.entries, convs)]
+            ops.pack_batch_run(ops.pack_batch(descs, convs[0].weight.device))
+            for e, k in zip(self.entries, keys):
+                e.key = k
+        return [e.packs for e in self.entries]
 
 
 _MODES = {'linear': 0, 'add': 1, 'irn_fwd': 2, 'irn_inv': 3}

@@ -164,8 +164,8 @@ class _PackRegistry:
             return
         ptrs = tuple(c.weight.data_ptr() for _, c in live)
         if self.table is None or self.table[0] != ptrs:
-            descs = [ops.pack_desc(c.weight.detach(), c.bias.detach(), e.colmap, e.packs, e.key[5], e.key[6])
-                     for e, c in live]
+            descs = [ops.pack_desc(c.weight.detach(), c.bias.detach(), e.colmap, e.packs, e.key[5], e.key[6],
+                                   getattr(e, 'pad', None)) for e, c in live]
             self.table = (ptrs, ops.pack_batch(descs, live[0][1].weight.device))
         ops.pack_batch_run(self.table[1])
         for e, c in live:

@@ -64,6 +64,19 @@ def pad32(n):
     return (n + 31) // 32 * 32
 
 
+def alloc_packs(n, cin, k, colmap, want_dgrad, wino_fwd, wino_dgrad, device):
+    """Empty (w_fwd, b_fwd, w_dgrad) buffers of a conv with n outputs / cin inputs (layouts: pack_conv)."""
+    npk = colmap.numel() if colmap is not None else pad16(n)
+    taps = k * k
+    b_fwd = torch.empty(npk, device=device, dtype=torch.float32)
+    w_fwd = torch.empty((16 if wino_fwd else taps) * npk * cin, device=device, dtype=torch.float32)
+    w_dg = None
+    if want_dgrad:
+        cdp = pad32(cin) if wino_dgrad else pad16(cin)
+        w_dg = torch.empty((16 if wino_dgrad else taps) * cdp * n, device=device, dtype=torch.float32)
+    return w_fwd, b_fwd, w_dg
+
+
 def pack_conv(weight, bias, colmap=None, want_dgrad=True, wino_fwd=False, wino_dgrad=False, out=None):
     """OIHW conv weight -> (w_fwd, b_fwd, w_dgrad).
     tap-major packs: w_fwd [taps][Np][Cin], w_dgrad [taps][pad16(Cin)][N];
@@ -119,11 +132,17 @@ def pack_conv_bf16(weight, bias, colmap=None, want_dgrad=True, out=None):
     return w_fwd, b_fwd, w_dg
 
 
-def pack_desc(weight, bias, colmap, packs, wino_fwd, wino_dgrad):
-    """sininn_pack_desc refreshing `packs` (a pack_conv result) from (weight, bias)."""
+def pack_desc(weight, bias, colmap, packs, wino_fwd, wino_dgrad, pad=None):
+    """sininn_pack_desc refreshing `packs` (a pack_conv / alloc_packs result) from (weight, bias).  pad = (n_packed, cin_packed,
+    gap_begin, gap_len): the packs describe a conv with zero-padded outputs / a zero input-channel gap the weight does not have."""
     n, cin, k, _ = weight.shape
     w_fwd, b_fwd, w_dg = packs
     d = _lib.PackDesc()
+    if pad is not None:
+        n_packed, cin_packed, gap_begin, gap_len = pad
+        assert cin_packed - gap_len == cin and n_packed >= n
+        d.src_n, d.gap_begin, d.gap_len = n, gap_begin, gap_len
+        n, cin = n_packed, cin_packed
     d.w, d.bias, d.N, d.Cin, d.ksize = ptr(weight), ptr(bias), n, cin, k
     d.colmap = ptr(colmap, dtype=torch.int32)
     d.Np = colmap.numel() if colmap is not None else pad16(n)
