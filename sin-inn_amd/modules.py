@@ -259,7 +259,8 @@ class _GlowFn(torch.autograd.Function):
         b, h, w, c = x.shape
         dev = x.device
         lib = _lib.lib()
-        need_grad = any(ctx.needs_input_grad)      # False under torch.no_grad(): nothing is kept then
+        # nothing is kept under torch.no_grad() (ctx.needs_input_grad reports the parameters' requires_grad whatever the grad mode)
+        need_grad = torch.is_grad_enabled() and any(ctx.needs_input_grad)
         out = torch.empty_like(x)
         # zero-initialised log-det accumulator: a row of the buffer the graph executor zeroed once for the whole pass
         # (one fill instead of one per block), else a fresh tensor
