@@ -85,6 +85,31 @@ class KernelTimer:
         return self.total_ms / self.count if self.count else None
 
 
+def gpu_clocks():
+    """Current shader / memory clock levels of the GPU(s) from sysfs (pp_dpm_sclk / pp_dpm_mclk: the line marked '*'), read
+    as plain files -- no child process is started from a GPU-initialised process.  Logged beside the bench line so that a slow
+    line can be told apart from a throttled or down-clocked box (round 2 saw configs[3] lines between 14.3 and 16.7 ms)."""
+    import glob
+    out = []
+    for dev in sorted(glob.glob('/sys/class/drm/card*/device')):
+        rec = {}
+        for key, name in (('sclk_mhz', 'pp_dpm_sclk'), ('mclk_mhz', 'pp_dpm_mclk')):
+            try:
+                for line in open(os.path.join(dev, name)):
+                    if '*' in line:
+                        rec[key] = int(''.join(ch for ch in line.split(':')[1] if ch.isdigit()))
+            except (OSError, ValueError, IndexError):
+                pass
+        if rec:
+            try:
+                rec['busy_percent'] = int(open(os.path.join(dev, 'gpu_busy_percent')).read())
+            except (OSError, ValueError):
+                pass
+            rec['card'] = os.path.basename(os.path.dirname(dev))
+            out.append(rec)
+    return out or None
+
+
 def host_cores():
     n = len(os.sched_getaffinity(0))
     try:                                       # cgroup v2 / v1 CPU quota
@@ -388,6 +413,7 @@ def main():
         step()
     barrier()
     print(f'[bench] rank {rank}: warm-up done', file=sys.stderr, flush=True)
+    clocks_before = gpu_clocks()
     timer.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -395,6 +421,7 @@ def main():
     t_issue = time.perf_counter() - t0      # host time to enqueue the steps (GPU still running)
     barrier()
     dt = time.perf_counter() - t0
+    clocks_after = gpu_clocks()
     timer.stop()
     if ws > 1:
         t = torch.tensor([dt], device=dev if torch.distributed.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
@@ -548,6 +575,8 @@ def main():
                       'baseline_config': args.config, 'height': args.height, 'width': args.width,
                       'global_batch': ws * b, 'num_coupling': args.num_coupling, 'architecture': args.arch, 'parallelism': f'dp{ws}'},
            'roofline': roof}
+    out['gpu_clocks'] = {'before_timed_region': clocks_before, 'after_timed_region': clocks_after,
+                         'source': '/sys/class/drm/card*/device/pp_dpm_{sclk,mclk} (active level), gpu_busy_percent'}
     out['config']['hip_graph'] = bool(args.graph == 'on' and any('graph' in v for v in model.__dict__.get('_graphs', {}).values()))
     if args.with_flow:
         out['config']['workload'] += '; preceded in every step by the pair_flow warp + photometric metric + flow gradient on the batch'

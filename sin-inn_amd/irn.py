@@ -172,7 +172,7 @@ class _DenseFn(torch.autograd.Function):
             a2 = aux2.detach().contiguous()
             a.aux2, a.aux2_floats = a2.data_ptr(), a2.numel()
         check(_lib.lib().sininn_dense_forward(a, ops._stream()))
-        if torch.is_grad_enabled() and any(ctx.needs_input_grad):
+        if block._grad_mode and any(ctx.needs_input_grad):      # the caller's grad mode (autograd is off inside forward)
             ctx.block, ctx.mode, ctx.clamp, ctx.shape = block, mode, clamp, (b, h, w, cin)
             ctx.save_for_backward(buf, out, a1 if a1 is not None else buf, a2 if a2 is not None else buf, xd)
             if GATE_TAP[0] is not None:          # parity tooling: the LeakyReLU gates of conv1-4 (feature slots of buf are > 0)
@@ -288,6 +288,7 @@ class DenseBlock(nn.Module):
 
     def run(self, x, mode='linear', aux1=None, aux2=None, clamp=1.0):
         params = [p for cv in self.convs() for p in (cv.weight, cv.bias)]
+        self._grad_mode = torch.is_grad_enabled()
         return _DenseFn.apply(x, aux1, aux2, self, mode, float(clamp), *params)
 
     def forward(self, x):

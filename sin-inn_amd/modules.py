@@ -259,8 +259,9 @@ class _GlowFn(torch.autograd.Function):
         b, h, w, c = x.shape
         dev = x.device
         lib = _lib.lib()
-        # nothing is kept under torch.no_grad() (ctx.needs_input_grad reports the parameters' requires_grad whatever the grad mode)
-        need_grad = torch.is_grad_enabled() and any(ctx.needs_input_grad)
+        # nothing is kept under torch.no_grad().  ctx.needs_input_grad reports the parameters' requires_grad whatever the grad
+        # mode, and inside Function.forward autograd is always off: the caller's grad mode is sampled by apply_pixel_major
+        need_grad = block._grad_mode and any(ctx.needs_input_grad)
         out = torch.empty_like(x)
         # zero-initialised log-det accumulator: a row of the buffer the graph executor zeroed once for the whole pass
         # (one fill instead of one per block), else a fresh tensor
@@ -349,6 +350,7 @@ class GLOWCouplingBlock(nn.Module):
     _ld_row = None          # set by ReversibleGraphNet.forward for the next call only
 
     def apply_pixel_major(self, x, rev=False, dst=None):
+        self._grad_mode = torch.is_grad_enabled()
         out, logdet = _GlowFn.apply(x, self, bool(rev), dst, *self._params())
         self.last_jac = logdet
         return out
