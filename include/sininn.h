@@ -171,7 +171,8 @@ int sininn_conv_pair_k1(const sininn_conv_args* first, const sininn_conv_args* s
  * ksize 3, bf16 weights, fp32 input, mode RELU, 256 output channels, out == NULL (the hidden tile lives in LDS only);
  * `second`: ksize 3, bf16 weights, Cin 256, mode COUPLE_FWD / COUPLE_INV (same kernel for both directions), Np in {16, 32,
  * 48, 64, 96, 192}.  Same values as the two sininn_conv launches with a bf16 hidden tensor (one rounding of h to bf16) up to
- * fp32 summation order.  sininn_glow_forward uses it for dtype == 1, ksize == 3, no_save != 0. */
+ * fp32 summation order.  sininn_glow_forward dispatches it for dtype == 1, ksize == 3, no_save != 0 when SININN_SUB3=1 is set in the
+ * environment (not the default: on MI355X it measures 1.8 - 2.7x slower than the two launches it replaces). */
 int sininn_conv_sub3_supported(const sininn_conv_args* first, const sininn_conv_args* second);
 int sininn_conv_sub3(const sininn_conv_args* first, const sininn_conv_args* second, void* stream);
 

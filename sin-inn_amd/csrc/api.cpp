@@ -223,7 +223,8 @@ int sininn_conv_pair_k1(const sininn_conv_args* first, const sininn_conv_args* s
 /* test hook (not part of the documented surface): force tile configuration / channel chunk */
 void sininn_conv_test_hooks(int force_cfg, int force_ck) { conv_set_test_hooks(force_cfg, force_ck); }
 void sininn_wgrad_test_hooks(int force16) { wgrad_set_force16(force16); }
-void sininn_pair_k1_test_hook(int on) { conv_pair_k1_enable(on & 1); sub3_fusion_set((on & 2) ? 0 : 1); }   // bit 1: no fused 3x3 subnet
+// bit 0: fused 1x1 pairs on; bit 2: force the fused 3x3 subnet on, bit 1: force it off, neither: its default policy (SININN_SUB3)
+void sininn_pair_k1_test_hook(int on) { conv_pair_k1_enable(on & 1); sub3_fusion_set((on & 4) ? 1 : ((on & 2) ? 0 : -1)); }
 int sininn_conv_sub3_supported(const sininn_conv_args* first, const sininn_conv_args* second) {
   return conv_sub3_bf16_supported(first, second);
 }

@@ -15,6 +15,8 @@
 // Both weight packs stream from L2 as MFMA B operands through a register ring (they are 0.1 - 1.3 MB per subnet).
 // What it saves against the two-launch path: the hidden tensor's HBM write + halo re-read (2 B x 256 ch x pixels, twice) and
 // one launch per half-coupling; what it costs: conv1 on 1.7x the pixels (+23 % MFMA work per subnet).
+#include <stdlib.h>
+
 #include "conv_bf16_types.h"
 
 namespace sininn {
@@ -214,8 +216,14 @@ static int sub3_launch(Sub3Dev& q, hipStream_t st) {
   return 0;
 }
 
-static int g_sub3_enabled = 1;                         // test hook (sininn_pair_k1_test_hook bit 1 clears it): A/B against two launches
-bool sub3_fusion_enabled() { return g_sub3_enabled != 0; }
+// Dispatch policy: OFF unless SININN_SUB3=1 (or the test hook forces it).  Measured on MI355X (gpurun_out/r03f_infer.log,
+// r03f_inf{1,3}_by_grid.csv; 512 x 512, batch 16, inverse pass): this kernel takes 346 us (level 0) / 382 us (level 1) per
+// half-coupling against 105 + 89 us / 99 + 44 us for the two launches it replaces -- its B operands come straight from L2
+// through a 3-deep register ring with one block per CU at level 1 (90 KB of LDS) and one MFMA per operand pair in stage 2,
+// so every k-step waits out an L2 round trip.  Kept, tested and callable (sininn_conv_sub3); not the default.
+static int sub3_default() { const char* e = getenv("SININN_SUB3"); return (e && atoi(e) != 0) ? 1 : 0; }
+static int g_sub3_enabled = -1;                        // -1: policy above; 0 / 1: forced by the test hook
+bool sub3_fusion_enabled() { return (g_sub3_enabled < 0 ? sub3_default() : g_sub3_enabled) != 0; }
 void sub3_fusion_set(int on) { g_sub3_enabled = on; }
 
 // 1 when (first, second) is a 3x3 subnet this kernel runs: first = fp32 input -> 256 hidden channels (RELU, bf16 weights, no

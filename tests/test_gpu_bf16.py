@@ -281,7 +281,8 @@ def test_bf16_backward_at_config4_shape():
 @pytest.mark.parametrize('channels,hw', [(48, (13, 21)), (192, (6, 18)), (48, (64, 64)), (192, (9, 33)), (96, (4, 16))])
 def test_fused_3x3_subnet_matches_the_two_launch_path(rev, channels, hw):
     """north_star's single fused coupling kernel (conv_sub3_bf16.hip, sininn_conv_sub3): in a no-grad pass on the mixed-
-    precision path a 3x3 subnet + affine coupling + log-det is ONE launch with the hidden tile in LDS.  Against the same block
+    precision path a 3x3 subnet + affine coupling + log-det can run as ONE launch with the hidden tile in LDS (SININN_SUB3=1;
+    not the default dispatch: measured slower than the two launches it replaces).  Against the same block
     through the two-launch path (bf16 hidden tensor in HBM): the hidden values are rounded to bf16 once in both, from fp32 sums
     accumulated in another order -> a value next to a rounding boundary lands one bf16 ulp apart in a few channels (budget
     8e-3 of the max-norm, 1.5e-3 L2); ragged image sizes (tiles cut by the border in x and y), both coupling
@@ -304,7 +305,7 @@ def test_fused_3x3_subnet_matches_the_two_launch_path(rev, channels, hw):
     x = torch.randn(2, channels, h, w)
     res = []
     try:
-        for hook in (1, 3):                      # 1: fused 3x3 subnet (default); 3: bit 1 set -> two launches
+        for hook in (5, 3):                      # bit 2: fused 3x3 subnet forced on; bit 1: forced off -> two launches
             _lib.lib().sininn_pair_k1_test_hook(hook)
             with torch.no_grad():
                 y = blk([x.cuda()], rev=rev)[0]

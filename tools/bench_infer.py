@@ -20,7 +20,7 @@ def main():
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32')
     ap.add_argument('--size', type=int, default=256)
-    ap.add_argument('--hook', type=int, default=1, help='sininn_pair_k1_test_hook: 1 default, 3 = no fused 3x3 subnet (two launches), '
+    ap.add_argument('--hook', type=int, default=1, help='sininn_pair_k1_test_hook: 1 default, 5 = fused 3x3 subnet forced on (bf16 no-grad), 3 = forced off, '
                     '0 = no fused 1x1 pair')
     a = ap.parse_args()
     dev = torch.device('cuda', 0)
