@@ -103,6 +103,10 @@ enum sininn_conv_mode {
   SININN_CONV_ADD = 4,        /* out = conv (+ bias if given) + addend[addend_map]   (data gradient + skip grad;
                                  with bias: y1 = x1 + F(x2), archs.py:151)                                  */
   SININN_CONV_LINEAR = 5,     /* out = conv + bias                                                          */
+  /* LINEAR and ADD with `mask` != NULL (ABI v4): a LeakyReLU-backward tail -- output columns c >= Co are multiplied by
+   * (mask[pix * mask_stride + c] > 0 ? 1 : clamp).  The data gradient of DenseBlock conv k+1 finalises the gradient of
+   * feature slot k in its last 32 columns; the LeakyReLU backward of that slot (archs.py:90-93) rides in its epilogue
+   * instead of being a launch of its own (192 launches per IRN training step). */
   /* IRN architecture (archs.py:74-160): */
   SININN_CONV_LRELU = 6,      /* out = leaky_relu(conv + bias, slope = clamp)        (DenseBlock conv1-4, archs.py:90-93) */
   SININN_CONV_IRN_FWD = 7,    /* out = v * exp(clamp*(2*sigmoid(aux)-1)) + conv + bias  (InvBlockExp, archs.py:152-153;

@@ -43,6 +43,9 @@ int conv_prepare(const sininn_conv_args* a, ConvDev& d) {
     const bool cbwd = a->mode == SININN_CONV_ADD_CBWD_FWD || a->mode == SININN_CONV_ADD_CBWD_INV;
     if (a->mode == SININN_CONV_ADD || cbwd) SININN_CHECK(a->addend != nullptr, "conv: ADD mode needs addend");
     if (cbwd) SININN_CHECK(a->v && a->sbuf && a->out2 && a->Co == a->N && a->out_stride >= 2 * a->Co && a->clamp > 0.f, "conv: ADD_CBWD needs v, sbuf, out2, Co == N, out_stride >= 2*Co");
+    if ((a->mode == SININN_CONV_LINEAR || a->mode == SININN_CONV_ADD) && a->mask)
+      SININN_CHECK(a->Co >= 0 && a->Co % 4 == 0 && a->mask_stride >= a->N && a->mask_stride % 4 == 0 && aligned16(a->mask) && a->mask_group_stride <= 0,
+                   "conv: LeakyReLU tail needs Co %% 4 == 0 and a 16-byte aligned pixel-major mask (Co=%d, mask_stride=%d)", a->Co, a->mask_stride);
     if (a->mode == SININN_CONV_IRN_FWD || a->mode == SININN_CONV_IRN_INV)
       SININN_CHECK(a->mask && a->v && a->mask_stride >= a->N && a->v_stride >= a->N && a->clamp > 0.f, "conv: IRN modes need aux (mask), v and clamp");
   }

@@ -181,6 +181,8 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvDev& p, const float
       const bool act = MODE == SININN_CONV_RELU || MODE == SININN_CONV_LINEAR || MODE == SININN_CONV_LRELU;
       const bool plain_add = MODE == SININN_CONV_ADD && p.addend_map == nullptr;
       const int colq = n0 + (tid % Q) * 4;           // this thread's column quad in every iteration
+      // LINEAR / ADD with a mask: LeakyReLU-backward tail on the columns >= Co (IRN DenseBlock data gradients, see sininn.h)
+      const bool lrelu_tail = (MODE == SININN_CONV_LINEAR || MODE == SININN_CONV_ADD) && p.mask != nullptr && colq >= p.Co;
       if ((act || MODE == SININN_CONV_MASK || plain_add) && colq + 3 < p.N) {
         // hot modes, full quads: the bias is a loop invariant; the per-pixel side input (mask / addend) is requested one
         // iteration ahead.  Partial quads and the other modes take the general loop below.
@@ -224,6 +226,11 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvDev& p, const float
             } else {
               val += bq;
               val += sd;
+            }
+            if (lrelu_tail) {
+              const f32x4 fk = *reinterpret_cast<const f32x4*>(p.mask + pix * p.mask_stride + colq);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) val[j] = fk[j] > 0.f ? val[j] : val[j] * p.clamp;
             }
             if (p.out_gs) *reinterpret_cast<f32x4*>(p.out + (size_t)(colq >> 3) * p.out_gs + pix * 8 + (colq & 7)) = val;
             else *reinterpret_cast<f32x4*>(p.out + pix * p.out_stride + colq) = val;
@@ -282,6 +289,11 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvDev& p, const float
                 val[j] += p.addend[pix * p.addend_stride + ac];
               }
           }
+        }
+        if ((MODE == SININN_CONV_LINEAR || MODE == SININN_CONV_ADD) && p.mask != nullptr) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (col + j < p.N && col + j >= p.Co && !(p.mask[pix * p.mask_stride + col + j] > 0.f)) val[j] *= p.clamp;
         }
         if (MODE == SININN_CONV_ADD_CBWD_FWD || MODE == SININN_CONV_ADD_CBWD_INV) {
           // val = gradient w.r.t. the first half's output y; emit (ds | dt) and dv of that half's coupling tail

@@ -161,27 +161,27 @@ int dense_backward(const sininn_dense_args* a, hipStream_t st, hipStream_t wst) 
     if (int rc = copy_channels_launch(a->dout, cout, a->dD, coutp, M, cout, coutp, st)) return rc;
     dD = a->dD; dD_stride = coutp;
   }
-  auto dgrad = [&](const float* src, int src_stride, int n_src, const float* w, int n_out, bool accumulate) -> int {
+  // The data gradient of conv i+1 writes (conv5) or accumulates (conv2-4) dF[:, :k_{i+1}); its last 32 columns are feature
+  // slot i, whose gradient is final at that point: the LeakyReLU backward of slot i is applied in that conv's epilogue
+  // (`tail` = first column of the slot; the mask is the saved feature buffer), not by a launch of its own.
+  auto dgrad = [&](const float* src, int src_stride, int n_src, const float* w, int n_out, bool accumulate, int tail) -> int {
     sininn_conv_args c = {};
     c.in = src; c.in_stride = src_stride; c.Cin = n_src; c.w = w; c.winograd = a->winograd;
     c.Np = a->winograd ? pad32(n_out) : pad16(n_out);
     c.B = a->B; c.H = a->H; c.W = a->W; c.ksize = 3; c.out = a->dF; c.out_stride = bw; c.N = n_out;
     if (accumulate) { c.mode = SININN_CONV_ADD; c.addend = a->dF; c.addend_stride = bw; }
     else c.mode = SININN_CONV_LINEAR;
+    if (tail >= 0) { c.mask = a->buf; c.mask_stride = bw; c.Co = tail; c.clamp = SLOPE; }
     return conv_launch(&c, st);
   };
   {
     Scope sc(2, cflops(M, cout, cin + 4 * GC), st);
-    if (int rc = dgrad(dD, dD_stride, coutp, a->w_dgrad[4], bw, false)) return rc;
+    if (int rc = dgrad(dD, dD_stride, coutp, a->w_dgrad[4], bw, false, cinp + GC * 3)) return rc;
   }
   for (int i = 3; i >= 0; --i) {
     const int k = cinp + GC * i;
-    {
-      Scope sc(5, 0.0, st);
-      if (int rc = lrelu_bwd_launch(a->dF + k, bw, a->buf + k, bw, M, GC, SLOPE, st)) return rc;
-    }
     Scope sc(3, cflops(M, GC, cin + GC * i), st);
-    if (int rc = dgrad(a->dF + k, bw, GC, a->w_dgrad[i], k, true)) return rc;
+    if (int rc = dgrad(a->dF + k, bw, GC, a->w_dgrad[i], k, true, i > 0 ? cinp + GC * (i - 1) : -1)) return rc;
   }
   // ---- the five weight gradients: every dF slot is final now -> one grouped launch pair on the weight-gradient stream ----
   sininn_wgrad_item it[5];
