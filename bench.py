@@ -85,12 +85,21 @@ class KernelTimer:
         return self.total_ms / self.count if self.count else None
 
 
-def gpu_clocks():
+def gpu_clocks(device_index=None):
     """Current shader / memory clock levels of the GPU(s) from sysfs (pp_dpm_sclk / pp_dpm_mclk: the line marked '*'), read
     as plain files -- no child process is started from a GPU-initialised process.  Logged beside the bench line so that a slow
-    line can be told apart from a throttled or down-clocked box (round 2 saw configs[3] lines between 14.3 and 16.7 ms)."""
+    line can be told apart from a throttled or down-clocked box (round 2 saw configs[3] lines between 14.3 and 16.7 ms).
+    The host's sysfs lists every GPU of the node (other tenants' too): with device_index the list is narrowed to the card whose
+    PCI address is the torch device's."""
     import glob
-    out = []
+    want = None
+    if device_index is not None:
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            want = f'{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}'
+        except (AttributeError, RuntimeError):
+            want = None
+    out, mine = [], []
     for dev in sorted(glob.glob('/sys/class/drm/card*/device')):
         rec = {}
         for key, name in (('sclk_mhz', 'pp_dpm_sclk'), ('mclk_mhz', 'pp_dpm_mclk')):
@@ -107,7 +116,9 @@ def gpu_clocks():
                 pass
             rec['card'] = os.path.basename(os.path.dirname(dev))
             out.append(rec)
-    return out or None
+            if want is not None and os.path.basename(os.path.realpath(dev)).lower().startswith(want):
+                mine.append(rec)
+    return mine or out or None
 
 
 def host_cores():
@@ -413,7 +424,7 @@ def main():
         step()
     barrier()
     print(f'[bench] rank {rank}: warm-up done', file=sys.stderr, flush=True)
-    clocks_before = gpu_clocks()
+    clocks_before = gpu_clocks(local)
     timer.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -421,7 +432,7 @@ def main():
     t_issue = time.perf_counter() - t0      # host time to enqueue the steps (GPU still running)
     barrier()
     dt = time.perf_counter() - t0
-    clocks_after = gpu_clocks()
+    clocks_after = gpu_clocks(local)
     timer.stop()
     if ws > 1:
         t = torch.tensor([dt], device=dev if torch.distributed.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
