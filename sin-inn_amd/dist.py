@@ -21,10 +21,11 @@ def world():
     return 0, 1
 
 
-def init_from_env(backend=None):
-    """Initialise the default process group from torchrun's environment (no-op for a single process)."""
+def init_from_env(backend=None, allow_single=False):
+    """Initialise the default process group from torchrun's environment (no-op for a single process unless allow_single:
+    a one-rank RCCL group, used by the test of the collective's stream ordering)."""
     ws = int(os.environ.get('WORLD_SIZE', '1'))
-    if ws <= 1 or dist.is_initialized():
+    if (ws <= 1 and not allow_single) or dist.is_initialized():
         return world()
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
@@ -37,7 +38,10 @@ def init_from_env(backend=None):
             kw['pg_options'] = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
         except (AttributeError, TypeError):
             pass
-    dist.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=ws, **kw)
+    try:
+        dist.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=ws, **kw)
+    except TypeError:                   # a torch build whose init_process_group does not take pg_options
+        dist.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=ws)
     return world()
 
 
@@ -51,7 +55,7 @@ def allreduce_mean_(flat_buffers):
         buf.div_(ws)
 
 
-def allreduce_sum_(flat_buffers, after=None):
+def allreduce_sum_(flat_buffers, after=None, _force=False):
     """In-place SUM of each flat gradient buffer over the ranks; the 1/world factor is folded into the fused Adam launch
     (sininn_adam_step's grad_scale) instead of a separate pass over the buffer.
 
@@ -60,9 +64,9 @@ def allreduce_sum_(flat_buffers, after=None):
     communication stream waits for the last weight-gradient kernel and not for whatever else the caller's stream still has
     in flight (tail of the data-gradient chains, loss logging) -- and the caller's current stream waits for the collective
     (`work.wait()` is a stream wait, the host does not block).  Adam, launched next on the caller's stream, is thereby
-    ordered after the reduced gradients."""
+    ordered after the reduced gradients.  (_force: run the collective in a one-rank group too -- ordering test.)"""
     _, ws = world()
-    if ws == 1:
+    if ws == 1 and not _force:
         return
     if after is not None and flat_buffers and flat_buffers[0].is_cuda:
         if dist.get_backend() == 'nccl':

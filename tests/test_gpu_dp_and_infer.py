@@ -88,6 +88,42 @@ def test_replicas_stay_bit_identical_under_unequal_host_delays(tmp_path):
     assert torch.isfinite(r0).all() and torch.equal(r0, r1)
 
 
+_ORDER_SCRIPT = r'''
+import os, sys, torch
+sys.path.insert(0, %(root)r)
+import sin_inn_amd
+from sin_inn_amd import dist as sd
+import torch.distributed as dist
+rank, ws = sd.init_from_env('nccl', allow_single=True)          # a ONE-rank RCCL group: the real backend, the real streams
+assert dist.is_initialized() and dist.get_backend() == 'nccl' and ws == 1
+side = torch.cuda.Stream()
+buf = torch.ones(1 << 22, device='cuda')
+torch.cuda.synchronize()
+with torch.cuda.stream(side):                                   # the producer of the buffer, held up on the side stream
+    torch.cuda._sleep(200_000_000)
+    buf.mul_(3.0)
+sd.allreduce_sum_([buf], after=side, _force=True)               # issued from the main stream, ordered behind `side` alone
+out = buf * 2.0                                                 # main stream: must see the reduced (== produced) values
+torch.cuda.synchronize()
+assert float(out.min()) == 6.0 and float(out.max()) == 6.0, (float(out.min()), float(out.max()))
+sys.stdout.write('ordering ok\n')
+dist.destroy_process_group()
+'''
+
+
+def test_gradient_allreduce_is_ordered_behind_the_producer_stream_on_rccl(tmp_path):
+    """dist.allreduce_sum_(after=stream) on the REAL backend (RCCL, a one-rank group -- two ranks cannot share the test box's
+    GPU): the collective waits for a producer that is still spinning on the side stream although it is issued from the main
+    stream, and the main stream's next kernel waits for the collective.  Exercises ProcessGroupNCCL.Options(high priority),
+    async_op under a stream context and work.wait() exactly as the optimiser proxy uses them."""
+    script = tmp_path / 'order.py'
+    script.write_text(_ORDER_SCRIPT % dict(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0 and 'ordering ok' in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
 def test_infer_writes_frames(tmp_path):
     import lit_wrapper
     from data import FrameStore, VideoAllDataset, get_loader
