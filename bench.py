@@ -420,6 +420,12 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # diagnostic: run the steps on a stream of explicit priority instead of the default stream (SININN_MAIN_PRIO)
+    main_prio = os.environ.get('SININN_MAIN_PRIO')
+    if main_prio is not None:
+        work_stream = _m.make_stream(dev, int(main_prio))
+        work_stream.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(work_stream)
     for _ in range(args.warmup):
         step()
     barrier()

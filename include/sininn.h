@@ -38,6 +38,12 @@ const char* sininn_last_error(void);
  * 2 sininn_dense_args, 3 sininn_glow_args, 4 sininn_subnet, 5 sininn_pack_desc; 0 for an unknown index.  A binding written in
  * another language (the ctypes mirrors in sin-inn_amd/_lib.py) checks its own layout against it at load time (ABI v4). */
 size_t sininn_sizeof(int which);
+/* A HIP stream at an explicit priority (lower number = higher priority; range from sininn_stream_priority_range: `least` is the
+ * numerically largest, lowest priority).  torch.cuda.Stream only offers {high, normal}; the weight-gradient stream of the
+ * training step can be created LOW with this (SININN_WGRAD_PRIO) and wrapped with torch.cuda.ExternalStream.  The stream lives
+ * until the process exits.  ABI v4. */
+int sininn_stream_priority_range(int* least, int* greatest);
+int sininn_stream_create(int priority, void** stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Weight packing.  Source: torch Conv2d weight, OIHW fp32 [N][Cin][k][k] (archs.py:12-13,16-17).

@@ -33,7 +33,8 @@ _SECOND = {}
 def _second_stream(device):
     key = str(device)
     if key not in _SECOND:
-        _SECOND[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get('SININN_PASS2_PRIO', '0')))
+        from sin_inn_amd.modules import make_stream
+        _SECOND[key] = make_stream(device, int(os.environ.get('SININN_PASS2_PRIO', '0')))
     return _SECOND[key]
 
 

@@ -100,6 +100,8 @@ _SIGS = {
     'sininn_version': (C.c_int, []),
     'sininn_last_error': (C.c_char_p, []),
     'sininn_sizeof': (C.c_size_t, [C.c_int]),
+    'sininn_stream_priority_range': (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'sininn_stream_create': (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     'sininn_pack_conv_weights': (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, c_i, C.c_int, c_f, c_f, C.c_int, c_f, C.c_void_p]),
     'sininn_pack_conv_weights_bf16': (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, c_i, C.c_int, C.c_void_p, c_f, C.c_int,
                                                C.c_void_p, C.c_void_p]),

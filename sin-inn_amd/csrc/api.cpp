@@ -132,6 +132,23 @@ extern "C" {
 
 int sininn_version(void) { return SININN_ABI_VERSION; }
 const char* sininn_last_error(void) { return g_err; }
+// HIP streams at a priority torch.cuda.Stream cannot express (it clamps to {high, normal}): lower number = higher priority,
+// the device's range is reported by sininn_stream_priority_range.  The handle is wrapped with torch.cuda.ExternalStream.
+int sininn_stream_priority_range(int* least, int* greatest) {
+  if (!least || !greatest) { set_error("stream_priority_range: null argument"); return 1; }
+  hipError_t e = hipDeviceGetStreamPriorityRange(least, greatest);
+  if (e != hipSuccess) { set_error("stream_priority_range: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+int sininn_stream_create(int priority, void** stream) {
+  if (!stream) { set_error("stream_create: null argument"); return 1; }
+  hipStream_t s = nullptr;
+  hipError_t e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority);
+  if (e != hipSuccess) { set_error("stream_create(priority %d): %s", priority, hipGetErrorString(e)); return (int)e; }
+  *stream = s;
+  return 0;
+}
+
 size_t sininn_sizeof(int which) {
   switch (which) {
     case 0: return sizeof(sininn_conv_args);

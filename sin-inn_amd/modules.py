@@ -185,11 +185,25 @@ USE_SIDE_STREAM = [True]
 GATE_TAP = [None]       # parity tooling: set to a list -> every differentiable GLOW / DenseBlock forward appends its gates
 
 
+def make_stream(device, priority):
+    """A HIP stream at `priority` (lower = higher priority).  torch.cuda.Stream covers {-1, 0}; anything else (a LOW-priority
+    stream, +1 on MI355X) is created through the library and wrapped."""
+    if priority in (0, -1):
+        return torch.cuda.Stream(device=device, priority=priority)
+    least, greatest = C.c_int(0), C.c_int(0)
+    with torch.cuda.device(device):
+        _lib.check(_lib.lib().sininn_stream_priority_range(C.byref(least), C.byref(greatest)))
+        prio = max(min(priority, least.value), greatest.value)
+        handle = C.c_void_p()
+        _lib.check(_lib.lib().sininn_stream_create(prio, C.byref(handle)))
+    return torch.cuda.ExternalStream(handle.value, device=device)
+
+
 def _side_stream(device):
     key = str(device)
     if key not in _SIDE:
         import os
-        _SIDE[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get('SININN_WGRAD_PRIO', '0')))
+        _SIDE[key] = make_stream(device, int(os.environ.get('SININN_WGRAD_PRIO', '0')))
     return _SIDE[key]
 
 

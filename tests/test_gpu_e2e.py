@@ -200,3 +200,27 @@ def test_pack_miss_after_validation_is_ordered_across_streams():
 
     a, b = run(True), run(False)
     assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_bench_with_flow_line_is_well_formed(tmp_path):
+    """`bench.py --with-flow` (BASELINE configs[3] as named: pair_flow warp + INN) at a toy size: one JSON line with the contract's
+    keys, the roofline / cpu_baseline objects and the two HBM rows of the warp."""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--config', '3', '--with-flow', '--size', '64', '--batch', '2',
+                          '--num-coupling', '1', '--frames', '24', '--steps', '2', '--warmup', '1', '--cpu-batch', '1'],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in rec, k
+    assert rec['dtype'] == 'bf16' and rec['config']['with_flow'] is True and rec['value'] > 0
+    r = rec['roofline']
+    assert r['bound'] in ('hbm', 'mfma') and 0 < r['frac'] <= 1.0 and r['achieved'] > 0 and r['peak'] > 0
+    warp = [c for c in r['classes'] if c['class'].startswith('flow warp')]
+    assert len(warp) == 2 and all(c['bound'] == 'hbm' and c['achieved_gbs'] > 0 for c in warp)
+    assert rec['cpu_baseline']['kind'] == 'port' and rec['cpu_baseline']['cores'] >= 1
