@@ -9,6 +9,8 @@
 //     and shared by the 9 taps; the dout A-fragment is shared by all taps / column tiles of a wave
 //   * partial sums go to a slab per split; a second kernel reduces the slabs in a fixed order
 //     (bitwise reproducible, no float atomics) straight into the OIHW gradient (+=).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace sininn {
@@ -1108,7 +1110,10 @@ static int plan_group(const sininn_wgrad_item* items, int n, int B, int H, int W
     out_tiles += ((it.N + bn_i - 1) / bn_i) * ((it.Cin + bc_i - 1) / bc_i);
   }
   // two blocks per CU; all problems of a group see the same pixels, so one split count serves them all
-  int S = 512 / out_tiles;
+  // (SININN_WGRAD_BLOCKS: diagnostic -- target block count of the grouped gradient launch, e.g. 256 = one block per CU, which
+  // leaves half of every CU's registers / LDS to the pass chains' kernels that run beside it)
+  static const int target_blocks = getenv("SININN_WGRAD_BLOCKS") ? atoi(getenv("SININN_WGRAD_BLOCKS")) : 512;
+  int S = (target_blocks > 0 ? target_blocks : 512) / out_tiles;
   if (S < 1) S = 1;
   if (S > ntiles) S = ntiles;
   const int tps = (ntiles + S - 1) / S;
