@@ -28,6 +28,18 @@ int conv_pair_bf16_launch(const sininn_conv_args* f, const sininn_conv_args* s, 
 
 struct PairDev { ConvDev a, b; };
 
+// build tunables (A/B'd with tools/build_variant.sh + SININN_LIB on one box): how many 16-channel steps ahead the weight
+// fragments are requested from L2 in stage 1 (ring size - 1) and in stage 2 (row-split / column-split wave layouts)
+#ifndef PAIR_RING1
+#define PAIR_RING1 2
+#endif
+#ifndef PAIR_DEPTH_M
+#define PAIR_DEPTH_M 2
+#endif
+#ifndef PAIR_DEPTH_N
+#define PAIR_DEPTH_N 1
+#endif
+
 constexpr int PK_HID = 256;           // hidden channels (SININN_HIDDEN)
 constexpr int PK_HS = PK_HID + 4;     // floats per pixel row of the hidden tile in LDS
 
@@ -98,22 +110,31 @@ __global__ __launch_bounds__(256) void conv_pair_k1_kernel(PairDev q) {
         bf[n] = live ? *reinterpret_cast<const f32x4*>(wrow + (size_t)n * 16 * K1 + ((pa.ablate & 1) ? 0 : 16 * s)) : z;
       }
     };
-    f32x4 bf[4], bn[4];
-    load_b(0, bf);
-    for (int s = 0; s < nsteps; ++s) {
-      if (s + 1 < nsteps) load_b(s + 1, bn);
-      f32x4 af[MT];
+    // weights requested RING1 - 1 sixteen-channel steps ahead through a register ring (an L2 round trip is longer than the
+    // 16 MT MFMAs of a step)
+    constexpr int RING1 = PAIR_RING1;
+    f32x4 bfr[RING1][4];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const f32x4*>(xs + (m * 16 + li) * XS + 16 * s + 4 * kq);
+    for (int s = 0; s < RING1 - 1; ++s)
+      if (s < nsteps) load_b(s, bfr[s]);
+    for (int s0 = 0; s0 < nsteps; s0 += RING1) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int u = 0; u < RING1; ++u) {
+        const int s = s0 + u;
+        if (s < nsteps) {
+          if (s + RING1 - 1 < nsteps) load_b(s + RING1 - 1, bfr[(u + RING1 - 1) % RING1]);
+          f32x4 af[MT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+          for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const f32x4*>(xs + (m * 16 + li) * XS + 16 * s + 4 * kq);
 #pragma unroll
-          for (int n = 0; n < 4; ++n)
-            accs[j % KS1][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][j], bf[n][j], accs[j % KS1][m][n], 0, 0, 0);
+          for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int n = 0; n < 4; ++n) bf[n] = bn[n];
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+              for (int n = 0; n < 4; ++n)
+                accs[j % KS1][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][j], bfr[u][n][j], accs[j % KS1][m][n], 0, 0, 0);
+        }
+      }
     }
     // D[row = 4 kq + r][col = li] -> hs[pixel][column] (raw sums; bias / activation in the pass below)
 #pragma unroll
@@ -171,7 +192,7 @@ __global__ __launch_bounds__(256) void conv_pair_k1_kernel(PairDev q) {
   // the pair's two waves take alternate column tiles)
   constexpr int WM = MSPLIT ? MT : 1, WN = 4 / WM;
   static_assert(!MSPLIT || MT == 4 || MT == 2, "row-tile split needs 2 or 4 row tiles");
-  constexpr int NI = (NT2 + WN - 1) / WN, MI = MSPLIT ? 1 : MT, DEPTH = MSPLIT ? 2 : 1;
+  constexpr int NI = (NT2 + WN - 1) / WN, MI = MSPLIT ? 1 : MT, DEPTH = MSPLIT ? PAIR_DEPTH_M : PAIR_DEPTH_N;
   constexpr int KS2 = (NI * MI <= 4) ? 4 : ((NI * MI <= 8) ? 2 : 1);     // accumulator sets, see stage 1
   f32x4 acc2[KS2][NI][MI];
 #pragma unroll
