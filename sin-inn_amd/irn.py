@@ -101,7 +101,7 @@ class _DensePacks:
     conv, ~700 tiny launches per step on the main stream in front of the pass chains)."""
 
     def __init__(self):
-        self.entries = None
+        self.entries, self.packs = None, None
 
     def get(self, block):
         from .modules import _PACK_REGISTRY, _PackCache, _PackEntry
@@ -122,6 +122,7 @@ class _DensePacks:
                 e.pad = pad
                 self.entries.append(e)
                 _PACK_REGISTRY.add(e)
+            self.packs = [e.packs for e in self.entries]          # ONE list object per allocation: descriptor caches key on it
         if any(e.key != k for e, k in zip(self.entries, keys)):
             # stale (new block, weights changed outside the optimiser): refresh these five with one batched launch
             descs = [ops.pack_desc(cv.weight.detach(), cv.bias.detach(), None, e.packs, wino, wino, e.pad)
@@ -129,18 +130,26 @@ class _DensePacks:
             ops.pack_batch_run(ops.pack_batch(descs, convs[0].weight.device))
             for e, k in zip(self.entries, keys):
                 e.key = k
-        return [e.packs for e in self.entries]
+        return self.packs
 
 
 _MODES = {'linear': 0, 'add': 1, 'irn_fwd': 2, 'irn_inv': 3}
 
 
 def _dense_args(block, packs, b, h, w, mode, clamp):
-    a = _lib.DenseArgs(B=b, H=h, W=w, cin=block.channel_in, cout=block.channel_out, mode=_MODES[mode],
-                       winograd=int(USE_WINOGRAD[0]), clamp=float(clamp))
-    for i, (wf, bf, wd) in enumerate(packs):
-        a.w_fwd[i], a.b_fwd[i], a.w_dgrad[i] = wf.data_ptr(), bf.data_ptr(), wd.data_ptr()
-    return a
+    """A fresh sininn_dense_args with everything that does not change from call to call filled in: copied from a per-block
+    template that is rebuilt only when the pack list (its identity) or the shape / mode changes."""
+    key = (b, h, w, mode, float(clamp), bool(USE_WINOGRAD[0]))
+    cache = block.__dict__.setdefault('_args_tpl', {})
+    hit = cache.get(key)
+    if hit is None or hit[0] is not packs:
+        a = _lib.DenseArgs(B=b, H=h, W=w, cin=block.channel_in, cout=block.channel_out, mode=_MODES[mode],
+                           winograd=int(USE_WINOGRAD[0]), clamp=float(clamp))
+        for i, (wf, bf, wd) in enumerate(packs):
+            a.w_fwd[i], a.b_fwd[i], a.w_dgrad[i] = wf.data_ptr(), bf.data_ptr(), wd.data_ptr()
+        hit = (packs, bytes(a))
+        cache[key] = hit
+    return _lib.DenseArgs.from_buffer_copy(hit[1])
 
 
 class _DenseFn(torch.autograd.Function):
@@ -172,7 +181,7 @@ class _DenseFn(torch.autograd.Function):
             a2 = aux2.detach().contiguous()
             a.aux2, a.aux2_floats = a2.data_ptr(), a2.numel()
         check(_lib.lib().sininn_dense_forward(a, ops._stream()))
-        if block._grad_mode and any(ctx.needs_input_grad):      # the caller's grad mode (autograd is off inside forward)
+        if block.__dict__.get('_grad_mode', True) and any(ctx.needs_input_grad):      # the caller's grad mode (autograd is off inside forward)
             ctx.block, ctx.mode, ctx.clamp, ctx.shape = block, mode, clamp, (b, h, w, cin)
             ctx.save_for_backward(buf, out, a1 if a1 is not None else buf, a2 if a2 is not None else buf, xd)
             if GATE_TAP[0] is not None:          # parity tooling: the LeakyReLU gates of conv1-4 (feature slots of buf are > 0)
@@ -272,7 +281,8 @@ class DenseBlock(nn.Module):
         self._ar = {}
 
     def convs(self):
-        return (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5)
+        m = self._modules                      # the plain dict behind self.convK (nn.Module.__getattr__ is slow; hot path)
+        return (m['conv1'], m['conv2'], m['conv3'], m['conv4'], m['conv5'])
 
     def arange(self, dev):
         key = str(dev)
@@ -287,8 +297,8 @@ class DenseBlock(nn.Module):
         return self._ar[key]
 
     def run(self, x, mode='linear', aux1=None, aux2=None, clamp=1.0):
-        params = [p for cv in self.convs() for p in (cv.weight, cv.bias)]
-        self._grad_mode = torch.is_grad_enabled()
+        params = [q[n] for cv in self.convs() for q in (cv._parameters,) for n in ('weight', 'bias')]
+        self.__dict__['_grad_mode'] = torch.is_grad_enabled()
         return _DenseFn.apply(x, aux1, aux2, self, mode, float(clamp), *params)
 
     def forward(self, x):

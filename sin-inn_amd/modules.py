@@ -97,8 +97,11 @@ class _PackCache:
 
     @staticmethod
     def _key(conv, want_dgrad, wino_fwd, wino_dgrad, bf16=False):
-        return (conv.weight.data_ptr(), conv.weight._version, conv.bias._version, WEIGHTS_EPOCH[0], want_dgrad,
-                wino_fwd, wino_dgrad, bf16)
+        # (conv._parameters[...]: the plain dict behind conv.weight -- nn.Module.__getattr__ costs more than the rest of the key,
+        # and this runs a few hundred times per training step)
+        prm = conv._parameters
+        w, b = prm['weight'], prm['bias']
+        return (w.data_ptr(), w._version, b._version, WEIGHTS_EPOCH[0], want_dgrad, wino_fwd, wino_dgrad, bf16)
 
     def get(self, conv, colmap, want_dgrad, wino_fwd=False, wino_dgrad=False, bf16=False):
         key = self._key(conv, want_dgrad, wino_fwd, wino_dgrad, bf16)
@@ -240,24 +243,48 @@ def _pd(t):
 
 
 def _subnet_args(block, seq, co, dev, need_grad, with_grads):
-    conv1, conv2, k = inspect_subnet(seq)
+    """sininn_subnet descriptor of one subnet of `block` + the pack tensors it points into.  Called four times per block pass
+    (forward and backward, two subnets): the subnet's structure is inspected once per block, and the descriptor is rebuilt only
+    when a pack tuple or a gradient buffer it points to has been replaced (the optimiser refreshes packs IN PLACE)."""
+    which = 1 if seq is block._modules['s1'] else 2
+    sub = block.__dict__.get('_subinfo')
+    if sub is None or sub[0] is not block._modules['s1'] or sub[1] is not block._modules['s2']:
+        sub = (block._modules['s1'], block._modules['s2'], inspect_subnet(block._modules['s1']), inspect_subnet(block._modules['s2']))
+        block.__dict__['_subinfo'] = sub
+        block.__dict__['_subargs'] = {}
+    conv1, conv2, k = sub[1 + which]
     cmap = ops.coupling_colmap(co, dev)
     bf16 = block.precision == 'bf16'
     wino = USE_WINOGRAD[0] and k == 3 and not bf16
     wino_w2 = wino                                  # conv2 forward: (s|t) interleave of either width
+    p1, p2 = conv1._parameters, conv2._parameters
     # The data-gradient packs are built whenever the conv is trainable, not only when this call needs them: the cache key
     # then does not flip between no_grad (validation) and training passes, so an entry is never REPLACED mid-training --
     # a replacement would be packed lazily on whichever stream first misses (see ReversibleGraphNet.prepare_packs).
-    w1, b1, wd1 = block._packs.get(conv1, None, need_grad or conv1.weight.requires_grad, wino, wino, bf16)
-    w2, b2, wd2 = block._packs.get(conv2, cmap, need_grad or conv2.weight.requires_grad, wino_w2, wino, bf16)
+    pk1 = block._packs.get(conv1, None, need_grad or p1['weight'].requires_grad, wino, wino, bf16)
+    pk2 = block._packs.get(conv2, cmap, need_grad or p2['weight'].requires_grad, wino_w2, wino, bf16)
+    grads = None
+    if with_grads:
+        grads = tuple((_grad_buf(q['weight']), _grad_buf(q['bias'])) if q['weight'].requires_grad else None for q in (p1, p2))
+        gkey = tuple(None if g is None else (g[0].data_ptr(), g[1].data_ptr()) for g in grads)
+    else:
+        gkey = None
+    cache = block.__dict__['_subargs']
+    hit = cache.get((which, with_grads))
+    if hit is not None and hit[0] is pk1 and hit[1] is pk2 and hit[2] == gkey:
+        return hit[3], hit[4]
+    w1, b1, wd1 = pk1
+    w2, b2, wd2 = pk2
     a = SubnetArgs(w1=_pd(w1), b1=_pv(b1), w2=_pd(w2), b2=_pv(b2), w1_dgrad=_pd(wd1), w2_dgrad=_pd(wd2),
                    winograd=(1 if wino else 0) | (2 if wino_w2 else 0) | (12 if wino else 0))
     if with_grads:
-        if conv1.weight.requires_grad:
-            a.gw1, a.gb1 = _pv(_grad_buf(conv1.weight)), _pv(_grad_buf(conv1.bias))
-        if conv2.weight.requires_grad:
-            a.gw2, a.gb2 = _pv(_grad_buf(conv2.weight)), _pv(_grad_buf(conv2.bias))
-    return a, (w1, b1, wd1, w2, b2, wd2)
+        if grads[0] is not None:
+            a.gw1, a.gb1 = _pv(grads[0][0]), _pv(grads[0][1])
+        if grads[1] is not None:
+            a.gw2, a.gb2 = _pv(grads[1][0]), _pv(grads[1][1])
+    keep = (w1, b1, wd1, w2, b2, wd2)
+    cache[(which, with_grads)] = (pk1, pk2, gkey, a, keep)
+    return a, keep
 
 
 class _GlowFn(torch.autograd.Function):
@@ -275,7 +302,7 @@ class _GlowFn(torch.autograd.Function):
         lib = _lib.lib()
         # nothing is kept under torch.no_grad().  ctx.needs_input_grad reports the parameters' requires_grad whatever the grad
         # mode, and inside Function.forward autograd is always off: the caller's grad mode is sampled by apply_pixel_major
-        need_grad = block._grad_mode and any(ctx.needs_input_grad)
+        need_grad = block.__dict__.get('_grad_mode', True) and any(ctx.needs_input_grad)
         out = torch.empty_like(x)
         # zero-initialised log-det accumulator: a row of the buffer the graph executor zeroed once for the whole pass
         # (one fill instead of one per block), else a fresh tensor
@@ -359,12 +386,17 @@ class GLOWCouplingBlock(nn.Module):
         self.precision = 'fp32'
 
     def _params(self):
-        return [p for s in (self.s1, self.s2) for p in s.parameters()]
+        ps = self.__dict__.get('_param_list')
+        subs = (self._modules['s1'], self._modules['s2'])
+        if ps is None or ps[0] is not subs[0] or ps[1] is not subs[1]:
+            ps = (subs[0], subs[1], [p for s in subs for p in s.parameters()])
+            self.__dict__['_param_list'] = ps
+        return ps[2]
 
     _ld_row = None          # set by ReversibleGraphNet.forward for the next call only
 
     def apply_pixel_major(self, x, rev=False, dst=None):
-        self._grad_mode = torch.is_grad_enabled()
+        self.__dict__['_grad_mode'] = torch.is_grad_enabled()       # plain attribute: nn.Module.__setattr__ is slow (hot path)
         out, logdet = _GlowFn.apply(x, self, bool(rev), dst, *self._params())
         self.last_jac = logdet
         return out
