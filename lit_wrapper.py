@@ -296,7 +296,27 @@ class SingleVideoINN(pl.LightningModule):
             side.wait_stream(torch.cuda.current_stream())
         return st['loss']
 
+    # ---- host jitter: the cyclic garbage collector --------------------------------------------------------------------
+    # A full (generation-2) collection walks every container object of the process -- with torch imported that is 50 - 90 ms
+    # of host time (rocprofv3 timeline: idle gaps of that length every ~10 - 30 steps), several times the two
+    # steps of run-ahead the GPU has queued: the GPU drains and idles.  Whether one falls into a 20 - 30 step measurement is
+    # what made the step time bimodal (9.8 vs 11.2 - 12.8 ms at configs[1]).  After GC_FREEZE_AFTER steps -- modules, packs,
+    # streams, lazily built maps exist by then -- everything alive is moved to the permanent generation (gc.freeze): later
+    # collections only look at what a step itself creates.  SININN_GC_FREEZE=0 switches it off.
+    GC_FREEZE_AFTER = 3
+    _gc_frozen = [False]
+
+    def _maybe_freeze_gc(self):
+        n = self.__dict__.get('_steps_seen', 0) + 1
+        self.__dict__['_steps_seen'] = n
+        if n == self.GC_FREEZE_AFTER and not SingleVideoINN._gc_frozen[0] and os.environ.get('SININN_GC_FREEZE', '1') != '0':
+            import gc
+            gc.collect()
+            gc.freeze()
+            SingleVideoINN._gc_frozen[0] = True
+
     def training_step(self, batch, batch_idx):
+        self._maybe_freeze_gc()
         optim = self.optimizers()
         ring = self._throttle(batch[0]['hr']) if batch[0]['hr'].is_cuda else None
         total = None
