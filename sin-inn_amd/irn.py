@@ -101,12 +101,18 @@ class _DensePacks:
     conv, ~700 tiny launches per step on the main stream in front of the pass chains)."""
 
     def __init__(self):
-        self.entries, self.packs = None, None
+        self.entries, self.packs, self.sig = None, None, None
 
     def get(self, block):
         from .modules import _PACK_REGISTRY, _PackCache, _PackEntry
         convs = block.convs()
         wino = bool(USE_WINOGRAD[0])
+        # one cheap signature for the block first (this runs ~100 times per step): optimiser epoch, every parameter's version
+        # counter and storage address.  Equal to the signature the packs were last validated with -> nothing to check.
+        sig = (WEIGHTS_EPOCH[0], wino) + tuple(v for cv in convs for q in (cv._parameters,)
+                                               for v in (q['weight']._version, q['bias']._version, q['weight'].data_ptr()))
+        if sig == self.sig:
+            return self.packs
         keys = [_PackCache._key(cv, True, wino, wino, False) for cv in convs]
         if self.entries is None or any(e.key[0] != k[0] or e.key[4:] != k[4:] for e, k in zip(self.entries, keys)):
             # first use, another device / storage, or the Winograd switch flipped: (re)allocate and (re)register
@@ -130,6 +136,7 @@ class _DensePacks:
             ops.pack_batch_run(ops.pack_batch(descs, convs[0].weight.device))
             for e, k in zip(self.entries, keys):
                 e.key = k
+        self.sig = sig
         return self.packs
 
 
@@ -228,12 +235,13 @@ class _DenseFn(torch.autograd.Function):
         a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
         # weight gradients go to the dedicated side stream (like the GLOW executor's): every `+=` into a parameter gradient
         # is issued on that ONE stream, so two pass chains may run concurrently
-        main = torch.cuda.current_stream()
-        side = _side_stream(dev) if USE_SIDE_STREAM[0] else main
-        check(lib.sininn_dense_backward(a, ctypes.c_void_p(main.cuda_stream), ctypes.c_void_p(side.cuda_stream)))
+        main_h = ops._stream_handle()
+        side = _side_stream(dev) if USE_SIDE_STREAM[0] else None
+        side_h = side.cuda_stream if side is not None else main_h
+        check(lib.sininn_dense_backward(a, ctypes.c_void_p(main_h), ctypes.c_void_p(side_h)))
         if DEBUG_SYNC[0]:
             torch.cuda.synchronize()
-        if side is not main:
+        if side is not None and side_h != main_h:
             for t in (buf, dF, dD, ws, dout):
                 if t is not None:
                     t.record_stream(side)

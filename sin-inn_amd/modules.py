@@ -352,10 +352,11 @@ class _GlowFn(torch.autograd.Function):
                      scratch_bytes=nbytes, dout=_pv(dout), gld=_pv(gld), dx=_pv(dx),
                      skip_dx=0 if ctx.needs_input_grad[0] else 1,     # first block of a pass: nobody consumes dx
                      dtype=1 if block.precision == 'bf16' else 0)
-        main = torch.cuda.current_stream()
-        side = _side_stream(dev) if USE_SIDE_STREAM[0] else main
-        _lib.check(lib.sininn_glow_backward(C.byref(a), C.c_void_p(main.cuda_stream), C.c_void_p(side.cuda_stream)))
-        if side is not main:                # the weight-gradient kernels on the side stream still read these
+        main_h = ops._stream_handle()
+        side = _side_stream(dev) if USE_SIDE_STREAM[0] else None
+        side_h = side.cuda_stream if side is not None else main_h
+        _lib.check(lib.sininn_glow_backward(C.byref(a), C.c_void_p(main_h), C.c_void_p(side_h)))
+        if side is not None and side_h != main_h:                # the weight-gradient kernels on the side stream still read these
             for t in (scratch, saved, x) + keep1 + keep2:
                 if t is not None:
                     t.record_stream(side)

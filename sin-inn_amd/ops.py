@@ -13,8 +13,14 @@ from ._lib import ConvArgs, I64x4, check
 HIDDEN = 256
 
 
+def _stream_handle():
+    """raw hipStream_t (int) of torch's current stream on the current device.  torch.cuda.current_stream() builds a Stream
+    object through three layers of device-index helpers (~10 us, a hundred times per training step); the C binding is 0.3 us."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_stream_handle())
 
 
 def _chk(t, dtype=torch.float32):

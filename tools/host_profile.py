@@ -45,6 +45,7 @@ def main():
         step()
     torch.cuda.synchronize()
     print(f'{a.arch} {a.precision}: {(time.perf_counter() - t0) / a.steps * 1e3:.2f} ms per step (host-bound by construction)')
+    torch.autograd.set_multithreading_enabled(False)       # backward in THIS thread, so that the profile sees it
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(a.steps):
@@ -52,7 +53,7 @@ def main():
     torch.cuda.synchronize()
     pr.disable()
     st = pstats.Stats(pr)
-    st.sort_stats('tottime').print_stats(28)
+    st.sort_stats('tottime').print_stats(40)
 
 
 if __name__ == '__main__':
