@@ -119,7 +119,10 @@ class GlowBlock(nn.Module):
         bf = self.emulate_bf16
         g1 = g2 = None
         if self.forced_gates is not None:
-            g1, g2 = self.forced_gates['s1'], self.forced_gates['s2']
+            fg = self.forced_gates
+            if rev in fg:                # {False: {...}, True: {...}}: a training step evaluates the block in both directions
+                fg = fg[rev]
+            g1, g2 = fg['s1'], fg['s2']
         if not rev:
             r2 = run_subnet(self.s2, x2, bf, g2)
             s2, t2 = r2[:, :self.l1], r2[:, self.l1:]
@@ -248,15 +251,19 @@ class DenseBlockOracle(nn.Module):
         self.convs[4].weight.data *= 0
         self.convs[4].bias.data.zero_()
 
-        self.forced_gates = None         # checker: four (B,32,H,W) 0/1 masks replace the LeakyReLU decisions (run_subnet)
+        self.forced_gates = None         # checker: four (B,32,H,W) 0/1 masks replace the LeakyReLU decisions (run_subnet);
+        self.rev = False                 # or {False: [...], True: [...]} selected by the direction the owning block runs in
 
     def forward(self, x):
         feats = [x]
+        fg = self.forced_gates
+        if isinstance(fg, dict):
+            fg = fg[self.rev]
         for i, conv in enumerate(self.convs):
             y = conv(torch.cat(feats, 1))
             if i < 4:
-                if self.forced_gates is not None:
-                    g = self.forced_gates[i].to(y.dtype)
+                if fg is not None:
+                    g = fg[i].to(y.dtype)
                     y = y * (0.2 + 0.8 * g)
                 else:
                     y = F.leaky_relu(y, 0.2)
@@ -276,6 +283,7 @@ class InvBlockExpOracle(nn.Module):
 
     def forward(self, x, rev=False):
         x1, x2 = x[:, :self.l1], x[:, self.l1:]
+        self.F.rev = self.G.rev = self.H.rev = bool(rev)
         if not rev:
             y1 = x1 + self.F(x2)
             s = self.clamp * (torch.sigmoid(self.H(y1)) * 2 - 1)

@@ -193,7 +193,8 @@ class _DenseFn(torch.autograd.Function):
             ctx.save_for_backward(buf, out, a1 if a1 is not None else buf, a2 if a2 is not None else buf, xd)
             if GATE_TAP[0] is not None:          # parity tooling: the LeakyReLU gates of conv1-4 (feature slots of buf are > 0)
                 feats = buf.view(b, h, w, bw)[..., cinp:]
-                GATE_TAP[0].append((block, None, [(feats[..., GC * i:GC * (i + 1)] > 0).permute(0, 3, 1, 2) for i in range(4)]))
+                GATE_TAP[0].append((block, block.__dict__.get('_tap_rev'),
+                                    [(feats[..., GC * i:GC * (i + 1)] > 0).permute(0, 3, 1, 2) for i in range(4)]))
         return out
 
     @staticmethod
@@ -325,6 +326,9 @@ class InvBlockExp(nn.Module):
         self.H = DenseBlock(self.split_len1, self.split_len2)
 
     def apply_pixel_major(self, x, rev=False):
+        if GATE_TAP[0] is not None:            # parity tooling: the direction this pass runs in, recorded with the gates
+            for blk in (self.F, self.G, self.H):
+                blk.__dict__['_tap_rev'] = bool(rev)
         x1, x2 = x[..., :self.split_len1], x[..., self.split_len1:]
         if not rev:
             y1 = self.F.run(x2, 'add', x1)                               # y1 = x1 + F(x2)

@@ -223,3 +223,107 @@ def test_irn_random_shape_sweep_with_forced_gates():
         seen.add((8 * rng.randint(2, 12), rng.randint(1, 3), rng.randint(1, 2)))
     for i, (size, b, c) in enumerate(sorted(seen)):
         _irn_case(size, c, b, seed=200 + i)
+
+
+@pytest.mark.parametrize('arch,batch', [('SRF', 16), ('SRF', 2), ('IRN', 2)])
+def test_training_step_at_baseline_config_shape_with_forced_gates(arch, batch):
+    """The WHOLE training step (reference lit_wrapper.py:29-77: forward pass + loss + backward, reverse pass + loss + backward,
+    Adam) at BASELINE configs[1]'s own shape -- 256x256, -c 4, lr_window 10, the benchmark's batch 16 -- against the float64
+    oracle step with the gates of BOTH passes forced to the ones the HIP step took: logged loss, every parameter's accumulated
+    gradient (max-norm 2e-5) and the Adam update.  This is the comparison tests/test_gpu_model.py::
+    test_baseline_config_shape_matches_oracle makes against the fp32 oracle with max-norm bounds of 2e-3 (gate flips); here
+    nothing is left to flip."""
+    import lit_wrapper
+    from data import FrameStore
+    from oracle import sininn_oracle as O
+    from sin_inn_amd.functional import sample_windows
+    from test_gpu_model import make_opt
+    import archs
+    torch.manual_seed(23)
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    opt = make_opt(num_coupling=4, lr_window=10, architecture=arch, lambda_latent_nll=0.5)
+    model = lit_wrapper.SingleVideoINN(3, 256, 256, opt)
+    if arch == 'IRN':
+        g5 = torch.Generator().manual_seed(24)
+        for m in model.inn.modules():
+            if isinstance(m, archs.DenseBlock):
+                m.conv5.weight.data = torch.randn(m.conv5.weight.shape, generator=g5) * 0.02
+        ref64 = O.IRNOracle(3, opt.lr_dims, scale=4, num_coupling=4)
+        O.load_reference_irn_state(ref64, {k[len('inn.'):]: v.detach().clone() for k, v in model.state_dict().items()})
+        ref64.double()
+    else:
+        ref64 = O.SRFlowOracle(3, 256, 256, scale=4, num_coupling=4).double()
+        ref64.load_state_dict({k[len('inn.'):]: v.detach().double() for k, v in model.state_dict().items()})
+    model.cuda()
+    optim = model.attach_optimizer()
+    store = FrameStore.synthetic(40, 256, 256)
+    g = torch.Generator().manual_seed(8)
+    idx = torch.randint(10, 30, (batch,), generator=g)
+    hr_g, lr_g = sample_windows(store.hr.cuda(), store.lr.cuda(), idx.cuda(), 10)
+    pairs = [O.gather_window(store.lr, store.hr, i, 10) for i in idx.tolist()]
+    hr_c, lr_c = torch.stack([p[0] for p in pairs]).double(), torch.stack([p[1] for p in pairs]).double()
+    z = torch.randn(batch, opt.z_dims, 32, 32, generator=g)
+    z_dev = z.cuda().permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)       # pixel-major like lit_wrapper._latent's
+    real_latent = lit_wrapper._latent
+    lit_wrapper._latent = lambda b, zd, h, w, device, temp=1.0: z_dev
+    before = optim.flat_params()[0].detach().cpu().clone()
+    try:
+        _, taps = _tapped(lambda: model.training_step([{'hr': hr_g, 'lr': lr_g}, {'hr': hr_g, 'lr': lr_g}], 0))
+    finally:
+        lit_wrapper._latent = real_latent
+    # route the gates of both passes to the oracle's blocks
+    if arch == 'SRF':
+        mods = list(model.inn.module_list)
+        per = {}
+        for blk, rev, gates in taps:
+            i = next(j for j, m in enumerate(mods) if m is blk)
+            per.setdefault(i, {})[rev] = {k: v.cpu() for k, v in gates.items()}
+        assert all(set(d) == {False, True} for d in per.values()) and len(per) == 8
+        for i, d in per.items():
+            ref64.module_list[i].forced_gates = d
+        hip_named = [(n[len('inn.'):], p) for n, p in model.named_parameters()]
+        ref_named = dict(ref64.named_parameters())
+        key = lambda n: n
+    else:
+        hip_blocks = [m for m in model.inn.modules() if isinstance(m, archs.InvBlockExp)]
+        twin = {}
+        for hb, ob in zip(hip_blocks, ref64.blocks):
+            for name in 'FGH':
+                twin[id(getattr(hb, name))] = getattr(ob, name)
+        per = {}
+        for blk, rev, gates in taps:
+            per.setdefault(id(blk), {})[rev] = [t.cpu() for t in gates]
+        assert all(set(d) == {False, True} for d in per.values()) and len(per) == 3 * len(hip_blocks)
+        for k, d in per.items():
+            twin[k].forced_gates = d
+        named = dict(model.inn.named_parameters())
+        op_ids = sorted({int(k.split('.')[1]) for k in named if '.conv' in k})
+        inv = {}
+        for n, _ in ref64.named_parameters():
+            p = n.split('.')
+            inv[f'operations.{op_ids[int(p[1])]}.{p[2]}.conv{int(p[4]) + 1}.{p[5]}'] = n
+        hip_named = [(n[len('inn.'):], p) for n, p in model.named_parameters() if p.requires_grad]
+        ref_named = dict(ref64.named_parameters())
+        key = lambda n: inv[n]
+    lam = dict(fwd_rec=1.0, fwd_mmd=0.0, latent_nll=0.5, bwd_rec=1.0, bwd_mmd=0.0)
+    f64, b64, _, _, _ = O.training_step(ref64, hr_c, lr_c, z.double(), lam, opt.lr_dims)
+    assert abs(float(model._logged['train']) / float(f64 + b64) - 1) < RTOL
+    flat_g = optim.flat_grads()[0].cpu()
+    off, pairs_g, ref_order = 0, [], []
+    for n, p in hip_named:
+        k = p.numel()
+        pairs_g.append((n, flat_g[off:off + k], ref_named[key(n)].grad.reshape(-1)))
+        ref_order.append(ref_named[key(n)])
+        off += k
+    wm, wl = _check_params(pairs_g, f'{arch} training step, batch {batch}')
+    print(f'[forced gates] {arch} TRAINING STEP 256x256 -c 4 batch {batch}: loss rel {abs(float(model._logged["train"]) / float(f64 + b64) - 1):.1e}; '
+          f'parameter gradients worst max-norm {wm:.1e}, worst L2 {wl:.1e}')
+    # Adam as the reference configures it, in float64, on the oracle's parameters (same order as the flat buffer)
+    o = torch.optim.Adam(ref_order, lr=opt.learning_rate, betas=tuple(opt.adam_betas), weight_decay=opt.weight_decay)
+    o.step()
+    new_ref = torch.cat([p.detach().reshape(-1) for p in ref_order])
+    new_hip = optim.flat_params()[0].detach().cpu()[:new_ref.numel()].double()
+    ref_g = torch.cat([t[2] for t in pairs_g])
+    big = ref_g.abs() > 1e-3 * ref_g.abs().max()         # the first Adam step is ~ -lr * sign(g): compare where g is not noise
+    upd_h, upd_r = (new_hip - before[:new_ref.numel()].double())[big], (new_ref - before[:new_ref.numel()].double())[big]
+    assert float((upd_h - upd_r).abs().max() / upd_r.abs().max()) < 1e-3
