@@ -243,6 +243,11 @@ int sininn_coupling_bwd(const float* dy, int dy_stride, const int* dy_map,
 int sininn_haar(const float* in, const int64_t in_strides[4], float* out, const int64_t out_strides[4],
                 int B, int C, int H, int W, int inverse, void* stream);
 int sininn_lrelu_bwd(float* g, int g_stride, const float* f, int f_stride, int64_t M, int n, float slope, void* stream);
+/* irn_tail: the InvBlockExp tail on its own (archs.py:152-156): out = v * exp(s) + g (inverse == 0) or (v - g) / exp(s)
+ *   (inverse == 1), s = clamp * (2 sigmoid(h) - 1); h, g [M][Co] compact, v / out at their pixel strides.  Its backward is
+ *   sininn_irn_coupling_bwd.  Lets the H and G DenseBlocks of a block run on two streams (ABI v4). */
+int sininn_irn_tail(const float* v, int v_stride, const float* h, const float* g, int64_t M, int Co, float clamp, int inverse,
+                    float* out, int out_stride, void* stream);
 int sininn_irn_coupling_bwd(const float* dy, int dy_stride, const float* vy, int vy_stride, const float* hval,
                             int64_t M, int Co, float clamp, int inverse, float* dG, float* dh, float* dv,
                             int dv_stride, void* stream);

@@ -153,6 +153,7 @@ _SIGS = {
     'sininn_dense_backward': (C.c_int, [C.POINTER(DenseArgs), C.c_void_p, C.c_void_p]),
     'sininn_haar': (C.c_int, [c_f, I64x4, c_f, I64x4, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'sininn_lrelu_bwd': (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
+    'sininn_irn_tail': (C.c_int, [c_f, C.c_int, c_f, c_f, C.c_int64, C.c_int, C.c_float, C.c_int, c_f, C.c_int, C.c_void_p]),
     'sininn_irn_coupling_bwd': (C.c_int, [c_f, C.c_int, c_f, C.c_int, c_f, C.c_int64, C.c_int, C.c_float, C.c_int,
                                           c_f, c_f, c_f, C.c_int, C.c_void_p]),
     'sininn_squeeze': (C.c_int, [c_f, I64x4, c_f, I64x4, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i,

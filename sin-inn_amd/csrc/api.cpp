@@ -71,6 +71,8 @@ int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float l
 int haar_launch(const float* in, const int64_t is[4], float* out, const int64_t os[4], int B, int C, int H, int W,
                 int inverse, hipStream_t st);
 int lrelu_bwd_launch(float* g, int g_stride, const float* f, int f_stride, int64_t M, int n, float slope, hipStream_t st);
+int irn_tail_launch(const float* v, int v_stride, const float* h, const float* g, int64_t M, int Co, float clamp, int inverse,
+                    float* out, int out_stride, hipStream_t st);
 int irn_coupling_bwd_launch(const float* dy, int dy_stride, const float* vy, int vy_stride, const float* hval, int64_t M,
                             int Co, float clamp, int inverse, float* dG, int dG_stride, int dG_pad, float* dh, float* dv,
                             int dv_stride, hipStream_t st);
@@ -294,6 +296,11 @@ int sininn_irn_coupling_bwd(const float* dy, int dy_stride, const float* vy, int
                             void* stream) {
   return irn_coupling_bwd_launch(dy, dy_stride, vy, vy_stride, hval, M, Co, clamp, inverse, dG, Co, Co, dh, dv, dv_stride,
                                  ST(stream));
+}
+
+int sininn_irn_tail(const float* v, int v_stride, const float* h, const float* g, int64_t M, int Co, float clamp, int inverse,
+                    float* out, int out_stride, void* stream) {
+  return irn_tail_launch(v, v_stride, h, g, M, Co, clamp, inverse, out, out_stride, ST(stream));
 }
 
 int sininn_squeeze(const float* in, const int64_t in_strides[4], float* out, const int64_t out_strides[4], int B, int C,

@@ -931,6 +931,39 @@ __global__ void irn_coupling_bwd_kernel(const float* __restrict__ dy, int dy_str
   }
 }
 
+// Stand-alone InvBlockExp tail (archs.py:152-156): out = v * exp(s) + g (inverse == 0) or (v - g) / exp(s) (inverse == 1),
+// s = clamp * (2 sigmoid(h) - 1).  The DenseBlock executor fuses this into conv5's epilogue; the stand-alone form lets the H and
+// G DenseBlocks of a block run on two streams (the tail then joins them).  float4 per lane; Co % 4 == 0.
+__global__ void irn_tail_kernel(const float* __restrict__ v, int v_stride, const float* __restrict__ h, const float* __restrict__ g,
+                                int64_t total4, int Co4, float clamp, int inverse, float* __restrict__ out, int out_stride) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % Co4);
+    const int64_t m = i / Co4;
+    const f32x4 vv = *reinterpret_cast<const f32x4*>(v + m * v_stride + c4 * 4);
+    const f32x4 hv = *reinterpret_cast<const f32x4*>(h + i * 4);
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i * 4);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float sv = clamp * (2.f / (1.f + expf(-hv[j])) - 1.f);
+      o[j] = inverse ? (vv[j] - gv[j]) / expf(sv) : vv[j] * expf(sv) + gv[j];
+    }
+    *reinterpret_cast<f32x4*>(out + m * out_stride + c4 * 4) = o;
+  }
+}
+
+int irn_tail_launch(const float* v, int v_stride, const float* h, const float* g, int64_t M, int Co, float clamp, int inverse,
+                    float* out, int out_stride, hipStream_t st) {
+  SININN_CHECK(v && h && g && out && M > 0 && Co > 0 && Co % 4 == 0 && clamp > 0.f, "irn_tail: bad arguments");
+  SININN_CHECK(v_stride >= Co && out_stride >= Co && v_stride % 4 == 0 && out_stride % 4 == 0, "irn_tail: strides");
+  SININN_CHECK(aligned16(v) && aligned16(h) && aligned16(g) && aligned16(out), "irn_tail: 16-byte alignment");
+  const int64_t total4 = M * (Co / 4);
+  const int blocks = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
+  hipLaunchKernelGGL(irn_tail_kernel, dim3(blocks), dim3(256), 0, st, v, v_stride, h, g, total4, Co / 4, clamp, inverse, out, out_stride);
+  SININN_LAUNCH_CHECK("irn_tail");
+  return 0;
+}
+
 int irn_coupling_bwd_launch(const float* dy, int dy_stride, const float* vy, int vy_stride, const float* hval, int64_t M,
                             int Co, float clamp, int inverse, float* dG, int dG_stride, int dG_pad, float* dh, float* dv,
                             int dv_stride, hipStream_t st) {

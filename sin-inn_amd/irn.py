@@ -209,6 +209,7 @@ class _DenseFn(torch.autograd.Function):
         packs = block._packs.get(block)
         convs = block.convs()
         dout = dout.contiguous()
+        dout.record_stream(torch.cuda.current_stream())     # may have been produced on another chain / helper stream
         lib = _lib.lib()
         irn = mode in ('irn_fwd', 'irn_inv')
         a = _dense_args(block, packs, b, h, w, mode, clamp)
@@ -315,6 +316,54 @@ class DenseBlock(nn.Module):
         return self.run(import_nchw(x)).permute(0, 3, 1, 2)
 
 
+class _IrnTailFn(torch.autograd.Function):
+    """y = v * exp(s) + g  (inverse: (v - g) / exp(s)),  s = clamp * (2 sigmoid(h) - 1): the InvBlockExp tail as a node of its
+    own (sininn_irn_tail / sininn_irn_coupling_bwd).  With the tail outside G's DenseBlock call, H(y1) and G(y1) are
+    independent autograd nodes in both directions of differentiation and can run on two streams."""
+
+    @staticmethod
+    def forward(ctx, v, h, g, clamp, inverse):
+        vd, vs = _pixel_view(v.detach())
+        hd, gd = h.detach().contiguous(), g.detach().contiguous()
+        b, hh, ww, co = vd.shape
+        out = torch.empty((b, hh, ww, co), device=vd.device, dtype=torch.float32)
+        check(_lib.lib().sininn_irn_tail(vd.data_ptr(), vs, hd.data_ptr(), gd.data_ptr(), b * hh * ww, co, float(clamp), int(inverse),
+                                         out.data_ptr(), co, ops._stream()))
+        ctx.clamp, ctx.inverse = float(clamp), int(inverse)
+        ctx.save_for_backward(out if inverse else vd, hd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        vy, hd = ctx.saved_tensors
+        b, hh, ww, co = hd.shape
+        m = b * hh * ww
+        dout = dout.contiguous()
+        vyv, vys = _pixel_view(vy)
+        dg = torch.empty((b, hh, ww, co), device=hd.device, dtype=torch.float32)
+        dh = torch.empty_like(dg)
+        dv = torch.empty_like(dg)
+        check(_lib.lib().sininn_irn_coupling_bwd(dout.data_ptr(), co, vyv.data_ptr(), vys, hd.data_ptr(), m, co, ctx.clamp, ctx.inverse,
+                                                 dg.data_ptr(), dh.data_ptr(), dv.data_ptr(), co, ops._stream()))
+        return dv, dh, dg, None, None
+
+
+_AUX = {}
+# H(y1) on a second stream beside G(y1): level-1 DenseBlock convs launch 64 blocks on 256 CUs, so a pass chain alone leaves most
+# of the chip idle; `bench.py --arch IRN` --overlap none / wgrad / full = 25.0 / 24.7 / 21.1 ms says chain-level concurrency is what
+# this architecture responds to.  SININN_IRN_HG=0 restores the single-chain block with the tail fused into G's conv5.
+import os as _os
+HG_OVERLAP = [_os.environ.get('SININN_IRN_HG', '1') != '0']
+
+
+def _aux_stream(device):
+    """the helper stream that belongs to the CURRENT stream (each pass chain of a training step gets its own)"""
+    key = (str(device), ops._stream_handle())
+    if key not in _AUX:
+        _AUX[key] = torch.cuda.Stream(device=device)
+    return _AUX[key]
+
+
 class InvBlockExp(nn.Module):
     def __init__(self, channel_num, channel_split_num, clamp=1.):
         super().__init__()
@@ -330,6 +379,8 @@ class InvBlockExp(nn.Module):
             for blk in (self.F, self.G, self.H):
                 blk.__dict__['_tap_rev'] = bool(rev)
         x1, x2 = x[..., :self.split_len1], x[..., self.split_len1:]
+        if HG_OVERLAP[0] and x.is_cuda:
+            return self._apply_two_streams(x1, x2, rev)
         if not rev:
             y1 = self.F.run(x2, 'add', x1)                               # y1 = x1 + F(x2)
             hval = self.H.run(y1)                                        # s = clamp*(2*sigmoid(H(y1)) - 1)
@@ -338,6 +389,24 @@ class InvBlockExp(nn.Module):
             hval = self.H.run(x1)
             y2 = self.G.run(x1, 'irn_inv', x2, hval, self.clamp)         # y2 = (x2 - G(x1)) / exp(s)
             y1 = x1 - self.F.run(y2)                                     # y1 = x1 - F(y2)
+        return torch.cat((y1, y2), dim=3)
+
+    def _apply_two_streams(self, x1, x2, rev):
+        """The same block with H and G as independent nodes: H runs on the chain's helper stream beside G, the stand-alone tail
+        joins them.  Backward mirrors it by itself: the tail's backward yields dh and dG, and autograd runs every node on the
+        stream its forward ran on (with the event waits between them), so H's and G's backward overlap as well."""
+        main = torch.cuda.current_stream()
+        aux = _aux_stream(x1.device)
+        cond = x1 if rev else self.F.run(x2, 'add', x1)                  # y1 = x1 + F(x2) in the forward direction
+        aux.wait_stream(main)
+        with torch.cuda.stream(aux):
+            hval = self.H.run(cond)
+        cond.record_stream(aux)
+        gout = self.G.run(cond)
+        main.wait_stream(aux)
+        hval.record_stream(main)
+        y2 = _IrnTailFn.apply(x2, hval, gout, self.clamp, 1 if rev else 0)
+        y1 = (x1 - self.F.run(y2)) if rev else cond
         return torch.cat((y1, y2), dim=3)
 
     def forward(self, x, rev=False):
