@@ -349,9 +349,9 @@ class _IrnTailFn(torch.autograd.Function):
 
 
 _AUX = {}
-# H(y1) on a second stream beside G(y1): level-1 DenseBlock convs launch 64 blocks on 256 CUs, so a pass chain alone leaves most
-# of the chip idle; `bench.py --arch IRN` --overlap none / wgrad / full = 25.0 / 24.7 / 21.1 ms says chain-level concurrency is what
-# this architecture responds to.  SININN_IRN_HG=0 restores the single-chain block with the tail fused into G's conv5.
+# H(y1) on a second stream beside G(y1) in no-grad passes: level-1 DenseBlock convs launch 64 blocks on 256 CUs, so a single pass
+# chain leaves most of the chip idle (`bench.py --arch IRN --overlap none / wgrad / full` = 25.0 / 24.7 / 21.1 ms: chain-level
+# concurrency is what this architecture responds to).  SININN_IRN_HG=0 switches it off.
 import os as _os
 HG_OVERLAP = [_os.environ.get('SININN_IRN_HG', '1') != '0']
 
@@ -379,7 +379,11 @@ class InvBlockExp(nn.Module):
             for blk in (self.F, self.G, self.H):
                 blk.__dict__['_tap_rev'] = bool(rev)
         x1, x2 = x[..., :self.split_len1], x[..., self.split_len1:]
-        if HG_OVERLAP[0] and x.is_cuda:
+        # two streams only for passes that are not differentiated (validation / inference: ONE chain, which leaves the chip
+        # underfilled -- IRN inverse pass at batch 40: 7.43 -> 6.46 ms).  A training step already runs two pass chains and the
+        # weight-gradient stream; H beside G on top of that measured slower (21.0 -> 23.4 ms: two more streams, the tail as a
+        # kernel of its own), so training keeps the single-chain block with the tail fused into G's conv5.
+        if HG_OVERLAP[0] and x.is_cuda and not torch.is_grad_enabled():
             return self._apply_two_streams(x1, x2, rev)
         if not rev:
             y1 = self.F.run(x2, 'add', x1)                               # y1 = x1 + F(x2)

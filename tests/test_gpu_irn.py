@@ -336,3 +336,43 @@ def test_saved_tensors_outlive_the_weight_gradient_stream(arch):
     assert all(torch.isfinite(g).all() for g in got)
     for n, a, b in zip([n for n, p in net.named_parameters() if p.requires_grad], got, base):
         assert torch.equal(a, b), n
+
+
+@pytest.mark.parametrize('rev', [False, True])
+def test_two_stream_block_equals_the_fused_block(rev):
+    """No-grad passes run H beside G on a helper stream with the InvBlockExp tail as a kernel of its own (sininn_irn_tail);
+    the differentiable pass keeps the tail fused into G's conv5.  Same block, same input: the two agree to fp32 rounding in
+    both directions, the tail's own backward (sininn_irn_coupling_bwd through _IrnTailFn) matches autograd of the formula,
+    and a network-level no-grad pass equals the differentiable one."""
+    import archs
+    from sin_inn_amd import irn as I
+    torch.manual_seed(17)
+    blk = archs.InvBlockExp(48, 24)
+    _reseed_conv5(blk, 18, scale=0.05)
+    blk.cuda()
+    x = torch.randn(2, 48, 24, 40, device='cuda')
+    with torch.no_grad():
+        y_two = blk(x, rev=rev)
+    y_fused = blk(x.clone().requires_grad_(True), rev=rev)
+    assert relerr(y_two, y_fused) < 1e-6
+    try:
+        I.HG_OVERLAP[0] = False
+        with torch.no_grad():
+            y_one = blk(x, rev=rev)
+    finally:
+        I.HG_OVERLAP[0] = True
+    assert relerr(y_two, y_one) < 1e-6
+    # the stand-alone tail and its backward against autograd of the formula
+    v = torch.randn(2, 6, 7, 24, device='cuda', requires_grad=True)
+    h = torch.randn(2, 6, 7, 24, device='cuda', requires_grad=True)
+    g = torch.randn(2, 6, 7, 24, device='cuda', requires_grad=True)
+    w = torch.randn(2, 6, 7, 24, device='cuda')
+    out = I._IrnTailFn.apply(v, h, g, 1.0, 1 if rev else 0)
+    (out * w).sum().backward()
+    v2, h2, g2 = (t.detach().clone().requires_grad_(True) for t in (v, h, g))
+    s = 1.0 * (torch.sigmoid(h2) * 2 - 1)
+    ref = (v2 - g2) / torch.exp(s) if rev else v2 * torch.exp(s) + g2
+    (ref * w).sum().backward()
+    assert relerr(out, ref) < 1e-6
+    for a, b in ((v, v2), (h, h2), (g, g2)):
+        assert relerr(a.grad, b.grad) < 1e-5
