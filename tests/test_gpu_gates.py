@@ -327,3 +327,15 @@ def test_training_step_at_baseline_config_shape_with_forced_gates(arch, batch):
     big = ref_g.abs() > 1e-3 * ref_g.abs().max()         # the first Adam step is ~ -lr * sign(g): compare where g is not noise
     upd_h, upd_r = (new_hip - before[:new_ref.numel()].double())[big], (new_ref - before[:new_ref.numel()].double())[big]
     assert float((upd_h - upd_r).abs().max() / upd_r.abs().max()) < 1e-3
+
+
+def test_srf_at_config3_shape_with_forced_gates():
+    """BASELINE configs[3]'s frame size and depth (512x512, -c 4, lr_window 10) in the fp32 arithmetic, batch 2."""
+    _srf_case((512, 512), 4, 2, seed=33)
+
+
+def test_srf_at_config4_shape_12_blocks_with_forced_gates():
+    """BASELINE configs[4] as a 12-block INN at 1280x720 (`-c 6`: six GLOW blocks per level; SURVEY 8 tabulates both readings of
+    "12-block"), lr_window 10, batch 1, fp32 arithmetic: forward, log-det, input gradients and every parameter gradient of the
+    deep network at that frame size, both directions."""
+    _srf_case((720, 1280), 6, 1, seed=35)
