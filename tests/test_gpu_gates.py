@@ -334,8 +334,9 @@ def test_srf_at_config3_shape_with_forced_gates():
     _srf_case((512, 512), 4, 2, seed=33)
 
 
-def test_srf_at_config4_shape_12_blocks_with_forced_gates():
-    """BASELINE configs[4] as a 12-block INN at 1280x720 (`-c 6`: six GLOW blocks per level; SURVEY 8 tabulates both readings of
-    "12-block"), lr_window 10, batch 1, fp32 arithmetic: forward, log-det, input gradients and every parameter gradient of the
-    deep network at that frame size, both directions."""
-    _srf_case((720, 1280), 6, 1, seed=35)
+@pytest.mark.parametrize('num_coupling', [6, 12])
+def test_srf_at_config4_shape_and_depth_with_forced_gates(num_coupling):
+    """BASELINE configs[4] at its own frame size AND depth: 1280x720, lr_window 10, `-c 12` (24 GLOW blocks: what bench.py
+    --config 4 runs) and `-c 6` (the other reading of "12-block INN"), batch 1, in the fp32 arithmetic: forward, log-det,
+    input gradients and every parameter gradient of the deep network at that frame size, both directions."""
+    _srf_case((720, 1280), num_coupling, 1, seed=35)
