@@ -641,7 +641,13 @@ __global__ void flow_warp_l1_bwd_kernel(const T* __restrict__ img, const float* 
 // all round, per channel) with ds_add_f32 and the window is flushed once with row-contiguous global atomics; only taps
 // further away go to HBM atomics directly (plain per-tap global atomics made this kernel 17x slower than its flow-only
 // form: 1.3 ms at 16x3x512x512).
-constexpr int FB_TX = 32, FB_TY = 8, FB_R = 8, FB_WX = FB_TX + 2 * FB_R, FB_WY = FB_TY + 2 * FB_R;
+#ifndef FLOWBWD_TY
+#define FLOWBWD_TY 8
+#endif
+#ifndef FLOWBWD_R
+#define FLOWBWD_R 8
+#endif
+constexpr int FB_TX = 32, FB_TY = FLOWBWD_TY, FB_R = FLOWBWD_R, FB_WX = FB_TX + 2 * FB_R, FB_WY = FB_TY + 2 * FB_R;   // build tunables
 template <typename T>
 __global__ __launch_bounds__(FB_TX * FB_TY) void flow_warp_l1_bwd_tiled_kernel(
     const T* __restrict__ img, const float* __restrict__ flow, const T* __restrict__ target,
@@ -669,14 +675,27 @@ __global__ __launch_bounds__(FB_TX * FB_TY) void flow_warp_l1_bwd_tiled_kernel(
   const float wx1 = ix - flx, wy1 = iy - fly, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
   const float gm = (live && gmetric) ? gmetric[(int64_t)b * HW + r] / (float)C : 0.f;
   const int wx = x0 - (bx0 - FB_R), wy = y0 - (by0 - FB_R);             // window coordinates of the north-west tap
+  // neighbour relations inside the wave (lanes 0..31 = one tile row, 32..63 = the row below it; FB_TX == 32)
+  static_assert(FB_TX == 32, "the lane merges assume 32-pixel tile rows");
+  const int lane = threadIdx.x & 63;
+  const int fin = finite ? 1 : 0;
+  // (every shuffle is executed by all 64 lanes before anything is combined: no short-circuit around a cross-lane read)
+  const int fin_r = __shfl_down(fin, 1), x0_r = __shfl_down(x0, 1), y0_r = __shfl_down(y0, 1);
+  const int fin_d = __shfl_down(fin, 32), x0_d = __shfl_down(x0, 32), y0_d = __shfl_down(y0, 32);
+  const bool give_h = finite && (lane & 31) != 31 && fin_r != 0 && x0_r == x0 + 1 && y0_r == y0;
+  const bool give_v = finite && lane < 32 && fin_d != 0 && x0_d == x0 && y0_d == y0 + 1;
+  const int gh_l = __shfl_up(give_h ? 1 : 0, 1), gv_u = __shfl_up(give_v ? 1 : 0, 32);
+  const bool take_h = (lane & 31) != 0 && gh_l != 0;
+  const bool take_v = lane >= 32 && gv_u != 0;
   float gix = 0.f, giy = 0.f;
   for (int c0 = 0; c0 < C; c0 += CC) {
     const int cc = min(CC, C - c0);
     for (int e = threadIdx.x; e < cc * FB_WY * FB_WX; e += FB_TX * FB_TY) (&win[0][0][0])[e] = 0.f;
     __syncthreads();
-    if (finite) {
-      for (int c = 0; c < cc; ++c) {
-        const int64_t o = ((int64_t)b * C + c0 + c) * HW;
+    for (int c = 0; c < cc; ++c) {                      // every lane walks the channels: the merges below are wave-wide
+      const int64_t o = ((int64_t)b * C + c0 + c) * HW;
+      float c00 = 0.f, c01 = 0.f, c10 = 0.f, c11 = 0.f;
+      if (finite) {
         float g = gwarped ? fw_ld(gwarped, o + r) : 0.f;
         if (gmetric) {
           const float d = fw_ld(target, o + r) - fw_ld(warped, o + r);
@@ -689,16 +708,27 @@ __global__ __launch_bounds__(FB_TX * FB_TY) void flow_warp_l1_bwd_tiled_kernel(
         const float t00 = tap(y0, x0), t01 = tap(y0, x0 + 1), t10 = tap(y0 + 1, x0), t11 = tap(y0 + 1, x0 + 1);
         gix += g * ((t01 - t00) * wy0 + (t11 - t10) * wy1);
         giy += g * ((t10 - t00) * wx0 + (t11 - t01) * wx1);
-        auto put = [&](int dy, int dx, float wgt) {
-          const int yy = y0 + dy, xx = x0 + dx;
-          if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-            const int qy = wy + dy, qx = wx + dx;
-            if (qy >= 0 && qy < FB_WY && qx >= 0 && qx < FB_WX) atomicAdd(&win[c][qy][qx], g * wgt);
-            else atomicAdd(gimg + o + (int64_t)yy * W + xx, g * wgt);
-          }
-        };
-        put(0, 0, wy0 * wx0); put(0, 1, wy0 * wx1); put(1, 0, wy1 * wx0); put(1, 1, wy1 * wx1);
+        c00 = g * wy0 * wx0; c01 = g * wy0 * wx1; c10 = g * wy1 * wx0; c11 = g * wy1 * wx1;
       }
+      // For a locally smooth flow the four taps of neighbouring output pixels coincide: the bottom taps of a pixel are the top
+      // taps of the pixel below it (the wave's other row), its right taps the left taps of its right neighbour.  The
+      // contributions are summed across lanes first, so an interior pixel issues ONE LDS atomic per channel instead of four
+      // (every lane then adds to a different address: no same-address serialisation inside the wave).
+      const float r10 = __shfl_up(c10, 32), r11 = __shfl_up(c11, 32);
+      if (take_v) { c00 += r10; c01 += r11; }
+      if (give_v) { c10 = 0.f; c11 = 0.f; }
+      const float s01 = __shfl_up(c01, 1), s11 = __shfl_up(c11, 1);
+      if (take_h) { c00 += s01; c10 += s11; }
+      if (give_h) { c01 = 0.f; c11 = 0.f; }
+      auto put = [&](int dy, int dx, float val) {
+        const int yy = y0 + dy, xx = x0 + dx;
+        if (val != 0.f && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+          const int qy = wy + dy, qx = wx + dx;
+          if (qy >= 0 && qy < FB_WY && qx >= 0 && qx < FB_WX) atomicAdd(&win[c][qy][qx], val);
+          else atomicAdd(gimg + o + (int64_t)yy * W + xx, val);
+        }
+      };
+      if (finite) { put(0, 0, c00); put(0, 1, c01); put(1, 0, c10); put(1, 1, c11); }
     }
     __syncthreads();
     for (int e = threadIdx.x; e < cc * FB_WY * FB_WX; e += FB_TX * FB_TY) {
