@@ -84,8 +84,26 @@ def main():
     rows.append((f'flow_warp_l1 bwd (batch {fb}: d flow only)',
                  timeit(lambda: lib.sininn_flow_warp_l1_bwd(ptr(fimg), ptr(fflow), ptr(ftgt), ptr(fwarp), ptr(gwp), ptr(gmt), fb, 3, h, w, None, ptr(gfl), st()), a.reps),
                  fpx * 4 * (3 + 2 + 3 + 3 + 3 + 1 + 2)))
+    # the same three calls on a SMOOTH flow (what a flow network emits; bench.py --with-flow uses the same field): neighbouring
+    # pixels sample neighbouring source pixels, so the forward shares taps by shuffle and the image-gradient backward merges
+    # coinciding taps across lanes before its LDS atomics.  (The white-noise flow above is the worst case for both.)
+    yy, xx = torch.meshgrid(torch.arange(h, device=dev, dtype=torch.float32), torch.arange(w, device=dev, dtype=torch.float32), indexing='ij')
+    sflow = torch.stack((3.0 * torch.sin(yy / 37.0) + 1.5 * torch.cos(xx / 23.0), 2.5 * torch.cos(yy / 29.0 + xx / 41.0)))
+    sflow = sflow.unsqueeze(0).repeat(fb, 1, 1, 1).contiguous()
+    rows.append((f'flow_warp_l1 fwd, smooth flow',
+                 timeit(lambda: lib.sininn_flow_warp_l1(ptr(fimg), ptr(sflow), ptr(ftgt), fb, 3, h, w, ptr(fwarp), ptr(fmet), st()), a.reps),
+                 fpx * 4 * (3 + 2 + 3 + 3 + 1)))
+
+    def fw_bwd_s():
+        gim.zero_()
+        lib.sininn_flow_warp_l1_bwd(ptr(fimg), ptr(sflow), ptr(ftgt), ptr(fwarp), ptr(gwp), ptr(gmt), fb, 3, h, w, ptr(gim), ptr(gfl), st())
+    rows.append((f'flow_warp_l1 bwd, smooth flow (d img + d flow, incl. zero fill)', timeit(fw_bwd_s, a.reps),
+                 fpx * 4 * (3 + 2 + 3 + 3 + 3 + 1 + 3 + 3 + 2)))
+    rows.append((f'flow_warp_l1 bwd, smooth flow (d flow only)',
+                 timeit(lambda: lib.sininn_flow_warp_l1_bwd(ptr(fimg), ptr(sflow), ptr(ftgt), ptr(fwarp), ptr(gwp), ptr(gmt), fb, 3, h, w, None, ptr(gfl), st()), a.reps),
+                 fpx * 4 * (3 + 2 + 3 + 3 + 3 + 1 + 2)))
     for name, ms, nbytes in rows:
-        print(f'{name:42s} {ms * 1e3:9.1f} us  {nbytes / ms / 1e6:8.1f} GB/s algorithmic = {nbytes / ms / 1e6 / 8000 * 100:5.1f} % of the HBM roof')
+        print(f'{name:66s} {ms * 1e3:9.1f} us  {nbytes / ms / 1e6:8.1f} GB/s algorithmic = {nbytes / ms / 1e6 / 8000 * 100:5.1f} % of the HBM roof')
 
 
 if __name__ == '__main__':
