@@ -70,6 +70,20 @@ __device__ __forceinline__ void lds_wait(f32x2& a) { asm volatile("s_waitcnt lgk
 template <int N>
 __device__ __forceinline__ void lds_wait(f32x2& a, f32x2& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
 
+// ---- raw buffer loads ---------------------------------------------------------------------------------------------------
+// A load whose byte offset is >= num_records returns 0.  Staging loops give every lane that lies outside the image (or beyond
+// the packed columns) the offset BUF_OOB, so zero fill costs no select, no zeroed registers and no exec-mask branch, and the
+// per-step advance is the SCALAR offset operand: a staged 16-byte unit is ONE instruction (vector-ALU / branch instructions in
+// a K loop are issue time taken from the matrix pipe, tools/mfma_valu.hip).  Real offsets must stay below 2^31.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned BUF_OOB = 0xffffffffu;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)0x80000000u, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned uniform_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_off, (int)uniform_off, 0));
+}
+
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) {

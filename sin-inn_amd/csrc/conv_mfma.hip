@@ -83,6 +83,12 @@ int conv_prepare(const sininn_conv_args* a, ConvDev& d) {
     SININN_CHECK(!d.mask_gs || a->mode == SININN_CONV_MASK, "conv: mask_group_stride without MASK mode");
   }
   if (a->in_group_stride > 0) SININN_CHECK(a->winograd && a->in_stride == 8, "conv: the channel-group-major input layout needs the Winograd kernels and in_stride == 8");
+  if (a->winograd) {
+    // the Winograd kernels stage through raw buffer loads: 32-bit byte offsets inside one image, 32-bit chunk advance
+    SININN_CHECK((unsigned long long)a->H * a->W * a->in_stride * 4ull < (1ull << 31),
+                 "conv: one image of the input (%d x %d x stride %d floats) exceeds the 2 GB a Winograd block addresses", a->H, a->W, a->in_stride);
+    SININN_CHECK((unsigned long long)(a->Cin / 8) * (unsigned long long)d.in_chunk * 4ull < (1ull << 32), "conv: input channel-group stride too large");
+  }
   SININN_CHECK(a->mode >= 0 && a->mode <= SININN_CONV_ADD_CBWD_INV, "conv: unknown mode %d", a->mode);
   // channel chunk: the largest of 32/24/16/8 that divides Cin
   int ck = 8;

@@ -69,18 +69,43 @@ __global__ __launch_bounds__(SP_TX * SP_TY) void splat_fwd_kernel(const float* _
   const bool in_sw = wx >= 0 && wx < SP_WX && wy + 1 >= 0 && wy + 1 < SP_WY;
   const bool in_se = wx + 1 >= 0 && wx + 1 < SP_WX && wy + 1 >= 0 && wy + 1 < SP_WY;
   const int64_t o_nw = (int64_t)t.nwy * W + t.nwx;
+  // For a locally smooth flow the taps of neighbouring source pixels coincide (the south taps of a pixel are the north taps of
+  // the pixel below it -- the wave's other row --, its east taps the west taps of its right neighbour): the contributions are
+  // summed across lanes first, so an interior pixel issues one atomic per channel instead of four, all to different addresses
+  // (as in flow_warp_l1_bwd_tiled_kernel).  Every shuffle is executed by all 64 lanes.
+  static_assert(SP_TX == 32, "the lane merges assume 32-pixel tile rows");
+  const int lane = threadIdx.x & 63;
+  const int anyi = any ? 1 : 0;
+  const int any_r = __shfl_down(anyi, 1), nwx_r = __shfl_down(t.nwx, 1), nwy_r = __shfl_down(t.nwy, 1);
+  const int any_d = __shfl_down(anyi, 32), nwx_d = __shfl_down(t.nwx, 32), nwy_d = __shfl_down(t.nwy, 32);
+  const bool give_h = any && (lane & 31) != 31 && any_r != 0 && nwx_r == t.nwx + 1 && nwy_r == t.nwy;
+  const bool give_v = any && lane < 32 && any_d != 0 && nwx_d == t.nwx && nwy_d == t.nwy + 1;
+  const int gh_l = __shfl_up(give_h ? 1 : 0, 1), gv_u = __shfl_up(give_v ? 1 : 0, 32);
+  const bool take_h = (lane & 31) != 0 && gh_l != 0;
+  const bool take_v = lane >= 32 && gv_u != 0;
   for (int c0 = 0; c0 < C; c0 += SP_CC) {
     const int cc = min(SP_CC, C - c0);
     for (int e = threadIdx.x; e < cc * SP_WY * SP_WX; e += blockDim.x) (&win[0][0][0])[e] = 0.f;
     __syncthreads();
-    if (any) {
-      for (int c = 0; c < cc; ++c) {
+    for (int c = 0; c < cc; ++c) {                      // every lane walks the channels: the merges are wave-wide
+      float cnw = 0.f, cne = 0.f, csw = 0.f, cse = 0.f;
+      if (any) {
         const float v = ONES ? 1.f : in[((int64_t)b * C + c0 + c) * HW + r];
+        cnw = t.vnw ? v * t.nw : 0.f; cne = t.vne ? v * t.ne : 0.f; csw = t.vsw ? v * t.sw : 0.f; cse = t.vse ? v * t.se : 0.f;
+      }
+      const float rsw = __shfl_up(csw, 32), rse = __shfl_up(cse, 32);
+      if (take_v) { cnw += rsw; cne += rse; }
+      if (give_v) { csw = 0.f; cse = 0.f; }
+      const float sne = __shfl_up(cne, 1), sse = __shfl_up(cse, 1);
+      if (take_h) { cnw += sne; csw += sse; }
+      if (give_h) { cne = 0.f; cse = 0.f; }
+      if (any) {
         float* o = out + ((int64_t)b * C + c0 + c) * HW;
-        if (t.vnw) { if (in_nw) atomic_add_f32(&win[c][wy][wx], v * t.nw); else atomic_add_f32(o + o_nw, v * t.nw); }
-        if (t.vne) { if (in_ne) atomic_add_f32(&win[c][wy][wx + 1], v * t.ne); else atomic_add_f32(o + o_nw + 1, v * t.ne); }
-        if (t.vsw) { if (in_sw) atomic_add_f32(&win[c][wy + 1][wx], v * t.sw); else atomic_add_f32(o + o_nw + W, v * t.sw); }
-        if (t.vse) { if (in_se) atomic_add_f32(&win[c][wy + 1][wx + 1], v * t.se); else atomic_add_f32(o + o_nw + W + 1, v * t.se); }
+        // (a merged value lands where the receiving lane's own tap of that slot lands: same address, same validity)
+        if (t.vnw && cnw != 0.f) { if (in_nw) atomic_add_f32(&win[c][wy][wx], cnw); else atomic_add_f32(o + o_nw, cnw); }
+        if (t.vne && cne != 0.f) { if (in_ne) atomic_add_f32(&win[c][wy][wx + 1], cne); else atomic_add_f32(o + o_nw + 1, cne); }
+        if (t.vsw && csw != 0.f) { if (in_sw) atomic_add_f32(&win[c][wy + 1][wx], csw); else atomic_add_f32(o + o_nw + W, csw); }
+        if (t.vse && cse != 0.f) { if (in_se) atomic_add_f32(&win[c][wy + 1][wx + 1], cse); else atomic_add_f32(o + o_nw + W + 1, cse); }
       }
     }
     __syncthreads();

@@ -38,6 +38,11 @@ __device__ __forceinline__ f32x4 wg_load4(const float* base, size_t off, int is_
 }
 
 constexpr int WG_TH = 8;   // pixel tile 8 x 16
+// Diagnostic build variants of the Winograd weight gradient (tools/build_variant.sh ... "-DWG_ABL=n"):
+// bit 0 no transforms, bit 1 one staged tile reused (no global loads / barriers), bit 2 no MFMAs.
+#ifndef WG_ABL
+#define WG_ABL 0
+#endif
 
 template <int KS, int RT, int CT, int WR, int WC>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradDev p) {
@@ -342,7 +347,10 @@ __device__ __forceinline__ void wgrad_wino_body(const WgradDev& p, const int spl
   constexpr int NTHR = 256 * KH;
   constexpr int IW = 18, IH = TH + 2, NPIX_IN = IH * IW, NPIX = TH * 16;
   constexpr int BNW = WIDE_C ? 32 : 64, BCW = WIDE_C ? 64 : 32;
-  constexpr int SD = BNW + 8, SI = BCW + 8;            // 2*SD == 2*SI == 16 (mod 32): the 4 k-lanes hit disjoint banks
+  // the four k-lanes of a wave read pixels 4 kq (+ 2 e): 4*SD == 4*SI == 16 (mod 32), so k-lanes 0 / 2 and 1 / 3 fall on the two
+  // halves of the banks (two passes for 64 lanes, the minimum); rows stay 16-byte aligned for the float4 staging stores
+  constexpr int SD = BNW + 4, SI = BCW + 4;
+  static_assert((4 * SD) % 32 == 16 && (4 * SI) % 32 == 16, "LDS pitch against the k-lane pixel stride");
   static_assert(!(WIDE_C && KH != 1), "the 32 x 64 block shape exists for four-wave blocks only");
   constexpr int D_F4 = (NPIX * BNW / 4 + NTHR - 1) / NTHR;
   constexpr int I_F4 = (NPIX_IN * BCW / 4 + NTHR - 1) / NTHR;
@@ -350,7 +358,7 @@ __device__ __forceinline__ void wgrad_wino_body(const WgradDev& p, const int spl
   constexpr int LDS_TILE = NPIX * SD + NPIX_IN * SI;
   constexpr int LDS_RED = (KH == 2) ? 16 * 256 * 4 : 0;   // 8 positions x 2 row tiles x 256 lanes x float4
   constexpr int LDS_FLOATS = LDS_TILE > LDS_RED ? LDS_TILE : LDS_RED;
-  static_assert(TH % KH == 0, "k-steps must split evenly");
+  static_assert(TH % (2 * KH) == 0, "a wave walks whole Winograd tile rows (two k-steps each)");
   __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
   float* const d_lds = smem;
   float* const i_lds = smem + NPIX * SD;
@@ -369,6 +377,39 @@ __device__ __forceinline__ void wgrad_wino_body(const WgradDev& p, const int spl
   const int t_begin = split * p.tiles_per_split;
   const int t_end = min(t_begin + p.tiles_per_split, p.ntiles);
 
+  // ---- staging descriptors, constant over the tiles (the per-tile address arithmetic is issue time taken from the matrix
+  // pipe: every slot keeps its BYTE offset from the tile's origin pixel -- for the input tile the origin is the halo corner
+  // (y0 - 1, x0 - 1), so offsets are never negative -- and its tile-local (row, column); per tile a slot costs two adds, two
+  // unsigned compares and one scalar-base + 32-bit-offset load.  A statically dead slot (beyond the tile / N / Cin) carries a
+  // position that fails every bounds check.)
+  const unsigned d_es = p.dout_bf16 ? 2u : 4u, i_es = p.in_bf16 ? 2u : 4u;                     // element sizes in HBM
+  const unsigned d_ps = p.dout_gs ? 8u : (unsigned)p.dout_stride, i_ps = p.in_gs ? 8u : (unsigned)p.in_stride;   // elements per pixel step
+  unsigned d_off[D_F4], d_pos[D_F4], i_off[I_F4], i_pos[I_F4];
+#pragma unroll
+  for (int r = 0; r < D_F4; ++r) {
+    const int f = tid + NTHR * r;
+    const int pix = f / (BNW / 4), n = n0 + (f % (BNW / 4)) * 4;
+    const bool live = pix < NPIX && n < p.N;
+    const unsigned col = p.dout_gs ? (unsigned)((size_t)(n >> 3) * p.dout_gs) + (unsigned)(n & 7) : (unsigned)n;
+    d_off[r] = (((unsigned)(pix / 16) * (unsigned)p.W + (unsigned)(pix & 15)) * d_ps + col) * d_es;
+    d_pos[r] = live ? (unsigned)((pix / 16) << 16 | (pix & 15)) : 0x7fff7fffu;
+  }
+#pragma unroll
+  for (int r = 0; r < I_F4; ++r) {
+    const int f = tid + NTHR * r;
+    const int pix = f / (BCW / 4), c = c0 + (f % (BCW / 4)) * 4;
+    const int py = pix / IW, px = pix - py * IW;
+    const bool live = pix < NPIX_IN && c < p.Cin;
+    const unsigned col = p.in_gs ? (unsigned)((size_t)(c >> 3) * p.in_gs) + (unsigned)(c & 7) : (unsigned)c;
+    i_off[r] = (((unsigned)py * (unsigned)p.W + (unsigned)px) * i_ps + col) * i_es;
+    i_pos[r] = live ? (unsigned)(py << 16 | px) : 0x7fff7fffu;
+  }
+  const bool mixed = (p.dout_bf16 | p.in_bf16) != 0;      // bf16 operands in HBM (diagnostic route of the mixed-precision path)
+  auto uniform64 = [](long long a) -> long long {         // the tile bases are wave-uniform: keep their offsets in SGPRs, so that
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);                    // a load is scalar base + 32-bit lane offset
+  };
+
   f32x4 d_reg[D_F4], i_reg[I_F4];
   auto load_tile = [&](int tile) {
     int tt = tile;
@@ -376,37 +417,35 @@ __device__ __forceinline__ void wgrad_wino_body(const WgradDev& p, const int spl
     const int ty = tt % p.tiles_y;
     const int b = tt / p.tiles_y;
     const int y0 = ty * TH, x0 = tx * 16;
-#pragma unroll
-    for (int r = 0; r < D_F4; ++r) {
-      const int f = tid + NTHR * r;
-      const int pix = f / (BNW / 4), n4 = f % (BNW / 4);
-      const int gy = y0 + pix / 16, gx = x0 + (pix & 15);
-      const int n = n0 + n4 * 4;
+    // origin pixels (the halo corner of the first tile row / column lies before the image: only slots that pass the bounds
+    // check are dereferenced)
+    const long long opix = ((long long)b * p.H + y0) * p.W + x0;
+    const char* const dbase = reinterpret_cast<const char*>(p.dout) + uniform64(opix * (long long)(d_ps * d_es));
+    const char* const ibase = reinterpret_cast<const char*>(p.in) + uniform64((opix - p.W - 1) * (long long)(i_ps * i_es));
+    const unsigned hy = (unsigned)(p.H - y0), wx = (unsigned)(p.W - x0);          // d tile: rows / columns left in the image
+    const unsigned y1 = (unsigned)(y0 - 1), x1 = (unsigned)(x0 - 1);              // input tile: image coordinates of the halo corner
+    auto ld = [&](const char* base, unsigned off, bool live, bool is_bf16) -> f32x4 {
       f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (pix < NPIX && gy < p.H && gx < p.W && n < p.N)
-        {
-          const size_t pixi = (size_t)(b * p.H + gy) * p.W + gx;
-          val = p.dout_gs ? *reinterpret_cast<const f32x4*>(p.dout + (size_t)(n >> 3) * p.dout_gs + pixi * 8 + (n & 7))
-                          : wg_load4(p.dout, pixi * p.dout_stride + n, p.dout_bf16);
+      if (live) {
+        if (is_bf16) {
+          const wg_bf16x4 h = *reinterpret_cast<const wg_bf16x4*>(base + off);
+          val = (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        } else {
+          val = *reinterpret_cast<const f32x4*>(base + off);
         }
-      d_reg[r] = val;
-    }
+      }
+      return val;
+    };
+    auto all = [&](auto d_bf, auto i_bf) {
 #pragma unroll
-    for (int r = 0; r < I_F4; ++r) {
-      const int f = tid + NTHR * r;
-      const int pix = f / (BCW / 4), c4 = f % (BCW / 4);
-      const int py = pix / IW, px = pix - py * IW;
-      const int gy = y0 + py - 1, gx = x0 + px - 1;
-      const int c = c0 + c4 * 4;
-      f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (pix < NPIX_IN && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && c < p.Cin)
-        {
-          const size_t pixi = (size_t)(b * p.H + gy) * p.W + gx;
-          val = p.in_gs ? *reinterpret_cast<const f32x4*>(p.in + (size_t)(c >> 3) * p.in_gs + pixi * 8 + (c & 7))
-                        : wg_load4(p.in, pixi * p.in_stride + c, p.in_bf16);
-        }
-      i_reg[r] = val;
-    }
+      for (int r = 0; r < D_F4; ++r)
+        d_reg[r] = ld(dbase, d_off[r], (d_pos[r] >> 16) < hy && (d_pos[r] & 0xffffu) < wx, d_bf());
+#pragma unroll
+      for (int r = 0; r < I_F4; ++r)
+        i_reg[r] = ld(ibase, i_off[r], (y1 + (i_pos[r] >> 16)) < (unsigned)p.H && (x1 + (i_pos[r] & 0xffffu)) < (unsigned)p.W, i_bf());
+    };
+    if (!mixed) all([] { return false; }, [] { return false; });
+    else all([&] { return p.dout_bf16 != 0; }, [&] { return p.in_bf16 != 0; });
   };
   auto store_tile = [&]() {
 #pragma unroll
@@ -425,50 +464,77 @@ __device__ __forceinline__ void wgrad_wino_body(const WgradDev& p, const int spl
 
   if (t_begin < t_end) load_tile(t_begin);
   for (int tile = t_begin; tile < t_end; ++tile) {
+#if (WG_ABL & 2)
+    if (tile == t_begin) { __syncthreads(); store_tile(); __syncthreads(); }
+#else
     __syncthreads();
     store_tile();
     __syncthreads();
     if (tile + 1 < t_end) load_tile(tile + 1);
-#pragma unroll UNR
-    for (int kk = 0; kk < KSTEPS; ++kk) {
-      const int ks = kh * KSTEPS + kk;
-      const int t = 4 * ks + kq;                       // this lane's Winograd tile (k index)
-      const int ty2 = 2 * (t >> 3), tx2 = 2 * (t & 7);
-      // ---- V = B^T d B for (input channel c = 16*wc + li, tile t) ---------------------------------
-      float v[16];
+#endif
+    // Vector-ALU instructions do NOT hide behind the matrix pipe on this chip (tools/mfma_valu.hip: with two waves per SIMD every
+    // VALU instruction per v_mfma_f32_16x16x4_f32 adds ~2.5 clocks to its 32, every LDS read ~4.6), so the transforms are written
+    // for the fewest instructions.  The k-steps of a tile are walked two at a time -- Winograd tile row `trow`, this lane's tiles
+    // (trow, 2 kq) [even k-step] and (trow, 2 kq + 1) [odd k-step]:
+    //   * V = B^T d B: the 4x4 patches of the two x-adjacent tiles are columns 0-3 and 2-5 of one 4x6 patch, so the row pass
+    //     (24 values read, 24 adds) is shared; only the column pass runs per tile;
+    //   * row 3 and column 3 of BOTH transforms are computed negated (d3 - d1 for d1 - d3, +y1 for -y1): free in V, saves every
+    //     negation in W, and each product w * v is unchanged;
+    //   * the bias-gradient partial of a tile is W's (1, 1) entry, (y00 + y10) + (y01 + y11).
+#pragma unroll 1
+    for (int mm = 0; mm < KSTEPS / 2; ++mm) {
+      const int trow = kh * (KSTEPS / 2) + mm;
+      float v[2][16];
       {
-        const float* ip = i_lds + (ty2 * IW + tx2) * SI + 16 * wc + li;
-        float tt[4][4];
+        const float* ip = i_lds + ((2 * trow) * IW + 4 * kq) * SI + 16 * wc + li;
+#if (WG_ABL & 1)
+        const float v0 = ip[0], v1 = ip[SI];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < 16; ++c) { v[0][c] = (c & 1) ? v1 : v0; v[1][c] = (c & 1) ? v0 : v1; }
+#else
+        float t[4][6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
           const float d0 = ip[(0 * IW + c) * SI], d1 = ip[(1 * IW + c) * SI], d2 = ip[(2 * IW + c) * SI], d3 = ip[(3 * IW + c) * SI];
-          tt[0][c] = d0 - d2; tt[1][c] = d1 + d2; tt[2][c] = d2 - d1; tt[3][c] = d1 - d3;
+          t[0][c] = d0 - d2; t[1][c] = d1 + d2; t[2][c] = d2 - d1; t[3][c] = d3 - d1;
         }
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          v[a * 4 + 0] = tt[a][0] - tt[a][2];
-          v[a * 4 + 1] = tt[a][1] + tt[a][2];
-          v[a * 4 + 2] = tt[a][2] - tt[a][1];
-          v[a * 4 + 3] = tt[a][1] - tt[a][3];
-        }
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            v[e][a * 4 + 0] = t[a][2 * e + 0] - t[a][2 * e + 2];
+            v[e][a * 4 + 1] = t[a][2 * e + 1] + t[a][2 * e + 2];
+            v[e][a * 4 + 2] = t[a][2 * e + 2] - t[a][2 * e + 1];
+            v[e][a * 4 + 3] = t[a][2 * e + 3] - t[a][2 * e + 1];
+          }
+#endif
       }
-      // ---- W = A dY A^T for (output channel n = 32*wr + 16*a + li, tile t), a = 0, 1 ---------------
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        if (a == 1 && !a1_live) continue;     // row tile entirely beyond N (N = 48 in the 64-row block): no transform, no MFMAs
-        const float* dp = d_lds + (ty2 * 16 + tx2) * SD + 32 * wr + 16 * a + li;
-        const float y00 = dp[0], y01 = dp[SD], y10 = dp[16 * SD], y11 = dp[17 * SD];
-        bsum[a] += (y00 + y01) + (y10 + y11);
-        // R = A dY (4x2), W = R A^T (4x4)
-        const float r00 = y00, r01 = y01, r10 = y00 + y10, r11 = y01 + y11, r20 = y00 - y10, r21 = y01 - y11,
-                    r30 = -y10, r31 = -y11;
-        float w[16];
-        w[0] = r00; w[1] = r00 + r01; w[2] = r00 - r01; w[3] = -r01;
-        w[4] = r10; w[5] = r10 + r11; w[6] = r10 - r11; w[7] = -r11;
-        w[8] = r20; w[9] = r20 + r21; w[10] = r20 - r21; w[11] = -r21;
-        w[12] = r30; w[13] = r30 + r31; w[14] = r30 - r31; w[15] = -r31;
+      for (int e = 0; e < 2; ++e) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q][a] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q], v[q], acc[q][a], 0, 0, 0);
+        for (int a = 0; a < 2; ++a) {
+          if (a == 1 && !a1_live) continue;     // row tile entirely beyond N (N = 48 in the 64-row block): no transform, no MFMAs
+          const float* dp = d_lds + ((2 * trow) * 16 + 4 * kq + 2 * e) * SD + 32 * wr + 16 * a + li;
+          const float y00 = dp[0], y01 = dp[SD], y10 = dp[16 * SD], y11 = dp[17 * SD];
+          const float r10 = y00 + y10, r11 = y01 + y11, r20 = y00 - y10, r21 = y01 - y11;
+          float w[16];
+          w[0] = y00; w[1] = y00 + y01; w[2] = y00 - y01; w[3] = y01;
+          w[4] = r10; w[5] = r10 + r11; w[6] = r10 - r11; w[7] = r11;
+          w[8] = r20; w[9] = r20 + r21; w[10] = r20 - r21; w[11] = r21;
+          w[12] = y10; w[13] = y10 + y11; w[14] = y10 - y11; w[15] = y11;
+          bsum[a] += w[5];
+#if (WG_ABL & 1)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) w[q] = (q & 1) ? y01 : y00;
+#endif
+#if (WG_ABL & 4)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc[q][a][0] += w[q] * v[e][q];
+#else
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc[q][a] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q], v[e][q], acc[q][a], 0, 0, 0);
+#endif
+        }
       }
     }
   }

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256 * CG, 2 / CG) void wino_kernel(ConvDev p) {
   constexpr int IN_F4 = (NPIX_IN * 2 + NTHR - 1) / NTHR;   // 2 float4 per pixel
   constexpr int U_F4 = (16 * BN * 2 + NTHR - 1) / NTHR;
   constexpr int IN_BUF = IW * PITCH + 4, U_BUF = 16 * BN * SU;
+  constexpr bool U_EXACT = (16 * BN * 2) % NTHR == 0;      // every thread slot of the U staging loop is a real quad
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const in_lds0 = smem;
@@ -58,7 +59,9 @@ __global__ __launch_bounds__(256 * CG, 2 / CG) void wino_kernel(ConvDev p) {
   const int n0 = blockIdx.y * BN;
 
   // ---- staging descriptors ---------------------------------------------------------------------
-  int in_goff[IN_F4], in_loff[IN_F4];
+  // global side: byte offsets for raw buffer loads (BUF_OOB outside the image / beyond the packed columns -> the load returns
+  // zeros), relative to this block's image; the channel chunk advances through the scalar offset operand
+  unsigned in_goff[IN_F4]; int in_loff[IN_F4];
 #pragma unroll
   for (int r = 0; r < IN_F4; ++r) {
     const int f = tid + NTHR * r;
@@ -67,41 +70,38 @@ __global__ __launch_bounds__(256 * CG, 2 / CG) void wino_kernel(ConvDev p) {
     const int gy = y0 + py - 1, gx = x0 + px - 1;
     const bool inside = pix < NPIX_IN;
     const bool inimg = inside && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-    in_loff[r] = inside ? (py * PITCH + ((py >> 1) & 1) * 4 + px * SI + c4 * 4) : -1;
-    in_goff[r] = inimg ? (((b * p.H + gy) * p.W + gx) * p.in_stride + c4 * 4) : -1;
+    // slots beyond the halo tile store their (zero) quad into the four spare floats behind the tile: no exec-mask branch per store
+    in_loff[r] = inside ? (py * PITCH + ((py >> 1) & 1) * 4 + px * SI + c4 * 4) : IW * PITCH;
+    in_goff[r] = inimg ? (unsigned)(((gy * p.W + gx) * p.in_stride + c4 * 4) * 4) : BUF_OOB;
   }
-  int u_goff[U_F4], u_loff[U_F4];
+  unsigned u_goff[U_F4]; int u_loff[U_F4];
 #pragma unroll
   for (int r = 0; r < U_F4; ++r) {
     const int f = tid + NTHR * r;
     const int c4 = f & 1, col = (f >> 1) % BN, pos = (f >> 1) / BN;
     const bool inside = pos < 16;
-    u_loff[r] = inside ? ((pos * BN + col) * SU + c4 * 4) : -1;
+    u_loff[r] = (U_EXACT || inside) ? ((pos * BN + col) * SU + c4 * 4) : -1;
     // U pack = [16 positions][Cin / 8 chunks][Np columns][8 channels]
-    u_goff[r] = (inside && (n0 + col) < p.Np) ? ((pos * (p.Cin / CK) * p.Np + n0 + col) * CK + c4 * 4) : -1;
+    u_goff[r] = (inside && (n0 + col) < p.Np) ? (unsigned)(((pos * (p.Cin / CK) * p.Np + n0 + col) * CK + c4 * 4) * 4) : BUF_OOB;
   }
   const int nchunks = p.Cin / CK;
 
+  const __amdgpu_buffer_rsrc_t in_rs = buf_rsrc(p.in + (size_t)b * p.H * p.W * p.in_stride), u_rs = buf_rsrc(p.w);
+  const unsigned in_step = (unsigned)p.in_chunk * 4u, u_step = (unsigned)(p.Np * CK) * 4u;      // bytes per channel chunk
   f32x4 in_reg[IN_F4], u_reg[U_F4];
   auto load_chunk = [&](int chunk) {
 #pragma unroll
-    for (int r = 0; r < IN_F4; ++r) {
-      f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      in_reg[r] = (in_goff[r] >= 0) ? *reinterpret_cast<const f32x4*>(p.in + in_goff[r] + (size_t)chunk * p.in_chunk) : z;
-    }
+    for (int r = 0; r < IN_F4; ++r) in_reg[r] = buf_load4(in_rs, in_goff[r], (unsigned)chunk * in_step);
 #pragma unroll
-    for (int r = 0; r < U_F4; ++r) {
-      f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      u_reg[r] = (u_goff[r] >= 0) ? *reinterpret_cast<const f32x4*>(p.w + u_goff[r] + chunk * p.Np * CK) : z;
-    }
+    for (int r = 0; r < U_F4; ++r) u_reg[r] = buf_load4(u_rs, u_goff[r], (unsigned)chunk * u_step);
   };
   auto store_chunk = [&](float* idst, float* udst) {
 #pragma unroll
     for (int r = 0; r < IN_F4; ++r)
-      if (in_loff[r] >= 0) *reinterpret_cast<f32x4*>(idst + in_loff[r]) = in_reg[r];
+      *reinterpret_cast<f32x4*>(idst + in_loff[r]) = in_reg[r];
 #pragma unroll
     for (int r = 0; r < U_F4; ++r)
-      if (u_loff[r] >= 0) *reinterpret_cast<f32x4*>(udst + u_loff[r]) = u_reg[r];
+      if (U_EXACT || u_loff[r] >= 0) *reinterpret_cast<f32x4*>(udst + u_loff[r]) = u_reg[r];
   };
 
   // this lane's Winograd tile for the A operand (tile = 16*wave + li) and its patch origin in the halo tile

@@ -102,6 +102,9 @@ def main():
     rows.append((f'flow_warp_l1 bwd, smooth flow (d flow only)',
                  timeit(lambda: lib.sininn_flow_warp_l1_bwd(ptr(fimg), ptr(sflow), ptr(ftgt), ptr(fwarp), ptr(gwp), ptr(gmt), fb, 3, h, w, None, ptr(gfl), st()), a.reps),
                  fpx * 4 * (3 + 2 + 3 + 3 + 3 + 1 + 2)))
+    s4 = sflow[:b].contiguous()
+    rows.append(('softsplat fwd, smooth flow', timeit(lambda: lib.sininn_softsplat(ptr(x4), ptr(s4), b, 4, h, w, ptr(out), st()), a.reps), px * 4 * (4 + 2 + 4)))
+    rows.append(('occlusion_wang, smooth flow', timeit(lambda: lib.sininn_occlusion_wang(ptr(s4), b, h, w, 0.7, ptr(corr), ptr(m), st()), a.reps), px * 4 * (2 + 1 + 1 + 1)))
     for name, ms, nbytes in rows:
         print(f'{name:66s} {ms * 1e3:9.1f} us  {nbytes / ms / 1e6:8.1f} GB/s algorithmic = {nbytes / ms / 1e6 / 8000 * 100:5.1f} % of the HBM roof')
 
