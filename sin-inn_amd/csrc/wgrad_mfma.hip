@@ -37,6 +37,73 @@ __device__ __forceinline__ f32x4 wg_load4(const float* base, size_t off, int is_
   return *reinterpret_cast<const f32x4*>(base + off);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Staging of one operand tile (pixel-major, 16 bytes per slot) of a weight-gradient block: global -> registers.
+// The per-tile address arithmetic is issue time taken from the matrix pipe (tools/mfma_valu.hip), so every thread slot keeps,
+// constant over the tiles, its BYTE offset from the tile's origin pixel -- the halo corner (y0 - HALO, x0 - HALO), so offsets
+// are never negative -- and its tile-local (row, column).  Per tile a slot then costs two adds, two unsigned compares and ONE
+// load with a scalar (wave-uniform) base and a 32-bit lane offset.  A statically dead slot (beyond the tile or the channel
+// range) carries a position that fails every bounds check.  QPP = float4 slots per pixel, TW = tile width in pixels (with
+// halo), NPX = pixels of the tile (with halo).
+// ------------------------------------------------------------------------------------------------
+template <int F4, int NTHR, int QPP, int TW, int NPX, int HALO>
+struct WgStage {
+  unsigned off[F4], pos[F4];
+  unsigned pix_bytes;
+
+  // stride: elements per pixel (pixel-major) -- or gs > 0: channel-group-major [C/8][pixel][8], gs elements between groups;
+  // ch0: first channel of the block, chmax: channels of the tensor
+  __device__ __forceinline__ void init(int tid, int W, int stride, size_t gs, int is_bf16, int ch0, int chmax) {
+    const unsigned es = is_bf16 ? 2u : 4u, ps = gs ? 8u : (unsigned)stride;
+    pix_bytes = ps * es;
+#pragma unroll
+    for (int r = 0; r < F4; ++r) {
+      const int f = tid + NTHR * r;
+      const int pix = f / QPP, ch = ch0 + (f % QPP) * 4;
+      const int py = pix / TW, px = pix - py * TW;
+      const unsigned col = gs ? (unsigned)((size_t)(ch >> 3) * gs) + (unsigned)(ch & 7) : (unsigned)ch;
+      off[r] = (((unsigned)py * (unsigned)W + (unsigned)px) * ps + col) * es;
+      pos[r] = (pix < NPX && ch < chmax) ? (unsigned)(py << 16 | px) : 0x7fff7fffu;
+    }
+  }
+  // tile origin (image b, pixel row y0, column x0: WITHOUT the halo) in an image of H x W pixels
+  template <bool BF16>
+  __device__ __forceinline__ void load(f32x4 (&reg)[F4], const void* tensor, int b, int y0, int x0, int H, int W) const {
+    // wave-uniform 64-bit base, forced into SGPRs (the halo corner of the first tile row / column lies before the image: only
+    // slots that pass the bounds check are dereferenced)
+    const long long o = (((long long)b * H + (y0 - HALO)) * W + (x0 - HALO)) * (long long)pix_bytes;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)o), hi = __builtin_amdgcn_readfirstlane((unsigned)(o >> 32));
+    const char* const base = reinterpret_cast<const char*>(tensor) + (long long)(((unsigned long long)hi << 32) | lo);
+    const unsigned yo = (unsigned)(y0 - HALO), xo = (unsigned)(x0 - HALO);
+#pragma unroll
+    for (int r = 0; r < F4; ++r) {
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if ((yo + (pos[r] >> 16)) < (unsigned)H && (xo + (pos[r] & 0xffffu)) < (unsigned)W) {
+        if constexpr (BF16) {
+          const wg_bf16x4 h = *reinterpret_cast<const wg_bf16x4*>(base + off[r]);
+          val = (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        } else {
+          val = *reinterpret_cast<const f32x4*>(base + off[r]);
+        }
+      }
+      reg[r] = val;
+    }
+  }
+};
+
+// both operand tiles of a block for one pixel tile; the precision branch is taken once per tile, not once per slot
+template <class SD, class SI, int DF, int IF>
+__device__ __forceinline__ void wg_load_tile(const WgradDev& p, const SD& ds, const SI& is, f32x4 (&d_reg)[DF], f32x4 (&i_reg)[IF],
+                                             int b, int y0, int x0) {
+  if (!(p.dout_bf16 | p.in_bf16)) {
+    ds.template load<false>(d_reg, p.dout, b, y0, x0, p.H, p.W);
+    is.template load<false>(i_reg, p.in, b, y0, x0, p.H, p.W);
+  } else {                                              // bf16 operands in HBM (mixed-precision path)
+    if (p.dout_bf16) ds.template load<true>(d_reg, p.dout, b, y0, x0, p.H, p.W); else ds.template load<false>(d_reg, p.dout, b, y0, x0, p.H, p.W);
+    if (p.in_bf16) is.template load<true>(i_reg, p.in, b, y0, x0, p.H, p.W); else is.template load<false>(i_reg, p.in, b, y0, x0, p.H, p.W);
+  }
+}
+
 constexpr int WG_TH = 8;   // pixel tile 8 x 16
 // Diagnostic build variants of the Winograd weight gradient (tools/build_variant.sh ... "-DWG_ABL=n"):
 // bit 0 no transforms, bit 1 one staged tile reused (no global loads / barriers), bit 2 no MFMAs.
@@ -85,36 +152,17 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradDev p) {
   const int t_begin = split * p.tiles_per_split;
   const int t_end = min(t_begin + p.tiles_per_split, p.ntiles);
 
+  WgStage<D_F4, 256, BNW / 4, 16, NPIX, 0> d_st;
+  WgStage<I_F4, 256, BCW / 4, IW, NPIX_IN, HALO> i_st;
+  d_st.init(tid, p.W, p.dout_stride, 0, p.dout_bf16, n0, p.N);
+  i_st.init(tid, p.W, p.in_stride, 0, p.in_bf16, c0, p.Cin);
   f32x4 d_reg[D_F4], i_reg[I_F4];
   auto load_tile = [&](int tile) {
     int tt = tile;
     const int tx = tt % p.tiles_x; tt /= p.tiles_x;
     const int ty = tt % p.tiles_y;
     const int b = tt / p.tiles_y;
-    const int y0 = ty * WG_TH, x0 = tx * 16;
-#pragma unroll
-    for (int r = 0; r < D_F4; ++r) {
-      const int f = tid + 256 * r;
-      const int pix = f / (BNW / 4), n4 = f % (BNW / 4);
-      const int gy = y0 + pix / 16, gx = x0 + (pix & 15);
-      const int n = n0 + n4 * 4;
-      f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (pix < NPIX && gy < p.H && gx < p.W && n < p.N)   // N % 4 == 0 is checked on the host
-        val = wg_load4(p.dout, ((size_t)(b * p.H + gy) * p.W + gx) * p.dout_stride + n, p.dout_bf16);
-      d_reg[r] = val;
-    }
-#pragma unroll
-    for (int r = 0; r < I_F4; ++r) {
-      const int f = tid + 256 * r;
-      const int pix = f / (BCW / 4), c4 = f % (BCW / 4);
-      const int py = pix / IW, px = pix - py * IW;
-      const int gy = y0 + py - HALO, gx = x0 + px - HALO;
-      const int c = c0 + c4 * 4;
-      f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (pix < NPIX_IN && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && c < p.Cin)
-        val = wg_load4(p.in, ((size_t)(b * p.H + gy) * p.W + gx) * p.in_stride + c, p.in_bf16);
-      i_reg[r] = val;
-    }
+    wg_load_tile(p, d_st, i_st, d_reg, i_reg, b, ty * WG_TH, tx * 16);
   };
   auto store_tile = [&]() {
 #pragma unroll
@@ -228,36 +276,17 @@ __device__ __forceinline__ void wgrad32_body(const WgradDev& p, const int split,
   const int t_begin = split * p.tiles_per_split;
   const int t_end = min(t_begin + p.tiles_per_split, p.ntiles);
 
+  WgStage<D_F4, 256, 8, 16, NPIX, 0> d_st;
+  WgStage<I_F4, 256, 8, IW, NPIX_IN, HALO> i_st;
+  d_st.init(tid, p.W, p.dout_stride, 0, p.dout_bf16, n0, p.N);
+  i_st.init(tid, p.W, p.in_stride, 0, p.in_bf16, c0, p.Cin);
   f32x4 d_reg[D_F4], i_reg[I_F4];
   auto load_tile = [&](int tile) {
     int tt = tile;
     const int tx = tt % p.tiles_x; tt /= p.tiles_x;
     const int ty = tt % p.tiles_y;
     const int b = tt / p.tiles_y;
-    const int y0 = ty * WG_TH, x0 = tx * 16;
-#pragma unroll
-    for (int r = 0; r < D_F4; ++r) {
-      const int f = tid + 256 * r;
-      const int pix = f >> 3, n4 = f & 7;
-      const int gy = y0 + (pix >> 4), gx = x0 + (pix & 15);
-      const int n = n0 + n4 * 4;
-      f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (pix < NPIX && gy < p.H && gx < p.W && n < p.N)
-        val = wg_load4(p.dout, ((size_t)(b * p.H + gy) * p.W + gx) * p.dout_stride + n, p.dout_bf16);
-      d_reg[r] = val;
-    }
-#pragma unroll
-    for (int r = 0; r < I_F4; ++r) {
-      const int f = tid + 256 * r;
-      const int pix = f >> 3, c4 = f & 7;
-      const int py = pix / IW, px = pix - py * IW;
-      const int gy = y0 + py - HALO, gx = x0 + px - HALO;
-      const int c = c0 + c4 * 4;
-      f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (pix < NPIX_IN && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && c < p.Cin)
-        val = wg_load4(p.in, ((size_t)(b * p.H + gy) * p.W + gx) * p.in_stride + c, p.in_bf16);
-      i_reg[r] = val;
-    }
+    wg_load_tile(p, d_st, i_st, d_reg, i_reg, b, ty * WG_TH, tx * 16);
   };
   auto store_tile = [&]() {
 #pragma unroll
@@ -377,75 +406,17 @@ __device__ __forceinline__ void wgrad_wino_body(const WgradDev& p, const int spl
   const int t_begin = split * p.tiles_per_split;
   const int t_end = min(t_begin + p.tiles_per_split, p.ntiles);
 
-  // ---- staging descriptors, constant over the tiles (the per-tile address arithmetic is issue time taken from the matrix
-  // pipe: every slot keeps its BYTE offset from the tile's origin pixel -- for the input tile the origin is the halo corner
-  // (y0 - 1, x0 - 1), so offsets are never negative -- and its tile-local (row, column); per tile a slot costs two adds, two
-  // unsigned compares and one scalar-base + 32-bit-offset load.  A statically dead slot (beyond the tile / N / Cin) carries a
-  // position that fails every bounds check.)
-  const unsigned d_es = p.dout_bf16 ? 2u : 4u, i_es = p.in_bf16 ? 2u : 4u;                     // element sizes in HBM
-  const unsigned d_ps = p.dout_gs ? 8u : (unsigned)p.dout_stride, i_ps = p.in_gs ? 8u : (unsigned)p.in_stride;   // elements per pixel step
-  unsigned d_off[D_F4], d_pos[D_F4], i_off[I_F4], i_pos[I_F4];
-#pragma unroll
-  for (int r = 0; r < D_F4; ++r) {
-    const int f = tid + NTHR * r;
-    const int pix = f / (BNW / 4), n = n0 + (f % (BNW / 4)) * 4;
-    const bool live = pix < NPIX && n < p.N;
-    const unsigned col = p.dout_gs ? (unsigned)((size_t)(n >> 3) * p.dout_gs) + (unsigned)(n & 7) : (unsigned)n;
-    d_off[r] = (((unsigned)(pix / 16) * (unsigned)p.W + (unsigned)(pix & 15)) * d_ps + col) * d_es;
-    d_pos[r] = live ? (unsigned)((pix / 16) << 16 | (pix & 15)) : 0x7fff7fffu;
-  }
-#pragma unroll
-  for (int r = 0; r < I_F4; ++r) {
-    const int f = tid + NTHR * r;
-    const int pix = f / (BCW / 4), c = c0 + (f % (BCW / 4)) * 4;
-    const int py = pix / IW, px = pix - py * IW;
-    const bool live = pix < NPIX_IN && c < p.Cin;
-    const unsigned col = p.in_gs ? (unsigned)((size_t)(c >> 3) * p.in_gs) + (unsigned)(c & 7) : (unsigned)c;
-    i_off[r] = (((unsigned)py * (unsigned)p.W + (unsigned)px) * i_ps + col) * i_es;
-    i_pos[r] = live ? (unsigned)(py << 16 | px) : 0x7fff7fffu;
-  }
-  const bool mixed = (p.dout_bf16 | p.in_bf16) != 0;      // bf16 operands in HBM (diagnostic route of the mixed-precision path)
-  auto uniform64 = [](long long a) -> long long {         // the tile bases are wave-uniform: keep their offsets in SGPRs, so that
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-    return (long long)(((unsigned long long)hi << 32) | lo);                    // a load is scalar base + 32-bit lane offset
-  };
-
+  WgStage<D_F4, NTHR, BNW / 4, 16, NPIX, 0> d_st;
+  WgStage<I_F4, NTHR, BCW / 4, IW, NPIX_IN, 1> i_st;
+  d_st.init(tid, p.W, p.dout_stride, p.dout_gs, p.dout_bf16, n0, p.N);
+  i_st.init(tid, p.W, p.in_stride, p.in_gs, p.in_bf16, c0, p.Cin);
   f32x4 d_reg[D_F4], i_reg[I_F4];
   auto load_tile = [&](int tile) {
     int tt = tile;
     const int tx = tt % p.tiles_x; tt /= p.tiles_x;
     const int ty = tt % p.tiles_y;
     const int b = tt / p.tiles_y;
-    const int y0 = ty * TH, x0 = tx * 16;
-    // origin pixels (the halo corner of the first tile row / column lies before the image: only slots that pass the bounds
-    // check are dereferenced)
-    const long long opix = ((long long)b * p.H + y0) * p.W + x0;
-    const char* const dbase = reinterpret_cast<const char*>(p.dout) + uniform64(opix * (long long)(d_ps * d_es));
-    const char* const ibase = reinterpret_cast<const char*>(p.in) + uniform64((opix - p.W - 1) * (long long)(i_ps * i_es));
-    const unsigned hy = (unsigned)(p.H - y0), wx = (unsigned)(p.W - x0);          // d tile: rows / columns left in the image
-    const unsigned y1 = (unsigned)(y0 - 1), x1 = (unsigned)(x0 - 1);              // input tile: image coordinates of the halo corner
-    auto ld = [&](const char* base, unsigned off, bool live, bool is_bf16) -> f32x4 {
-      f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (live) {
-        if (is_bf16) {
-          const wg_bf16x4 h = *reinterpret_cast<const wg_bf16x4*>(base + off);
-          val = (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
-        } else {
-          val = *reinterpret_cast<const f32x4*>(base + off);
-        }
-      }
-      return val;
-    };
-    auto all = [&](auto d_bf, auto i_bf) {
-#pragma unroll
-      for (int r = 0; r < D_F4; ++r)
-        d_reg[r] = ld(dbase, d_off[r], (d_pos[r] >> 16) < hy && (d_pos[r] & 0xffffu) < wx, d_bf());
-#pragma unroll
-      for (int r = 0; r < I_F4; ++r)
-        i_reg[r] = ld(ibase, i_off[r], (y1 + (i_pos[r] >> 16)) < (unsigned)p.H && (x1 + (i_pos[r] & 0xffffu)) < (unsigned)p.W, i_bf());
-    };
-    if (!mixed) all([] { return false; }, [] { return false; });
-    else all([&] { return p.dout_bf16 != 0; }, [&] { return p.in_bf16 != 0; });
+    wg_load_tile(p, d_st, i_st, d_reg, i_reg, b, ty * TH, tx * 16);
   };
   auto store_tile = [&]() {
 #pragma unroll
@@ -1201,6 +1172,10 @@ static int plan_group(const sininn_wgrad_item* items, int n, int B, int H, int W
     d.in_bf16 = it.in_bf16; d.dout_bf16 = it.dout_bf16;
     d.in_gs = it.in_group_stride > 0 ? (size_t)it.in_group_stride : 0;
     d.dout_gs = it.dout_group_stride > 0 ? (size_t)it.dout_group_stride : 0;
+    // the staging descriptors (WgStage) hold 32-bit byte offsets from a tile's origin pixel
+    SININN_CHECK((unsigned long long)((it.Cin + 7) / 8) * (d.in_gs ? d.in_gs : 8) * 4ull + 64ull * W * (unsigned)it.in_stride < (1ull << 32) &&
+                 (unsigned long long)((it.N + 7) / 8) * (d.dout_gs ? d.dout_gs : 8) * 4ull + 64ull * W * (unsigned)it.dout_stride < (1ull << 32),
+                 "wgrad group: operand %d spans more than 4 GB from a tile origin (32-bit staging offsets)", i);
     d.partial = ws ? ws + off : nullptr; off += (size_t)S * taps * d.Nr * d.Cc;
     d.bpartial = ws ? ws + off : nullptr; off += ((size_t)S * d.Nr + 3) / 4 * 4;
     q.gw = it.gw; q.gb = it.gb;
