@@ -74,14 +74,14 @@ __global__ __launch_bounds__(256) void conv_pair_k1_kernel(PairDev q) {
 
   // ---- stage 0: input tile -> LDS (zero beyond the image and beyond K1) --------------------------------------------
   {
+    // raw buffer loads relative to this block's image: a slot outside the image or beyond K1 carries BUF_OOB and reads zeros
     const int q4 = K1R / 4;
+    const __amdgpu_buffer_rsrc_t in_rs = buf_rsrc(pa.in + (size_t)b * pa.H * pa.W * pa.in_stride);
     for (int f = tid; f < P * q4; f += 256) {
       const int pl = f / q4, c = (f - pl * q4) * 4;
       const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gy < pa.H && gx < pa.W && c < K1)
-        v = *reinterpret_cast<const f32x4*>(pa.in + ((size_t)(b * pa.H + gy) * pa.W + gx) * pa.in_stride + c);
-      *reinterpret_cast<f32x4*>(xs + pl * XS + c) = v;
+      const unsigned off = (gy < pa.H && gx < pa.W && c < K1) ? (unsigned)(((gy * pa.W + gx) * pa.in_stride + c) * 4) : BUF_OOB;
+      *reinterpret_cast<f32x4*>(xs + pl * XS + c) = buf_load4(in_rs, off, 0u);
     }
   }
   __syncthreads();
@@ -100,15 +100,17 @@ __global__ __launch_bounds__(256) void conv_pair_k1_kernel(PairDev q) {
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n) accs[k][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* wrow = pa.w + (size_t)(wave * 64 + li) * K1 + 4 * kq;
+    // weight fragments as raw buffer loads: one lane offset per column tile, the 16-channel step is the scalar offset; the
+    // k-quad beyond K1 of the last step (K1 % 16 != 0) lies past num_records of a descriptor that ends with the pack
+    const __amdgpu_buffer_rsrc_t wa_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pa.w), 0, PK_HID * K1 * 4, 0x00020000);
+    unsigned woff[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) woff[n] = (unsigned)(((wave * 64 + n * 16 + li) * K1 + 4 * kq) * 4);
     const int nsteps = K1R / 16;
     auto load_b = [&](int s, f32x4 (&bf)[4]) {
       const bool live = 16 * s + 4 * kq < K1;         // K1 % 4 == 0 (host check)
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        bf[n] = live ? *reinterpret_cast<const f32x4*>(wrow + (size_t)n * 16 * K1 + ((pa.ablate & 1) ? 0 : 16 * s)) : z;
-      }
+      for (int n = 0; n < 4; ++n) bf[n] = buf_load4(wa_rs, live ? woff[n] : BUF_OOB, (pa.ablate & 1) ? 0u : (unsigned)(64 * s));
     };
     // weights requested RING1 - 1 sixteen-channel steps ahead through a register ring (an L2 round trip is longer than the
     // 16 MT MFMAs of a step)
@@ -204,16 +206,15 @@ __global__ __launch_bounds__(256) void conv_pair_k1_kernel(PairDev q) {
   auto nt_of = [&](int i) -> int { return (wave / WM) + WN * i; };
   auto mt_of = [&](int m) -> int { return MSPLIT ? (wave % WM) : m; };
   {
-    const float* wrow = pb.w + (size_t)li * PK_HID + 4 * kq;
+    const __amdgpu_buffer_rsrc_t wb_rs = buf_rsrc(pb.w);
+    unsigned woff[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) woff[i] = nt_of(i) < NT2 ? (unsigned)((((pa.ablate & 1) ? 0 : nt_of(i)) * 16 + li) * PK_HID + 4 * kq) * 4u : BUF_OOB;
     constexpr int NSTEPS = PK_HID / 16;
     f32x4 bf[DEPTH + 1][NI];
     auto load_b = [&](int s, f32x4 (&dst)[NI]) {
 #pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int nt = nt_of(i);
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        dst[i] = nt < NT2 ? *reinterpret_cast<const f32x4*>(wrow + (size_t)((pa.ablate & 1) ? 0 : nt) * 16 * PK_HID + ((pa.ablate & 1) ? 0 : 16 * s)) : z;
-      }
+      for (int i = 0; i < NI; ++i) dst[i] = buf_load4(wb_rs, woff[i], (pa.ablate & 1) ? 0u : (unsigned)(64 * s));
     };
 #pragma unroll
     for (int s = 0; s < DEPTH; ++s) load_b(s, bf[s]);
