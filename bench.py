@@ -538,11 +538,14 @@ def main():
                 'alg_bytes_per_launch': abytes}
         if not bf16:
             roof['limiter'] = ('nearest roof is the f32 matrix pipe (168 algorithmic FLOP/B against a ridge of 20), but the pipe is '
-                               f'only {executed / peak:.0%} busy: in-kernel phase stamps (DESIGN 6) put the rest in the per-lane Winograd '
-                               'input / output transforms (vector ALU), LDS operand staging and the store-drain of the epilogue')
+                               f'only {executed / peak:.0%} busy: vector-ALU and LDS instructions do not hide behind an MFMA on this chip '
+                               '(tools/mfma_valu.hip: +2.5 / +4.6 clocks each per 32-clock MFMA), so the per-lane Winograd transforms and '
+                               'the fragment reads cost issue time in the K loop (~0.83 of the pipe there), and the block-level ablation '
+                               '(profiles/r03_wino_fwd_ablation.log) puts the rest in operand staging, the chunk barrier and the epilogue')
         else:
-            roof['limiter'] = ('nearest roof is the bf16 matrix pipe; phase stamps (DESIGN 6): operand staging, epilogue store '
-                               'drain and LDS fragment reads around an MFMA loop that is a third of the block time')
+            roof['limiter'] = ('nearest roof is the bf16 matrix pipe; the MFMA loop is LDS-bandwidth-bound (one 16-byte fragment read per '
+                               '32x32x16 MFMA and wave = the 128 B/clk of a CU), and phase stamps (DESIGN 6) put two thirds of the block time '
+                               'in operand staging and the epilogue store drain around it')
         # the same launch against the HBM roof (north_star quotes an HBM fraction): algorithmic bytes / time / 8 TB/s
         roof['hbm'] = {'achieved': abytes / (kms * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                        'frac': abytes / (kms * 1e-3) / 1e9 / PEAK_HBM_GBS,
