@@ -72,8 +72,8 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvDev& p, const float
     float ld_acc = 0.f;
     if constexpr (NTHR % Q == 0) {
       // a thread's channel quad is the same in every iteration: channel offsets and the packed bias are loop invariants,
-      // and the only per-pixel global input (v) is requested one iteration ahead, so the loop no longer pays a
-      // global-load latency per iteration (it was a third of the bf16 kernel's block time)
+      // and the only per-pixel global input (v) is requested for all iterations up front, so the loop pays one
+      // global-load latency, not one per iteration (it was a third of the bf16 kernel's block time)
       const int q4 = tid % Q;
       const int cl = q4 * 4;                         // block-local channel
       const int c = c_block0 + cl;
@@ -92,11 +92,14 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvDev& p, const float
         if (!(cok && pl < NPIX && gy < p.H && gx < p.W)) return z;
         return *reinterpret_cast<const f32x4*>(p.v + ((size_t)(b * p.H + gy) * p.W + gx) * p.v_stride + c);
       };
-      f32x4 v_next = load_v(0);
+      // every iteration's v is requested before the first one is used (the accumulators are dead, registers are free): the
+      // loop pays ONE global-load latency instead of one per iteration
+      f32x4 v_all[ITERS];
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) v_all[it] = load_v(it);
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
-        const f32x4 v4 = v_next;
-        if (it + 1 < ITERS) v_next = load_v(it + 1);
+        const f32x4 v4 = v_all[it];
         const int pl = (tid + it * NTHR) / Q;
         const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
         if (cok && pl < NPIX && gy < p.H && gx < p.W) {
@@ -200,11 +203,15 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvDev& p, const float
                              : *reinterpret_cast<const f32x4*>(p.mask + pix * p.mask_stride + colq);
           return *reinterpret_cast<const f32x4*>(p.addend + pix * p.addend_stride + colq);
         };
-        f32x4 side_next = side(0);
+        // all side inputs of the thread are requested up front (see the coupling path above): with one request in flight the
+        // eight iterations of a 32-column block each waited out a global-load round trip -- 24 us of the 105 us of the level-0
+        // data gradient of conv2 (profiles/r03_wino_fwd_ablation.log)
+        f32x4 side_all[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) side_all[it] = side(it);
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-          const f32x4 sd = side_next;
-          if (it + 1 < ITERS) side_next = side(it + 1);
+          const f32x4 sd = side_all[it];
           const int pl = (tid + it * NTHR) / Q;
           const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
           if (pl < NPIX && gy < p.H && gx < p.W) {
@@ -234,6 +241,68 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvDev& p, const float
             }
             if (p.out_gs) *reinterpret_cast<f32x4*>(p.out + (size_t)(colq >> 3) * p.out_gs + pix * 8 + (colq & 7)) = val;
             else *reinterpret_cast<f32x4*>(p.out + pix * p.out_stride + colq) = val;
+          }
+        }
+        return;
+      }
+      // data gradient of conv1 with the first half's coupling backward fused in (ADD_CBWD_*): full quads with 16-byte aligned
+      // side tensors take the same shape of loop -- every global input of the thread (skip gradient, u, s) is requested up front,
+      // (ds | dt) and dv leave as float4.  (The general loop below did these as 4-byte accesses with one round trip per
+      // iteration: ~15 us of the ~72 us launches of this class.)
+      const bool cbwd = MODE == SININN_CONV_ADD_CBWD_FWD || MODE == SININN_CONV_ADD_CBWD_INV;
+      if (cbwd && colq + 3 < p.N && p.Co % 4 == 0 && p.v_stride % 4 == 0 && p.out_stride % 4 == 0 && p.out2_stride % 4 == 0 &&
+          ((reinterpret_cast<uintptr_t>(p.v) | reinterpret_cast<uintptr_t>(p.sbuf) | reinterpret_cast<uintptr_t>(p.out) |
+            reinterpret_cast<uintptr_t>(p.out2)) & 15) == 0 &&
+          (p.addend_map != nullptr || (p.addend_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(p.addend) & 15) == 0))) {
+        f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bq = *reinterpret_cast<const f32x4*>(p.bias + colq);
+        const float gl = p.logdet ? p.logdet[b] : 0.f;
+        int amap[4] = {colq, colq + 1, colq + 2, colq + 3};
+        if (p.addend_map) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) amap[j] = p.addend_map[colq + j];
+        }
+        f32x4 ad_all[ITERS], u_all[ITERS], s_all[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+          const int pl = (tid + it * NTHR) / Q;
+          const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+          f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          ad_all[it] = z; u_all[it] = z; s_all[it] = z;
+          if (pl < NPIX && gy < p.H && gx < p.W) {
+            const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
+            if (p.addend_map) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) ad_all[it][j] = p.addend[pix * p.addend_stride + amap[j]];
+            } else {
+              ad_all[it] = *reinterpret_cast<const f32x4*>(p.addend + pix * p.addend_stride + colq);
+            }
+            u_all[it] = *reinterpret_cast<const f32x4*>(p.v + pix * p.v_stride + colq);
+            s_all[it] = *reinterpret_cast<const f32x4*>(p.sbuf + pix * p.Co + colq);
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+          const int pl = (tid + it * NTHR) / Q;
+          const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+          if (pl < NPIX && gy < p.H && gx < p.W) {
+            const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
+            f32x4 val = *reinterpret_cast<const f32x4*>(T + pl * TS + (tid % Q) * 4);
+            if (T2) val += *reinterpret_cast<const f32x4*>(T2 + pl * TS + (tid % Q) * 4);
+            val += bq;
+            val += ad_all[it];
+            f32x4 ds4, dt4, dv4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float g = val[j], u = u_all[it][j], sv = s_all[it][j];
+              const float L = glow_log_e(sv, p.clamp), dL = glow_dlog_e(sv, p.clamp);
+              const float e = expf(L);
+              if (MODE == SININN_CONV_ADD_CBWD_FWD) { dv4[j] = g * e; dt4[j] = g; ds4[j] = (g * u * e + gl) * dL; }
+              else { dv4[j] = g / e; dt4[j] = -dv4[j]; ds4[j] = -(g * u + gl) * dL; }
+            }
+            *reinterpret_cast<f32x4*>(p.out + pix * p.out_stride + colq) = ds4;
+            *reinterpret_cast<f32x4*>(p.out + pix * p.out_stride + p.Co + colq) = dt4;
+            *reinterpret_cast<f32x4*>(p.out2 + pix * p.out2_stride + colq) = dv4;
           }
         }
         return;

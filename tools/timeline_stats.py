@@ -31,6 +31,8 @@ def main():
     level_time = defaultdict(int)
     alone = defaultdict(int)
     gaps = []
+    gap_ctx = []                       # (length, kernel that ended before the gap, kernel that starts after it)
+    last_end_name = ''
     cur, prev_t, running = 0, ev[0][0], {}
     for t, d, n in ev:
         dt = t - prev_t
@@ -39,6 +41,9 @@ def main():
             alone[next(iter(running))] += dt
         if cur == 0 and dt > 0:
             gaps.append(dt)
+            gap_ctx.append((dt, last_end_name, n))
+        if d == -1:
+            last_end_name = n
         prev_t = t
         if d == 1:
             running[n] = running.get(n, 0) + 1
@@ -54,6 +59,16 @@ def main():
         print(f'  {k} kernels in flight: {level_time[k] / 1e6:8.3f} ms  {100.0 * level_time[k] / wall:5.1f} %')
     gaps.sort(reverse=True)
     print(f'  idle gaps: {len(gaps)}, total {sum(gaps) / 1e6:.3f} ms, largest {[round(g / 1e3, 1) for g in gaps[:8]]} us')
+    # idle time without the profiler's own buffer flushes (gaps of milliseconds), and where the idle time sits
+    real = [g for g in gap_ctx if g[0] < 2_000_000]
+    print(f'  idle gaps below 2 ms: {len(real)}, total {sum(g[0] for g in real) / 1e6:.3f} ms of {(wall - sum(g[0] for g in gap_ctx if g[0] >= 2_000_000)) / 1e6:.3f} ms')
+    by_pair = defaultdict(lambda: [0, 0])
+    for dt, a, b in real:
+        k = (a.split('(')[0][-48:], b.split('(')[0][-48:])
+        by_pair[k][0] += dt; by_pair[k][1] += 1
+    print('  idle time by (kernel before, kernel after), top 14:')
+    for k, (t, c) in sorted(by_pair.items(), key=lambda kv: -kv[1][0])[:14]:
+        print(f'    {t / 1e3:9.1f} us in {c:4d} gaps   {k[0]}  ->  {k[1]}')
     print('  kernels running alone (top 12 by time):')
     for n, t in sorted(alone.items(), key=lambda kv: -kv[1])[:12]:
         print(f'    {t / 1e6:8.3f} ms  {n[:110]}')
