@@ -39,7 +39,7 @@ __device__ __forceinline__ void epilogue_bf16(const ConvDevB& q, const float* T,
   const int col = n0 + q8 * 8;
   if (col >= p.N) return;                                    // N % 8 == 0 is checked on the host
   const bool masked = p.mode == SININN_CONV_MASK;
-  // loop invariants (bias) hoisted, the per-pixel mask requested one iteration ahead: no global-load latency per iteration
+  // loop invariants (bias) hoisted, the per-pixel masks of ALL iterations requested up front: one global-load latency per block
   f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
   if (!masked && p.bias) {
     b0 = *reinterpret_cast<const f32x4*>(p.bias + col);
@@ -53,11 +53,12 @@ __device__ __forceinline__ void epilogue_bf16(const ConvDevB& q, const float* T,
     if (!(pl < NPIX && gy < p.H && gx < p.W)) return z;
     return *reinterpret_cast<const bf16x8*>(q.mask_b + ((size_t)(b * p.H + gy) * p.W + gx) * p.mask_stride + col);
   };
-  bf16x8 mk_next = load_mask(0);
+  bf16x8 mk_all[ITERS];
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) mk_all[it] = load_mask(it);
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
-    const bf16x8 mk = mk_next;
-    if (it + 1 < ITERS) mk_next = load_mask(it + 1);
+    const bf16x8 mk = mk_all[it];
     const int pl = (tid + it * 256) / Q;
     const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
     if (pl < NPIX && gy < p.H && gx < p.W) {

@@ -120,15 +120,27 @@ __global__ __launch_bounds__(256, 4) void conv_pair_bf16_kernel(PairDevB q) {
     const bool masked = pa.mode == SININN_CONV_MASK;
     const int c8 = (tid & 31) * 8;
     if (masked || q.a.out_b) {
-#pragma unroll 2
-      for (int pl = tid >> 5; pl < P; pl += 8) {
+      // the ReLU masks of all the thread's pixels are requested before the first is used: one global-load latency per pass
+      bf16x8 m_all[P / 8];
+      if (masked) {
+#pragma unroll
+        for (int i = 0; i < P / 8; ++i) {
+          const int pl = (tid >> 5) + 8 * i;
+          const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+          m_all[i] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+          if (gy < pa.H && gx < pa.W)
+            m_all[i] = *reinterpret_cast<const bf16x8*>(q.a.mask_b + ((size_t)(b * pa.H + gy) * pa.W + gx) * pa.mask_stride + c8);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < P / 8; ++i) {
+        const int pl = (tid >> 5) + 8 * i;
         const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
         const bool inimg = gy < pa.H && gx < pa.W;
         const size_t pix = (size_t)(b * pa.H + gy) * pa.W + gx;
         bf16x8 v = *reinterpret_cast<const bf16x8*>(hs + pl * PB_HSB + c8 * 2);
         if (masked) {
-          bf16x8 m = {0, 0, 0, 0, 0, 0, 0, 0};
-          if (inimg) m = *reinterpret_cast<const bf16x8*>(q.a.mask_b + pix * pa.mask_stride + c8);
+          const bf16x8 m = m_all[i];
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = ((float)m[j] > 0.f) ? v[j] : (__bf16)0.f;
           *reinterpret_cast<bf16x8*>(hs + pl * PB_HSB + c8 * 2) = v;

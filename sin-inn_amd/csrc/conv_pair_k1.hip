@@ -161,15 +161,28 @@ __global__ __launch_bounds__(256) void conv_pair_k1_kernel(PairDev q) {
     f32x4 bq = {0.f, 0.f, 0.f, 0.f};
     if (pa.bias) bq = *reinterpret_cast<const f32x4*>(pa.bias + cq);
     const bool masked = pa.mode == SININN_CONV_MASK;
-#pragma unroll 4
-    for (int pl = tid >> 6; pl < P; pl += 4) {
+    // backward: the ReLU masks of all the thread's pixels are requested before the first is used (one global-load latency
+    // for the pass instead of one per group of iterations; the stage-1 accumulators are dead, registers are free)
+    f32x4 m_all[P / 4];
+    if (masked) {
+#pragma unroll
+      for (int i = 0; i < P / 4; ++i) {
+        const int pl = (tid >> 6) + 4 * i;
+        const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+        m_all[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (gy < pa.H && gx < pa.W)
+          m_all[i] = *reinterpret_cast<const f32x4*>(pa.mask + ((size_t)(b * pa.H + gy) * pa.W + gx) * pa.mask_stride + cq);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < P / 4; ++i) {
+      const int pl = (tid >> 6) + 4 * i;
       const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
       const bool inimg = gy < pa.H && gx < pa.W;
       const size_t pix = (size_t)(b * pa.H + gy) * pa.W + gx;
       f32x4 v = *reinterpret_cast<const f32x4*>(hs + pl * PK_HS + cq) + bq;
       if (masked) {
-        f32x4 m = {0.f, 0.f, 0.f, 0.f};
-        if (inimg) m = *reinterpret_cast<const f32x4*>(pa.mask + pix * pa.mask_stride + cq);
+        const f32x4 m = m_all[i];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = m[j] > 0.f ? v[j] : 0.f;
       } else {

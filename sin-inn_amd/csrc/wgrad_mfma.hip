@@ -726,6 +726,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(WgradGroup g) {
     const size_t slab = (size_t)TAPS * ncol;
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
     int k = 0;
+#pragma unroll 4                                     // eight slab loads in flight; the association below is unchanged
     for (; k + 1 < q.S; k += 2) { a0 += src[(size_t)k * slab]; a1 += src[(size_t)(k + 1) * slab]; }
     if (k < q.S) a0 += src[(size_t)k * slab];
     a0 += a1;                                        // fixed association: (even splits) + (odd splits)
