@@ -990,38 +990,77 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradDev& p, const int spl
     }
   };
 
-  // operand that is not prefetched: one (load, load, store) item at a time between the barriers (8 transient VGPRs)
+  // operand that is not prefetched across the MFMA loop: staged between the barriers in batches of NB items -- all 2 NB loads of
+  // a batch are issued before the first is stored (8 NB transient VGPRs; the MFMA operands are dead here).  One item at a time
+  // exposed a global-load round trip per item: 8 per tile for the fp32 input of conv1's gradient.
+  constexpr int NB = 4;
   auto stage_d_direct = [&](int tile) {
     int b, y0, x0; tile_origin(tile, b, y0, x0);
 #pragma unroll 1
-    for (int i = 0; i < D_ITEMS; ++i) {
-      const int f = tid + 256 * i;
-      const int pp = f & 63, g = f >> 6;
-      const int gy = y0 + (pp >> 3), gx = x0 + (pp & 7) * 2;
-      const int n = n0 + g * (DOUT_BF16 ? 8 : 4);
-      const bool rowok = gy < p.H && n < p.N;
-      const size_t base = ((size_t)(b * p.H + gy) * p.W + gx) * p.dout_stride + n;
-      const wgb_u32x4 v0 = (rowok && gx < p.W) ? load16(p.dout, base, DOUT_BF16) : zero4;
-      const wgb_u32x4 v1 = (rowok && gx + 1 < p.W) ? load16(p.dout, base + p.dout_stride, DOUT_BF16) : zero4;
-      store_pairs(dT + (g * (DOUT_BF16 ? 8 : 4)) * PD + pp * 4, PD, v0, v1, DOUT_BF16);
+    for (int i0 = 0; i0 < D_ITEMS; i0 += NB) {
+      wgb_u32x4 v0[NB], v1[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int i = i0 + u;
+        v0[u] = zero4; v1[u] = zero4;
+        if (i < D_ITEMS) {
+          const int f = tid + 256 * i;
+          const int pp = f & 63, g = f >> 6;
+          const int gy = y0 + (pp >> 3), gx = x0 + (pp & 7) * 2;
+          const int n = n0 + g * (DOUT_BF16 ? 8 : 4);
+          const bool rowok = gy < p.H && n < p.N;
+          const size_t base = ((size_t)(b * p.H + gy) * p.W + gx) * p.dout_stride + n;
+          if (rowok && gx < p.W) v0[u] = load16(p.dout, base, DOUT_BF16);
+          if (rowok && gx + 1 < p.W) v1[u] = load16(p.dout, base + p.dout_stride, DOUT_BF16);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int i = i0 + u;
+        if (i < D_ITEMS) {
+          const int f = tid + 256 * i;
+          const int pp = f & 63, g = f >> 6;
+          store_pairs(dT + (g * (DOUT_BF16 ? 8 : 4)) * PD + pp * 4, PD, v0[u], v1[u], DOUT_BF16);
+        }
+      }
     }
   };
   auto stage_i_direct = [&](int tile) {
     int b, y0, x0; tile_origin(tile, b, y0, x0);
 #pragma unroll 1
-    for (int it = 0; it < I_ITEMS; ++it) {
-      const int gi = it / I_RND, rnd = it - gi * I_RND;
-      const int f = tid + 256 * gi;
-      const int g = f >> 6, q = (f & 63) + 64 * rnd;
-      const int c = c0 + g * (IN_BF16 ? 8 : 4);
-      if (q < IPAIRS) {
-        const int row = q / (IWV / 2), pr = q - row * (IWV / 2);
-        const int gy = y0 + row - HALO, gx = x0 + pr * 2 - HALO;
-        const bool rowok = gy >= 0 && gy < p.H && c < p.Cin;
-        const size_t base = ((size_t)(b * p.H + gy) * p.W + gx) * p.in_stride + c;
-        const wgb_u32x4 v0 = (rowok && gx >= 0 && gx < p.W) ? load16(p.in, base, IN_BF16) : zero4;
-        const wgb_u32x4 v1 = (rowok && gx + 1 >= 0 && gx + 1 < p.W) ? load16(p.in, base + p.in_stride, IN_BF16) : zero4;
-        store_pairs(iT + (g * (IN_BF16 ? 8 : 4)) * PI + row * (IROWP * 2) + pr * 4, PI, v0, v1, IN_BF16);
+    for (int it0 = 0; it0 < I_ITEMS; it0 += NB) {
+      wgb_u32x4 v0[NB], v1[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int it = it0 + u;
+        v0[u] = zero4; v1[u] = zero4;
+        if (it < I_ITEMS) {
+          const int gi = it / I_RND, rnd = it - gi * I_RND;
+          const int f = tid + 256 * gi;
+          const int g = f >> 6, q = (f & 63) + 64 * rnd;
+          const int c = c0 + g * (IN_BF16 ? 8 : 4);
+          if (q < IPAIRS) {
+            const int row = q / (IWV / 2), pr = q - row * (IWV / 2);
+            const int gy = y0 + row - HALO, gx = x0 + pr * 2 - HALO;
+            const bool rowok = gy >= 0 && gy < p.H && c < p.Cin;
+            const size_t base = ((size_t)(b * p.H + gy) * p.W + gx) * p.in_stride + c;
+            if (rowok && gx >= 0 && gx < p.W) v0[u] = load16(p.in, base, IN_BF16);
+            if (rowok && gx + 1 >= 0 && gx + 1 < p.W) v1[u] = load16(p.in, base + p.in_stride, IN_BF16);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int it = it0 + u;
+        if (it < I_ITEMS) {
+          const int gi = it / I_RND, rnd = it - gi * I_RND;
+          const int f = tid + 256 * gi;
+          const int g = f >> 6, q = (f & 63) + 64 * rnd;
+          if (q < IPAIRS) {
+            const int row = q / (IWV / 2), pr = q - row * (IWV / 2);
+            store_pairs(iT + (g * (IN_BF16 ? 8 : 4)) * PI + row * (IROWP * 2) + pr * 4, PI, v0[u], v1[u], IN_BF16);
+          }
+        }
       }
     }
   };
