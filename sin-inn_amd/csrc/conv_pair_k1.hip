@@ -77,11 +77,23 @@ __global__ __launch_bounds__(256) void conv_pair_k1_kernel(PairDev q) {
     // raw buffer loads relative to this block's image: a slot outside the image or beyond K1 carries BUF_OOB and reads zeros
     const int q4 = K1R / 4;
     const __amdgpu_buffer_rsrc_t in_rs = buf_rsrc(pa.in + (size_t)b * pa.H * pa.W * pa.in_stride);
-    for (int f = tid; f < P * q4; f += 256) {
-      const int pl = f / q4, c = (f - pl * q4) * 4;
-      const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
-      const unsigned off = (gy < pa.H && gx < pa.W && c < K1) ? (unsigned)(((gy * pa.W + gx) * pa.in_stride + c) * 4) : BUF_OOB;
-      *reinterpret_cast<f32x4*>(xs + pl * XS + c) = buf_load4(in_rs, off, 0u);
+    // four slots per thread in flight (K1 = 192 at level 1 is six slots per thread: one at a time was six round trips per block)
+    for (int f0 = tid; f0 < P * q4; f0 += 4 * 256) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int f = f0 + 256 * u;
+        const int pl = f / q4, c = (f - pl * q4) * 4;
+        const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+        const unsigned off = (f < P * q4 && gy < pa.H && gx < pa.W && c < K1) ? (unsigned)(((gy * pa.W + gx) * pa.in_stride + c) * 4) : BUF_OOB;
+        v[u] = buf_load4(in_rs, off, 0u);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int f = f0 + 256 * u;
+        const int pl = f / q4, c = (f - pl * q4) * 4;
+        if (f < P * q4) *reinterpret_cast<f32x4*>(xs + pl * XS + c) = v[u];
+      }
     }
   }
   __syncthreads();
