@@ -206,9 +206,19 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvDev& p, const float
         // all side inputs of the thread are requested up front (see the coupling path above): with one request in flight the
         // eight iterations of a 32-column block each waited out a global-load round trip -- 24 us of the 105 us of the level-0
         // data gradient of conv2 (profiles/r03_wino_fwd_ablation.log)
-        f32x4 side_all[ITERS];
+        f32x4 side_all[ITERS], fk_all[ITERS];
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) side_all[it] = side(it);
+        if (lrelu_tail) {                                // the LeakyReLU gates of the tail columns, likewise
+#pragma unroll
+          for (int it = 0; it < ITERS; ++it) {
+            const int pl = (tid + it * NTHR) / Q;
+            const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+            fk_all[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (pl < NPIX && gy < p.H && gx < p.W)
+              fk_all[it] = *reinterpret_cast<const f32x4*>(p.mask + ((size_t)(b * p.H + gy) * p.W + gx) * p.mask_stride + colq);
+          }
+        }
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
           const f32x4 sd = side_all[it];
@@ -235,7 +245,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvDev& p, const float
               val += sd;
             }
             if (lrelu_tail) {
-              const f32x4 fk = *reinterpret_cast<const f32x4*>(p.mask + pix * p.mask_stride + colq);
+              const f32x4 fk = fk_all[it];
 #pragma unroll
               for (int j = 0; j < 4; ++j) val[j] = fk[j] > 0.f ? val[j] : val[j] * p.clamp;
             }
