@@ -46,16 +46,32 @@ __global__ __launch_bounds__(256, 4) void conv_pair_bf16_kernel(PairDevB q) {
   {
     const float* in = static_cast<const float*>(q.a.in);
     const int q4 = Kp1 / 4;
-    for (int f = tid; f < P * q4; f += 256) {
-      const int pl = f / q4, c = (f - pl * q4) * 4;
-      const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gy < pa.H && gx < pa.W && c < pa.Cin)                            // Cin % 4 == 0 (host check)
-        v = *reinterpret_cast<const f32x4*>(in + ((size_t)(b * pa.H + gy) * pa.W + gx) * pa.in_stride + c);
-      bf16x4 o;
+    // eight slots per thread in flight (raw buffer loads: a slot outside the image / beyond Cin reads zeros): K1 = 192 is twelve
+    // slots per thread, and one at a time was twelve global-load round trips at the head of every block
+    const __amdgpu_buffer_rsrc_t in_rs = buf_rsrc(in + (size_t)b * pa.H * pa.W * pa.in_stride);
+    constexpr int NB = 8;
+    for (int f0 = tid; f0 < P * q4; f0 += NB * 256) {
+      f32x4 v[NB];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[j];
-      *reinterpret_cast<bf16x4*>(xs + pl * XSB + c * 2) = o;
+      for (int u = 0; u < NB; ++u) {
+        const int f = f0 + 256 * u;
+        const int pl = f / q4, c = (f - pl * q4) * 4;
+        const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+        const unsigned off = (f < P * q4 && gy < pa.H && gx < pa.W && c < pa.Cin)            // Cin % 4 == 0 (host check)
+                                 ? (unsigned)(((gy * pa.W + gx) * pa.in_stride + c) * 4) : BUF_OOB;
+        v[u] = buf_load4(in_rs, off, 0u);
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int f = f0 + 256 * u;
+        if (f < P * q4) {
+          const int pl = f / q4, c = (f - pl * q4) * 4;
+          bf16x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[u][j];
+          *reinterpret_cast<bf16x4*>(xs + pl * XSB + c * 2) = o;
+        }
+      }
     }
   }
   __syncthreads();
