@@ -993,7 +993,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradDev& p, const int spl
   // operand that is not prefetched across the MFMA loop: staged between the barriers in batches of NB items -- all 2 NB loads of
   // a batch are issued before the first is stored (8 NB transient VGPRs; the MFMA operands are dead here).  One item at a time
   // exposed a global-load round trip per item: 8 per tile for the fp32 input of conv1's gradient.
-  constexpr int NB = 8;
+  constexpr int NB = 4;                               // (8: no faster, and the 3x3 kernel spills 8 VGPRs)
   auto stage_d_direct = [&](int tile) {
     int b, y0, x0; tile_origin(tile, b, y0, x0);
 #pragma unroll 1
