@@ -18,6 +18,7 @@
 //   stage 2: the N2 / 16 column tiles are dealt round-robin to the waves, all TH row tiles each; A = the hidden tile (LDS),
 //            B = rows of the second conv's packed weights [N2][256] from L2; accumulators -> T[pixel][N2 + 4] in LDS ->
 //            the shared epilogue (conv_mfma_impl.h), so every mode of the two-kernel path behaves identically.
+#include <cstdlib>
 #include "conv_mfma_impl.h"
 
 namespace sininn {
@@ -330,6 +331,15 @@ int conv_pair_k1_supported(const sininn_conv_args* f, const sininn_conv_args* s)
   const bool couple = s->mode == SININN_CONV_COUPLE_FWD || s->mode == SININN_CONV_COUPLE_INV;
   if (couple && s->col_tile == 32) return s->Np == 64 || s->Np == 192 || s->Np == 96 || s->Np == 32;
   return s->Np == 16 || s->Np == 32 || s->Np == 48 || s->Np == 64 || s->Np == 96 || s->Np == 192;
+}
+
+// Policy of the block executor, not capability: TRAINING forward subnets (hidden tensor stored) with fewer than 32 input
+// channels -- level 0 of the headline config -- take the two-launch path: 54.5 us against 64.9 us for the pair there
+// (tools/bench_pair.py), 8.56 against 8.60 ms per step in an A/B on one box (SININN_PAIR_FWD_MINK=0 / 32 / 128: 8.60 / 8.56 /
+// 8.63 ms).  The no-grad pair (no hidden store), the mixed-precision pair and every backward pair stay fused.
+int conv_pair_k1_preferred(const sininn_conv_args* f) {
+  static const int fwd_mink = getenv("SININN_PAIR_FWD_MINK") ? atoi(getenv("SININN_PAIR_FWD_MINK")) : 32;
+  return !(f->mode == SININN_CONV_RELU && f->out && !f->w_bf16 && f->Cin < fwd_mink);
 }
 
 int conv_pair_k1_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st) {

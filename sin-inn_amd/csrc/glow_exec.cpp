@@ -15,6 +15,7 @@ namespace sininn {
 int conv_launch(const sininn_conv_args* a, hipStream_t st);
 int conv_pair_k1_supported(const sininn_conv_args* f, const sininn_conv_args* s);
 int conv_pair_k1_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st);
+int conv_pair_k1_preferred(const sininn_conv_args* f);
 int conv_sub3_bf16_supported(const sininn_conv_args* f, const sininn_conv_args* s);
 int conv_sub3_bf16_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st);
 bool sub3_fusion_enabled();
@@ -355,7 +356,7 @@ int glow_forward(const sininn_glow_args* a, hipStream_t st) {
       }
     }
     // 1x1 subnets (fp32): both convs in one launch, the hidden tile stays in LDS between them (conv_pair_k1.hip)
-    if (conv_pair_k1_supported(&c1, &c2)) {
+    if (conv_pair_k1_supported(&c1, &c2) && (a->no_save || conv_pair_k1_preferred(&c1))) {
       if (a->no_save) c1.out = nullptr;              // ... and then the hidden tensor never reaches HBM
       ClassScope sc(PC_COUPLE, a->ksize, conv_flops(M, a->ksize, c1.Cin, SININN_HIDDEN) + conv_flops(M, a->ksize, SININN_HIDDEN, 2 * h.co), st);
       if (int rc = conv_pair_k1_launch(&c1, &c2, st)) return rc;
