@@ -260,6 +260,8 @@ int conv_pair_bf16_supported(const sininn_conv_args* f, const sininn_conv_args* 
 
 int conv_pair_bf16_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st) {
   SININN_CHECK(conv_pair_bf16_supported(f, s), "conv_pair_bf16: unsupported pair");
+  SININN_CHECK((unsigned long long)f->H * f->W * f->in_stride * 4ull < (1ull << 31),
+               "conv_pair_bf16: one image of the input exceeds the 2 GB a block addresses (raw buffer staging)");
   PairDevB q;
   sininn_conv_args fa = *f;
   alignas(16) __bf16 dummy_out[8] = {};               // conv_bf16_prepare insists on an output pointer; NULL = "do not store h"

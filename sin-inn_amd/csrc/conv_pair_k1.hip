@@ -345,6 +345,8 @@ int conv_pair_k1_preferred(const sininn_conv_args* f) {
 int conv_pair_k1_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st) {
   SININN_CHECK(conv_pair_k1_supported(f, s), "conv_pair: unsupported pair (check sininn_conv_pair_k1_supported first)");
   if (f->w_bf16) return conv_pair_bf16_launch(f, s, st);
+  SININN_CHECK((unsigned long long)f->H * f->W * f->in_stride * 4ull < (1ull << 31),
+               "conv_pair: one image of the input exceeds the 2 GB a block addresses (raw buffer staging)");
   PairDev q;
   sininn_conv_args fa = *f;
   alignas(16) float dummy_out[4] = {0.f, 0.f, 0.f, 0.f};   // conv_prepare insists on an output pointer; NULL = "do not store h"

@@ -816,6 +816,9 @@ int wgrad_launch(const float* in, int in_stride, int Cin, const float* dout, int
   SININN_CHECK(in_stride >= Cin && in_stride % 4 == 0 && aligned16(in), "wgrad: in must be 16-byte aligned, stride %% 4 == 0");
   SININN_CHECK(dout_stride >= N && dout_stride % 4 == 0 && aligned16(dout), "wgrad: dout must be 16-byte aligned, stride %% 4 == 0");
   SININN_CHECK(B > 0 && H > 0 && W > 0, "wgrad: bad shape");
+  // the staging descriptors (WgStage) hold 32-bit byte offsets from a tile's origin pixel
+  SININN_CHECK(64ull * W * (unsigned)in_stride + 4ull * Cin < (1ull << 32) && 64ull * W * (unsigned)dout_stride + 4ull * N < (1ull << 32),
+               "wgrad: a pixel tile spans more than 4 GB (32-bit staging offsets)");
   const WgradPlan pl = make_plan(N, Cin, ksize, B, H, W);
   SININN_CHECK(ws_bytes >= pl.bytes, "wgrad: workspace too small (%zu < %zu)", ws_bytes, pl.bytes);
   WgradDev d;

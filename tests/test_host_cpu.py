@@ -331,6 +331,24 @@ def test_descriptor_guards_refuse_before_any_launch():
         assert rc != 0 and word in lib.sininn_last_error(), (over, lib.sininn_last_error())
 
 
+def test_32_bit_staging_offsets_are_range_checked_on_the_host():
+    """Round 3 moved the staging loops to 32-bit byte offsets (raw buffer loads inside one image, per-tile descriptors in the
+    weight gradient): shapes those offsets cannot address are refused before any launch (no GPU needed)."""
+    import ctypes as C
+    import sin_inn_amd
+    from sin_inn_amd import _lib
+    lib = _lib.lib()
+    fake = 0x7f0000000000
+    # weight gradient: a pixel tile whose rows are 2^24 pixels x 256 floats apart
+    rc = lib.sininn_wgrad(fake, 256, 256, fake, 256, 256, 1, 8, 1 << 24, 3, fake, None, fake, 1 << 40, None)
+    assert rc != 0 and b'32-bit staging offsets' in lib.sininn_last_error(), lib.sininn_last_error()
+    # Winograd conv: one image of 2048 x 2048 pixels x 256 floats = 4 GB (its element count still fits the older 2^31 check)
+    a = _lib.ConvArgs(B=1, H=2048, W=2048, ksize=3, Cin=256, in_stride=256, Np=32, N=32, out_stride=32, winograd=1, mode=_lib.CONV_LINEAR)
+    a.inp, a.w, a.out = fake, fake, fake
+    rc = lib.sininn_conv(C.byref(a), None)
+    assert rc != 0 and b'exceeds the 2 GB' in lib.sininn_last_error(), lib.sininn_last_error()
+
+
 def test_frame_store_refuses_a_clip_that_does_not_start_at_frame_0(tmp_path):
     """the reference indexes frame_{x:05d}.png from 0 (data.py:33-38): LR frames missing BEFORE the first present index are a
     gap too (they would otherwise sit in neighbouring frames' LR windows as all-zero planes)"""
