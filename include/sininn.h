@@ -161,6 +161,9 @@ typedef struct sininn_conv_args {
   int mask_group_stride;                           /* `mask` (MASK mode)                                                  */
 } sininn_conv_args;
 
+/* Size limits (checked on the host, refused with sininn_last_error): B*H*W*stride of every operand < 2^31 elements; for
+ * winograd = 1 and for sininn_conv_pair_k1 one IMAGE of the input (H*W*in_stride floats) < 2 GB -- the kernels stage through
+ * raw buffer loads with 32-bit byte offsets inside the block's image (1280x720 at 1/4 scale with 256 channels is 59 MB). */
 int sininn_conv(const sininn_conv_args* args, void* stream);
 
 /* Two chained 1x1 convs of a GLOW subnet in one launch (subnet_conv_1x1, archs.py:15-17, called from FrEIA's
