@@ -73,6 +73,52 @@ __global__ __launch_bounds__(256) void conv_pair_k1_kernel(PairDev q) {
     if (stamping) { const unsigned long long t = __builtin_amdgcn_s_memtime(); atomicAdd(pb.stamp + k, t - tprev); tprev = t; }
   };
 
+  // ---- weight fragments of BOTH GEMMs are requested before the input tile is even staged: they depend on nothing this block
+  // computes, and every phase of this kernel used to open with an exposed L2 / HBM round trip (phase stamps at level 0: 11.6 k
+  // clocks of input staging for one load, 23.6 k for a GEMM whose MFMAs need 2 k)
+  // stage 1: raw buffer loads, one lane offset per column tile, the 16-channel step is the scalar offset; the k-quad beyond K1
+  // of the last step (K1 % 16 != 0) carries BUF_OOB
+  const __amdgpu_buffer_rsrc_t wa_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pa.w), 0, PK_HID * K1 * 4, 0x00020000);
+  unsigned woff1[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) woff1[n] = (unsigned)(((wave * 64 + n * 16 + li) * K1 + 4 * kq) * 4);
+  const int nsteps = K1R / 16;
+  auto load_b = [&](int s, f32x4 (&bf)[4]) {
+    const bool live = 16 * s + 4 * kq < K1;         // K1 % 4 == 0 (host check)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) bf[n] = buf_load4(wa_rs, live ? woff1[n] : BUF_OOB, (pa.ablate & 1) ? 0u : (unsigned)(64 * s));
+  };
+  // weights requested RING1 - 1 sixteen-channel steps ahead through a register ring (an L2 round trip is longer than the
+  // 16 MT MFMAs of a step)
+  constexpr int RING1 = PAIR_RING1;
+  f32x4 bfr[RING1][4];
+#pragma unroll
+  for (int s = 0; s < RING1 - 1; ++s)
+    if (s < nsteps) load_b(s, bfr[s]);
+
+  // ---- stage-2 wave layout and its first weight fragments (requested here, used after the activation pass) ----------------
+  constexpr bool MSPLIT = NT2 < 4;
+  // wave grid of stage 2: WM x WN = 4; row-split: one row tile per wave (P = 64: WM = 4) or per wave pair (P = 32: WM = 2,
+  // the pair's two waves take alternate column tiles)
+  constexpr int WM = MSPLIT ? MT : 1, WN = 4 / WM;
+  static_assert(!MSPLIT || MT == 4 || MT == 2, "row-tile split needs 2 or 4 row tiles");
+  constexpr int NI = (NT2 + WN - 1) / WN, MI = MSPLIT ? 1 : MT, DEPTH = MSPLIT ? PAIR_DEPTH_M : PAIR_DEPTH_N;
+  constexpr int KS2 = (NI * MI <= 4) ? 4 : ((NI * MI <= 8) ? 2 : 1);     // accumulator sets, see stage 1
+  auto nt_of = [&](int i) -> int { return (wave / WM) + WN * i; };
+  auto mt_of = [&](int m) -> int { return MSPLIT ? (wave % WM) : m; };
+  const __amdgpu_buffer_rsrc_t wb_rs = buf_rsrc(pb.w);
+  unsigned woff2[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) woff2[i] = nt_of(i) < NT2 ? (unsigned)((((pa.ablate & 1) ? 0 : nt_of(i)) * 16 + li) * PK_HID + 4 * kq) * 4u : BUF_OOB;
+  constexpr int NSTEPS = PK_HID / 16;
+  f32x4 bf2[DEPTH + 1][NI];
+  auto load_b2 = [&](int s, f32x4 (&dst)[NI]) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) dst[i] = buf_load4(wb_rs, woff2[i], (pa.ablate & 1) ? 0u : (unsigned)(64 * s));
+  };
+#pragma unroll
+  for (int s = 0; s < DEPTH; ++s) load_b2(s, bf2[s]);
+
   // ---- stage 0: input tile -> LDS (zero beyond the image and beyond K1) --------------------------------------------
   {
     // raw buffer loads relative to this block's image: a slot outside the image or beyond K1 carries BUF_OOB and reads zeros
@@ -113,25 +159,6 @@ __global__ __launch_bounds__(256) void conv_pair_k1_kernel(PairDev q) {
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n) accs[k][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // weight fragments as raw buffer loads: one lane offset per column tile, the 16-channel step is the scalar offset; the
-    // k-quad beyond K1 of the last step (K1 % 16 != 0) lies past num_records of a descriptor that ends with the pack
-    const __amdgpu_buffer_rsrc_t wa_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pa.w), 0, PK_HID * K1 * 4, 0x00020000);
-    unsigned woff[4];
-#pragma unroll
-    for (int n = 0; n < 4; ++n) woff[n] = (unsigned)(((wave * 64 + n * 16 + li) * K1 + 4 * kq) * 4);
-    const int nsteps = K1R / 16;
-    auto load_b = [&](int s, f32x4 (&bf)[4]) {
-      const bool live = 16 * s + 4 * kq < K1;         // K1 % 4 == 0 (host check)
-#pragma unroll
-      for (int n = 0; n < 4; ++n) bf[n] = buf_load4(wa_rs, live ? woff[n] : BUF_OOB, (pa.ablate & 1) ? 0u : (unsigned)(64 * s));
-    };
-    // weights requested RING1 - 1 sixteen-channel steps ahead through a register ring (an L2 round trip is longer than the
-    // 16 MT MFMAs of a step)
-    constexpr int RING1 = PAIR_RING1;
-    f32x4 bfr[RING1][4];
-#pragma unroll
-    for (int s = 0; s < RING1 - 1; ++s)
-      if (s < nsteps) load_b(s, bfr[s]);
     for (int s0 = 0; s0 < nsteps; s0 += RING1) {
 #pragma unroll
       for (int u = 0; u < RING1; ++u) {
@@ -215,13 +242,6 @@ __global__ __launch_bounds__(256) void conv_pair_k1_kernel(PairDev q) {
   // >= 4 column tiles: they are dealt round-robin to the waves (nt = wave, wave + 4, ...), every wave takes all row tiles;
   // fewer (level-0 shapes: N2 = 48 / 32): every wave takes ONE row tile and all column tiles, so no wave idles -- its
   // 4 * NT2 MFMAs per 16-channel step are shorter than an L2 round trip, hence the weights are requested two steps ahead
-  constexpr bool MSPLIT = NT2 < 4;
-  // wave grid of stage 2: WM x WN = 4; row-split: one row tile per wave (P = 64: WM = 4) or per wave pair (P = 32: WM = 2,
-  // the pair's two waves take alternate column tiles)
-  constexpr int WM = MSPLIT ? MT : 1, WN = 4 / WM;
-  static_assert(!MSPLIT || MT == 4 || MT == 2, "row-tile split needs 2 or 4 row tiles");
-  constexpr int NI = (NT2 + WN - 1) / WN, MI = MSPLIT ? 1 : MT, DEPTH = MSPLIT ? PAIR_DEPTH_M : PAIR_DEPTH_N;
-  constexpr int KS2 = (NI * MI <= 4) ? 4 : ((NI * MI <= 8) ? 2 : 1);     // accumulator sets, see stage 1
   f32x4 acc2[KS2][NI][MI];
 #pragma unroll
   for (int k = 0; k < KS2; ++k)
@@ -229,24 +249,10 @@ __global__ __launch_bounds__(256) void conv_pair_k1_kernel(PairDev q) {
     for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int m = 0; m < MI; ++m) acc2[k][i][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  auto nt_of = [&](int i) -> int { return (wave / WM) + WN * i; };
-  auto mt_of = [&](int m) -> int { return MSPLIT ? (wave % WM) : m; };
   {
-    const __amdgpu_buffer_rsrc_t wb_rs = buf_rsrc(pb.w);
-    unsigned woff[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) woff[i] = nt_of(i) < NT2 ? (unsigned)((((pa.ablate & 1) ? 0 : nt_of(i)) * 16 + li) * PK_HID + 4 * kq) * 4u : BUF_OOB;
-    constexpr int NSTEPS = PK_HID / 16;
-    f32x4 bf[DEPTH + 1][NI];
-    auto load_b = [&](int s, f32x4 (&dst)[NI]) {
-#pragma unroll
-      for (int i = 0; i < NI; ++i) dst[i] = buf_load4(wb_rs, woff[i], (pa.ablate & 1) ? 0u : (unsigned)(64 * s));
-    };
-#pragma unroll
-    for (int s = 0; s < DEPTH; ++s) load_b(s, bf[s]);
 #pragma unroll
     for (int s = 0; s < NSTEPS; ++s) {
-      if (s + DEPTH < NSTEPS) load_b(s + DEPTH, bf[(s + DEPTH) % (DEPTH + 1)]);
+      if (s + DEPTH < NSTEPS) load_b2(s + DEPTH, bf2[(s + DEPTH) % (DEPTH + 1)]);
       f32x4 af[MI];
 #pragma unroll
       for (int m = 0; m < MI; ++m) af[m] = *reinterpret_cast<const f32x4*>(hs + (mt_of(m) * 16 + li) * PK_HS + 16 * s + 4 * kq);
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(256) void conv_pair_k1_kernel(PairDev q) {
         for (int i = 0; i < NI; ++i)
 #pragma unroll
           for (int m = 0; m < MI; ++m)
-            acc2[j % KS2][i][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][j], bf[s % (DEPTH + 1)][i][j], acc2[j % KS2][i][m], 0, 0, 0);
+            acc2[j % KS2][i][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][j], bf2[s % (DEPTH + 1)][i][j], acc2[j % KS2][i][m], 0, 0, 0);
     }
   }
   __syncthreads();                                   // every wave is done reading the hidden tile
