@@ -364,11 +364,14 @@ __global__ __launch_bounds__(256, 2) void wgrad32_kernel(WgradDev p) {
 //   dg = G^T dU G is applied per lane before the slab write.  16 positions x (tiles x N x C) instead of 9 taps x (pixels x N x C):
 //   2.25x fewer MFMA FLOPs.  Both transforms are done per lane in registers (lane = (n or c, tile)); MFMA rows = n,
 //   cols = c, k = 4 Winograd tiles.  Block = 64 n x 32 c, waves 2 x 2, wave tile 32 n x 16 c x 16 positions
-//   (128 accumulator VGPRs); pixel tiles of 8x16 (32 Winograd tiles = 8 k-steps) are walked split-K style.
+//   (128 accumulator VGPRs); pixel tiles of TH x 16 (4 x 16 in the shipped kernels: 16 Winograd tiles = 4 k-steps, walked two
+//   k-steps -- one Winograd tile row -- at a time, see the loop) are walked split-K style.
 // ------------------------------------------------------------------------------------------------
 // WIDE_C: block = 32 n x 64 c (waves 1 x 4) instead of 64 n x 32 c (waves 2 x 2), for problems with at most 32 output
 // channels (the four growth convs of an IRN DenseBlock, N = 32: in a 64-row block the two waves of the upper row half have
 // no live row tile at all and only transform inputs for nothing -- half the block's matrix-pipe slots)
+// (UNR: the k-loop's unroll factor until round 3; the loop now walks k-step pairs without unrolling.  The parameter is kept so
+// that kernel names stay comparable with the committed profiles.)
 template <int TH, int UNR, int KH, bool WIDE_C = false>
 __device__ __forceinline__ void wgrad_wino_body(const WgradDev& p, const int split, const int n0, const int c0, const int zblock) {
   // KH = 2: eight waves; the two wave quads take alternate halves of every pixel tile's k-steps and are summed through
