@@ -8,6 +8,7 @@
 #include <utility>
 #include <vector>
 
+#include <cstdlib>
 #include "common.h"
 
 namespace sininn {
@@ -398,11 +399,14 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
   const int* map_b = a->dst_map ? a->dst_map + base_b : nullptr;
 
   // grouped weight gradients: the four problems are collected and launched together once the last of their inputs (the
-  // first half's dh) has been queued; one launch pair on the weight-gradient stream instead of four
-  // 3x3 blocks only: their grouped launch saves ~0.3 ms of kernel time per step (slab reduce 0.28 -> 0.09 ms, gradient
-  // kernels -4 %); the 1x1 convs are faster on their own kernels (N = 48 runs a 48 x 64 tile there, 64 x ... padded here)
+  // first half's dh) has been queued; one launch pair on the weight-gradient stream instead of four.
+  // 3x3 blocks: the grouped launch saves ~0.3 ms of kernel time per step (slab reduce 0.28 -> 0.09 ms, gradient kernels -4 %).
+  // 1x1 blocks: until the staging of the f32 kernels was rewritten (round 3, WgStage) their per-conv kernels were faster (N = 48
+  // runs a 48 x 64 tile there, 64 x ... padded here); since then the group wins: class 1.00 -> 0.86 ms per step, step 8.60 ->
+  // 8.49 ms in an A/B on one box (SININN_WGRAD_GROUP_K1=0 restores the per-conv launches).
   const bool bf16 = a->dtype == 1;
-  const bool grouped = bf16 || (wgrad_grouping_enabled() && k == 3);      // the bf16-operand loads exist in the grouped kernels
+  static const bool group_k1 = !(getenv("SININN_WGRAD_GROUP_K1") && atoi(getenv("SININN_WGRAD_GROUP_K1")) == 0);
+  const bool grouped = bf16 || (wgrad_grouping_enabled() && (k == 3 || group_k1));   // the bf16-operand loads exist in the grouped kernels
   const bool per_half = wgrad_group_mode() == 2;
   sininn_wgrad_item items[4] = {};
   int n_items = 0;
