@@ -345,7 +345,8 @@ int conv_pair_k1_supported(const sininn_conv_args* f, const sininn_conv_args* s)
 // 8.63 ms).  The no-grad pair (no hidden store), the mixed-precision pair and every backward pair stay fused.
 int conv_pair_k1_preferred(const sininn_conv_args* f) {
   static const int fwd_mink = getenv("SININN_PAIR_FWD_MINK") ? atoi(getenv("SININN_PAIR_FWD_MINK")) : 32;
-  return !(f->mode == SININN_CONV_RELU && f->out && !f->w_bf16 && f->Cin < fwd_mink);
+  static const int fwd_mink_bf16 = getenv("SININN_PAIR_FWD_MINK_BF16") ? atoi(getenv("SININN_PAIR_FWD_MINK_BF16")) : 0;   // diagnostic
+  return !(f->mode == SININN_CONV_RELU && f->out && f->Cin < (f->w_bf16 ? fwd_mink_bf16 : fwd_mink));
 }
 
 int conv_pair_k1_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st) {
