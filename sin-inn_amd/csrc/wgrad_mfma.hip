@@ -63,7 +63,7 @@ struct WgStage {
       const int py = pix / TW, px = pix - py * TW;
       const unsigned col = gs ? (unsigned)((size_t)(ch >> 3) * gs) + (unsigned)(ch & 7) : (unsigned)ch;
       off[r] = (((unsigned)py * (unsigned)W + (unsigned)px) * ps + col) * es;
-      pos[r] = (pix < NPX && ch < chmax) ? (unsigned)(py << 16 | px) : 0x7fff7fffu;
+      pos[r] = (pix < NPX && ch < chmax) ? (unsigned)(py << 16 | px) : 0xffffffffu;     // fails both checks while H, W < 65535
     }
   }
   // tile origin (image b, pixel row y0, column x0: WITHOUT the halo) in an image of H x W pixels
@@ -820,7 +820,8 @@ int wgrad_launch(const float* in, int in_stride, int Cin, const float* dout, int
   SININN_CHECK(dout_stride >= N && dout_stride % 4 == 0 && aligned16(dout), "wgrad: dout must be 16-byte aligned, stride %% 4 == 0");
   SININN_CHECK(B > 0 && H > 0 && W > 0, "wgrad: bad shape");
   // the staging descriptors (WgStage) hold 32-bit byte offsets from a tile's origin pixel
-  SININN_CHECK(64ull * W * (unsigned)in_stride + 4ull * Cin < (1ull << 32) && 64ull * W * (unsigned)dout_stride + 4ull * N < (1ull << 32),
+  SININN_CHECK(H < 65535 && W < 65535 && 64ull * W * (unsigned)in_stride + 4ull * Cin < (1ull << 32) &&
+               64ull * W * (unsigned)dout_stride + 4ull * N < (1ull << 32),
                "wgrad: a pixel tile spans more than 4 GB (32-bit staging offsets)");
   const WgradPlan pl = make_plan(N, Cin, ksize, B, H, W);
   SININN_CHECK(ws_bytes >= pl.bytes, "wgrad: workspace too small (%zu < %zu)", ws_bytes, pl.bytes);
@@ -1219,7 +1220,8 @@ static int plan_group(const sininn_wgrad_item* items, int n, int B, int H, int W
     d.in_gs = it.in_group_stride > 0 ? (size_t)it.in_group_stride : 0;
     d.dout_gs = it.dout_group_stride > 0 ? (size_t)it.dout_group_stride : 0;
     // the staging descriptors (WgStage) hold 32-bit byte offsets from a tile's origin pixel
-    SININN_CHECK((unsigned long long)((it.Cin + 7) / 8) * (d.in_gs ? d.in_gs : 8) * 4ull + 64ull * W * (unsigned)it.in_stride < (1ull << 32) &&
+    SININN_CHECK(H < 65535 && W < 65535 &&
+                 (unsigned long long)((it.Cin + 7) / 8) * (d.in_gs ? d.in_gs : 8) * 4ull + 64ull * W * (unsigned)it.in_stride < (1ull << 32) &&
                  (unsigned long long)((it.N + 7) / 8) * (d.dout_gs ? d.dout_gs : 8) * 4ull + 64ull * W * (unsigned)it.dout_stride < (1ull << 32),
                  "wgrad group: operand %d spans more than 4 GB from a tile origin (32-bit staging offsets)", i);
     d.partial = ws ? ws + off : nullptr; off += (size_t)S * taps * d.Nr * d.Cc;
