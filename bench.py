@@ -352,6 +352,7 @@ def main():
         custom = True
     torch.manual_seed(0)                                   # identical random-init weights on every rank
     model = lit_wrapper.SingleVideoINN(3, args.height, args.width, opt).to(dev)
+    model.freeze_gc = True                                 # this process is the benchmark's alone (lit_wrapper: opt-in)
     if args.no_overlap or args.overlap == 'none':
         args.no_overlap = True
         _m.USE_SIDE_STREAM[0] = False

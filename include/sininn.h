@@ -44,6 +44,10 @@ size_t sininn_sizeof(int which);
  * until the process exits.  ABI v4. */
 int sininn_stream_priority_range(int* least, int* greatest);
 int sininn_stream_create(int priority, void** stream);
+/* Stream-capture diagnostics (hipGraph replay of the pass chains, lit_wrapper._graph_step): which of `n` helper streams belong to
+ * the capture that `origin` started and still hold work that is NOT joined back into origin.  flags[i]: 0 not part of it,
+ * 1 capturing and joined, 2 capturing and unjoined (hipStreamEndCapture on origin would fail).  Host-only graph walk. */
+int sininn_capture_unjoined(void* origin, void** streams, int n, int* flags);
 
 /* ------------------------------------------------------------------------------------------------
  * Weight packing.  Source: torch Conv2d weight, OIHW fp32 [N][Cin][k][k] (archs.py:12-13,16-17).
@@ -364,6 +368,10 @@ int sininn_glow_backward(const sininn_glow_args* args, void* stream, void* wgrad
  * rev, dtype, s1 / s2 .winograd, saved).  With these gates forced, a float64 evaluation of the network is a smooth function
  * and can be compared with the HIP path without the discrete noise of units that sit within rounding distance of 0. */
 int sininn_glow_hidden_gates(const sininn_glow_args* args, int which, uint8_t* gates, void* stream);
+/* 1 when the block executor may keep the 256-channel hidden tensors of a fp32 3x3 subnet channel-group-major ([256/8][M][8]) at
+ * this shape, 0 when it takes the row-major layout because the 32-bit staging offsets of the kernels reading the tensor could not
+ * address it (the same bound sininn_conv / sininn_wgrad_group check and refuse).  Host-only; no launch. */
+int sininn_glow_group_major_fits(int B, int H, int W);
 
 /* ------------------------------------------------------------------------------------------------
  * Index maps: FrEIA IRevNetDownsampling (archs.py:28-31,35-38) and PermuteRandom (archs.py:65-68),

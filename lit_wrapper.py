@@ -34,7 +34,7 @@ def _second_stream(device):
     key = str(device)
     if key not in _SECOND:
         from sin_inn_amd.modules import make_stream
-        _SECOND[key] = make_stream(device, int(os.environ.get('SININN_PASS2_PRIO', '0')))
+        _SECOND[key] = make_stream(device, int(os.environ.get('SININN_PASS2_PRIO', '0')), 'second pass chain')
     return _SECOND[key]
 
 
@@ -260,12 +260,24 @@ class SingleVideoINN(pl.LightningModule):
     def _graph_step(self, batch, optim):
         """Replay (or, once, capture) the pass chains for this batch; returns the loss scalar or None if the step must run
         eagerly (warm-up, capture refused by the runtime)."""
-        from sin_inn_amd.modules import join_side_streams, side_stream_if_any
+        from sin_inn_amd.modules import _PACK_REGISTRY, USE_SIDE_STREAM, USE_WINOGRAD, join_capturing_helpers, join_side_streams, \
+            side_stream_if_any
         hr, lr = batch[0]['hr'], batch[0]['lr']
-        from sin_inn_amd.modules import USE_SIDE_STREAM
-        key = (tuple(hr.shape), tuple(lr.shape), tuple(hr.stride()), tuple(lr.stride()), getattr(self.opt, 'precision', 'fp32'),
-               self.overlap_passes, USE_SIDE_STREAM[0])
-        st = self.__dict__.setdefault('_graphs', {}).setdefault(key, {'seen': 0})
+        o = self.opt
+        # everything a capture bakes in besides the kernels' shapes (ADVICE r3): the loss weights (a zero weight removes a term's
+        # launches, any other value is a kernel argument), which parameters are trained (NULL gradient pointers / skipped data
+        # gradients), the conv algorithm switch, and the ADDRESSES of every packed-weight buffer -- the pack registry's generation
+        # changes whenever one is allocated or dropped (Winograd switch, weights re-homed, load_state_dict onto new storage)
+        trained = tuple(p.requires_grad for p in self.inn.parameters())
+        key = (tuple(hr.shape), tuple(lr.shape), tuple(hr.stride()), tuple(lr.stride()), getattr(o, 'precision', 'fp32'),
+               self.overlap_passes, USE_SIDE_STREAM[0], bool(USE_WINOGRAD[0]),
+               (o.lambda_fwd_rec, o.lambda_fwd_mmd, o.lambda_latent_nll, o.lambda_bwd_rec, o.lambda_bwd_mmd, o.lambda_bwd_tcr, o.z_dims, o.lr_dims),
+               hash(trained))
+        graphs = self.__dict__.setdefault('_graphs', {})
+        gen = _PACK_REGISTRY.generation
+        for k in [k for k, v in graphs.items() if 'graph' in v and v['generation'] != gen]:
+            del graphs[k]                              # a pack buffer it replays from may have been freed: capture again
+        st = graphs.setdefault(key, {'seen': 0})
         st['seen'] += 1
         if 'graph' not in st:
             if st['seen'] <= self.GRAPH_WARMUP:
@@ -283,12 +295,18 @@ class SingleVideoINN(pl.LightningModule):
                     if side is not None:               # the weight-gradient stream forked inside the capture: join it back
                         torch.cuda.current_stream().wait_stream(side)
                     out = out.clone()
+                    # nothing may be left on a stream other than the capturing one when the capture ends ("the
+                    # capture_end abort of round 3"): checked on the graph under construction, joined if found, and reported
+                    loose = join_capturing_helpers()
+                    if loose:
+                        logging.warning('hipGraph capture: work was still unjoined on ' + ', '.join(loose) + ' (joined now)')
+                        self.__dict__.setdefault('_capture_loose', []).extend(loose)
             except Exception as e:                     # noqa: BLE001 -- a runtime that refuses the capture must not stop training
                 logging.warning(f'hipGraph capture refused ({type(e).__name__}: {e}); this model continues eagerly')
                 self._graph_broken = True
                 torch.cuda.synchronize()
                 return None
-            st.update(graph=g, hr=s_hr, lr=s_lr, loss=out)
+            st.update(graph=g, hr=s_hr, lr=s_lr, loss=out, generation=_PACK_REGISTRY.generation)
             logging.info(f'captured the pass chains of a training step as one hipGraph for batch {tuple(hr.shape)}')
         else:
             st['hr'].copy_(hr, non_blocking=True); st['lr'].copy_(lr, non_blocking=True)
@@ -307,18 +325,33 @@ class SingleVideoINN(pl.LightningModule):
     # steps of run-ahead the GPU has queued: the GPU drains and idles.  Whether one falls into a 20 - 30 step measurement is
     # what made the step time bimodal (9.8 vs 11.2 - 12.8 ms at configs[1]).  After GC_FREEZE_AFTER steps -- modules, packs,
     # streams, lazily built maps exist by then -- everything alive is moved to the permanent generation (gc.freeze): later
-    # collections only look at what a step itself creates.  SININN_GC_FREEZE=0 switches it off.
+    # collections only look at what a step itself creates.  gc.freeze() is a PROCESS-WIDE interpreter setting, so the module
+    # does not touch it on its own: the owner of the training loop opts in with `model.freeze_gc = True` -- the
+    # Trainer of sin_inn_amd.lightning does for the duration of fit() and calls gc.unfreeze() when fit() returns, bench.py does
+    # for its process -- or the environment does (SININN_GC_FREEZE=1; =0 forbids it whatever the owner says).
     GC_FREEZE_AFTER = 3
     _gc_frozen = [False]
+    freeze_gc = False
 
     def _maybe_freeze_gc(self):
         n = self.__dict__.get('_steps_seen', 0) + 1
         self.__dict__['_steps_seen'] = n
-        if n == self.GC_FREEZE_AFTER and not SingleVideoINN._gc_frozen[0] and os.environ.get('SININN_GC_FREEZE', '1') != '0':
+        env = os.environ.get('SININN_GC_FREEZE')
+        wanted = (self.freeze_gc or env == '1') and env != '0'
+        if n == self.GC_FREEZE_AFTER and wanted and not SingleVideoINN._gc_frozen[0]:
             import gc
             gc.collect()
             gc.freeze()
             SingleVideoINN._gc_frozen[0] = True
+
+    @staticmethod
+    def unfreeze_gc():
+        """Undo _maybe_freeze_gc (end of a training loop): the frozen objects return to the oldest generation and are
+        collectable again."""
+        if SingleVideoINN._gc_frozen[0]:
+            import gc
+            gc.unfreeze()
+            SingleVideoINN._gc_frozen[0] = False
 
     def training_step(self, batch, batch_idx):
         self._maybe_freeze_gc()

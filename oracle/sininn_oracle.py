@@ -524,32 +524,46 @@ def load_reference_irn_state(oracle_net, ref_state):
 # LR synthesis of datasets/prepare.py (extract_bayer :35-52 without the optional Lanczos resize, binning :54-82,
 # quantisation :127-128,164) in numpy float64, the reference's own dtype
 # ----------------------------------------------------------------------------------------------
+def bayer_planes(frame_u8, scale, reduction):
+    """prepare.py:127-128 (u8 -> [0,1] float64), extract_bayer :35-52 (no resize), binning :54-82 -> (mosaic, [R, G1, G2, B] binned
+    planes), all float64 like the reference."""
+    red = {'mean': np.mean, 'sum': np.sum}[reduction]
+    f = frame_u8 / 255
+    bayer = np.empty(f.shape[:2])
+    bayer[::2, ::2] = f[::2, ::2, 0]
+    bayer[::2, 1::2] = f[::2, 1::2, 1]
+    bayer[1::2, ::2] = f[1::2, ::2, 1]
+    bayer[1::2, 1::2] = f[1::2, 1::2, 2]
+    planes = []
+    for plane in (bayer[::2, ::2], bayer[::2, 1::2], bayer[1::2, ::2], bayer[1::2, 1::2]):
+        ph, pw = plane.shape
+        blocks = plane[:, :, None].reshape(ph // scale, scale, pw // scale, scale, 1)
+        planes.append(red(red(blocks, 1), -2).squeeze(-1))
+    return bayer, planes
+
+
+def bayer_mosaic(frame_u8, scale=4, reduction='mean'):
+    """prepare.py:103-116: the UNQUANTISED binned RGGB planes packed back into one Bayer mosaic (what pack_demosaic hands to the
+    demosaicer).  One frame (H,W,3) uint8 -> (H/s, W/s) float64.  Pinned by fixture G8."""
+    _, planes = bayer_planes(frame_u8, scale, reduction)
+    h, w = planes[0].shape
+    cfa = np.empty((2 * h, 2 * w))
+    cfa[::2, ::2], cfa[::2, 1::2], cfa[1::2, ::2], cfa[1::2, 1::2] = planes
+    return cfa
+
+
 def bayer_demosaic(hr_u8, scale=4, reduction='mean'):
-    """datasets/prepare.py:103-119,158,163-165: pack the UNQUANTISED binned RGGB planes into a Bayer mosaic and demosaic
-    it bilinearly, then clip and quantise.  The demosaic restates colour_demosaicing 0.1.6 (pinned in requirements.txt,
-    absent here -> parity unpinned for this function) `demosaicing_CFA_Bayer_bilinear(CFA, 'RGGB')`:
+    """datasets/prepare.py:103-119,158,163-165: pack the UNQUANTISED binned RGGB planes into a Bayer mosaic (pinned, G8) and
+    demosaic it bilinearly, then clip and quantise.  The demosaic restates colour_demosaicing 0.1.6 (pinned in requirements.txt,
+    absent here -> parity unpinned for this step) `demosaicing_CFA_Bayer_bilinear(CFA, 'RGGB')`:
     R/B = convolve(CFA * mask, [[1,2,1],[2,4,2],[1,2,1]]/4), G = convolve(CFA * mask, [[0,1,0],[1,4,1],[0,1,0]]/4) with
     scipy.ndimage.convolve's default 'reflect' boundary.  hr (T,H,W,3) uint8 -> (T,H/s,W/s,3) uint8."""
     from scipy.ndimage import convolve
-    red = {'mean': np.mean, 'sum': np.sum}[reduction]
     h_g = np.array([[0, 1, 0], [1, 4, 1], [0, 1, 0]], dtype=np.float64) / 4
     h_rb = np.array([[1, 2, 1], [2, 4, 2], [1, 2, 1]], dtype=np.float64) / 4
     out = []
     for frame in hr_u8:
-        f = frame / 255
-        bayer = np.empty(f.shape[:2])
-        bayer[::2, ::2] = f[::2, ::2, 0]
-        bayer[::2, 1::2] = f[::2, 1::2, 1]
-        bayer[1::2, ::2] = f[1::2, ::2, 1]
-        bayer[1::2, 1::2] = f[1::2, 1::2, 2]
-        planes = []
-        for plane in (bayer[::2, ::2], bayer[::2, 1::2], bayer[1::2, ::2], bayer[1::2, 1::2]):
-            ph, pw = plane.shape
-            blocks = plane[:, :, None].reshape(ph // scale, scale, pw // scale, scale, 1)
-            planes.append(red(red(blocks, 1), -2).squeeze(-1))
-        h, w = planes[0].shape
-        cfa = np.empty((2 * h, 2 * w))
-        cfa[::2, ::2], cfa[::2, 1::2], cfa[1::2, ::2], cfa[1::2, 1::2] = planes
+        cfa = bayer_mosaic(frame, scale, reduction)
         r_m = np.zeros_like(cfa); r_m[::2, ::2] = 1
         b_m = np.zeros_like(cfa); b_m[1::2, 1::2] = 1
         g_m = 1 - r_m - b_m
@@ -559,21 +573,9 @@ def bayer_demosaic(hr_u8, scale=4, reduction='mean'):
 
 
 def bayer_bin(hr_u8, scale=4, reduction='mean'):
-    """hr (T,H,W,3) uint8 numpy -> lr (T,H/(2s),W/(2s),4) uint8."""
-    red = {'mean': np.mean, 'sum': np.sum}[reduction]
+    """hr (T,H,W,3) uint8 numpy -> lr (T,H/(2s),W/(2s),4) uint8 (prepare.py:35-82 + the quantisation of :164).  Pinned by G8."""
     out = []
     for frame in hr_u8:
-        f = frame / 255
-        bayer = np.empty(f.shape[:2])
-        bayer[::2, ::2] = f[::2, ::2, 0]
-        bayer[::2, 1::2] = f[::2, 1::2, 1]
-        bayer[1::2, ::2] = f[1::2, ::2, 1]
-        bayer[1::2, 1::2] = f[1::2, 1::2, 2]
-        h, w = bayer.shape
-        binned = np.empty((h // scale // 2, w // scale // 2, 4))
-        for k, plane in enumerate((bayer[::2, ::2], bayer[::2, 1::2], bayer[1::2, ::2], bayer[1::2, 1::2])):
-            ph, pw = plane.shape
-            blocks = plane[:, :, None].reshape(ph // scale, scale, pw // scale, scale, 1)
-            binned[..., k] = red(red(blocks, 1), -2).squeeze()
-        out.append((np.clip(binned, 0, 1) * 255).astype(np.uint8))
+        _, planes = bayer_planes(frame, scale, reduction)
+        out.append((np.clip(np.stack(planes, -1), 0, 1) * 255).astype(np.uint8))
     return np.stack(out)

@@ -144,6 +144,8 @@ _SIGS = {
     'sininn_glow_forward': (C.c_int, [C.POINTER(GlowArgs), C.c_void_p]),
     'sininn_glow_backward': (C.c_int, [C.POINTER(GlowArgs), C.c_void_p, C.c_void_p]),
     'sininn_glow_hidden_gates': (C.c_int, [C.POINTER(GlowArgs), C.c_int, C.c_void_p, C.c_void_p]),
+    'sininn_glow_group_major_fits': (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    'sininn_capture_unjoined': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int)]),
     'sininn_conv_pair_k1_supported': (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs)]),
     'sininn_conv_sub3_supported': (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs)]),
     'sininn_conv_sub3': (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs), C.c_void_p]),

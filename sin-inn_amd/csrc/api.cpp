@@ -2,6 +2,10 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
 #include "common.h"
 
 namespace sininn {
@@ -125,6 +129,7 @@ size_t glow_scratch_bytes(int B, int H, int W, int C, int ksize);
 int glow_forward(const sininn_glow_args* a, hipStream_t st);
 int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst);
 int glow_hidden_gates(const sininn_glow_args* a, int which, unsigned char* gates, hipStream_t st);
+bool group_major_fits(size_t M, int W);
 }  // namespace sininn
 
 using namespace sininn;
@@ -148,6 +153,55 @@ int sininn_stream_create(int priority, void** stream) {
   hipError_t e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority);
   if (e != hipSuccess) { set_error("stream_create(priority %d): %s", priority, hipGetErrorString(e)); return (int)e; }
   *stream = s;
+  return 0;
+}
+
+/* Capture diagnostics: for each of `n` streams, is it part of the stream capture that `origin` started and is its work joined
+ * back into origin?  flags[i] = 0 not capturing (or another capture), 1 capturing and every node at its frontier is an ancestor of
+ * (or is at) origin's frontier, 2 capturing and UNJOINED: ending the capture now would fail (hipErrorStreamCaptureUnjoined).
+ * Walks the graph under construction (hipStreamGetCaptureInfo_v2 + hipGraphGetEdges); launches nothing. */
+int sininn_capture_unjoined(void* origin, void** streams, int n, int* flags) {
+  if (!streams || !flags || n < 0) { set_error("capture_unjoined: null argument"); return 1; }
+  hipStreamCaptureStatus st0 = hipStreamCaptureStatusNone;
+  unsigned long long id0 = 0;
+  hipGraph_t graph = nullptr;
+  const hipGraphNode_t* deps0 = nullptr;
+  size_t nd0 = 0;
+  hipError_t e = hipStreamGetCaptureInfo_v2((hipStream_t)origin, &st0, &id0, &graph, &deps0, &nd0);
+  if (e != hipSuccess) { set_error("capture_unjoined: %s", hipGetErrorString(e)); return (int)e; }
+  for (int i = 0; i < n; ++i) flags[i] = 0;
+  if (st0 != hipStreamCaptureStatusActive) return 0;
+  size_t ne = 0;
+  e = hipGraphGetEdges(graph, nullptr, nullptr, &ne);
+  if (e != hipSuccess) { set_error("capture_unjoined: hipGraphGetEdges: %s", hipGetErrorString(e)); return (int)e; }
+  std::vector<hipGraphNode_t> from(ne), to(ne);
+  if (ne) {
+    e = hipGraphGetEdges(graph, from.data(), to.data(), &ne);
+    if (e != hipSuccess) { set_error("capture_unjoined: hipGraphGetEdges: %s", hipGetErrorString(e)); return (int)e; }
+  }
+  // ancestors of origin's frontier (reverse reachability)
+  std::unordered_map<hipGraphNode_t, std::vector<hipGraphNode_t>> preds;
+  for (size_t k = 0; k < ne; ++k) preds[to[k]].push_back(from[k]);
+  std::unordered_set<hipGraphNode_t> anc;
+  std::vector<hipGraphNode_t> stack(deps0, deps0 + nd0);
+  while (!stack.empty()) {
+    hipGraphNode_t v = stack.back(); stack.pop_back();
+    if (!anc.insert(v).second) continue;
+    auto it = preds.find(v);
+    if (it != preds.end()) for (hipGraphNode_t p : it->second) stack.push_back(p);
+  }
+  for (int i = 0; i < n; ++i) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    const hipGraphNode_t* deps = nullptr;
+    size_t nd = 0;
+    hipGraph_t g = nullptr;
+    if (hipStreamGetCaptureInfo_v2((hipStream_t)streams[i], &st, &id, &g, &deps, &nd) != hipSuccess) { (void)hipGetLastError(); continue; }
+    if (st != hipStreamCaptureStatusActive || id != id0) continue;
+    flags[i] = 1;
+    for (size_t k = 0; k < nd; ++k)
+      if (!anc.count(deps[k])) { flags[i] = 2; break; }
+  }
   return 0;
 }
 
@@ -400,6 +454,7 @@ int sininn_pack_conv_weights_bf16(const float* w_oihw, const float* bias, int N,
 void sininn_profile_classes_begin(void) { profile_classes_begin(); }
 int sininn_profile_classes_end(int n, double* ms, double* flops, int* launches) { return profile_classes_end(n, ms, flops, launches); }
 
+int sininn_glow_group_major_fits(int B, int H, int W) { return group_major_fits((size_t)B * H * W, W) ? 1 : 0; }
 int sininn_glow_hidden_gates(const sininn_glow_args* args, int which, uint8_t* gates, void* stream) {
   return glow_hidden_gates(args, which, gates, ST(stream));
 }

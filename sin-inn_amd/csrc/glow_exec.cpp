@@ -169,10 +169,17 @@ static inline double conv_flops(size_t M, int k, int cin, int n) { return 2.0 * 
 static const bool g_group_major = getenv("SININN_GROUP_MAJOR") == nullptr || atoi(getenv("SININN_GROUP_MAJOR")) != 0;   // A/B switch
 
 // h / dh of this subnet are channel-group-major: fp32, 3x3, every conv of the subnet on the Winograd kernels, and the
-// tensor small enough for the int group stride
+// tensor small enough for the 32-bit staging offsets of the kernels that read it: the Winograd convs advance through the
+// 256 / 8 channel groups with a 32-bit byte offset (conv_prepare: (Cin / 8) * group stride * 4 < 2^32) and the weight-gradient
+// staging descriptors hold 32-bit byte offsets from a tile origin (wgrad_group_plan: the same product + a 64-row tile span).
+// Larger tensors (M = B*H*W >= ~2^22 pixels, e.g. 1024 x 1024 at batch 16, level 0) take the row-major hidden layout.
+bool group_major_fits(size_t M, int W) {
+  const unsigned long long gs = (unsigned long long)M * 8ull;                       // floats between channel groups
+  return (SININN_HIDDEN / 8) * gs * 4ull + 64ull * (unsigned long long)W * 8ull * 4ull < (1ull << 32);
+}
 static bool group_major_hidden(const sininn_glow_args* a, const sininn_subnet* net) {
   const size_t M = (size_t)a->B * a->H * a->W;
-  return g_group_major && a->dtype == 0 && a->ksize == 3 && (net->winograd & 15) == 15 && M * 8 < (1u << 30) && wgrad_grouping_enabled();
+  return g_group_major && a->dtype == 0 && a->ksize == 3 && (net->winograd & 15) == 15 && group_major_fits(M, a->W) && wgrad_grouping_enabled();
 }
 
 struct Half {                 // one half-coupling in execution order

@@ -354,13 +354,15 @@ _AUX = {}
 # concurrency is what this architecture responds to).  SININN_IRN_HG=0 switches it off.
 import os as _os
 HG_OVERLAP = [_os.environ.get('SININN_IRN_HG', '1') != '0']
+HG_TRAIN = [_os.environ.get('SININN_IRN_HG_TRAIN', '0') == '1']     # diagnostic: the two-stream block in differentiated passes too (measured slower)
 
 
 def _aux_stream(device):
     """the helper stream that belongs to the CURRENT stream (each pass chain of a training step gets its own)"""
     key = (str(device), ops._stream_handle())
     if key not in _AUX:
-        _AUX[key] = torch.cuda.Stream(device=device)
+        from .modules import make_stream
+        _AUX[key] = make_stream(device, 0, f'IRN H-beside-G helper of stream {key[1]:#x}')
     return _AUX[key]
 
 
@@ -383,7 +385,7 @@ class InvBlockExp(nn.Module):
         # underfilled -- IRN inverse pass at batch 40: 7.43 -> 6.46 ms).  A training step already runs two pass chains and the
         # weight-gradient stream; H beside G on top of that measured slower (21.0 -> 23.4 ms: two more streams, the tail as a
         # kernel of its own), so training keeps the single-chain block with the tail fused into G's conv5.
-        if HG_OVERLAP[0] and x.is_cuda and not torch.is_grad_enabled():
+        if HG_OVERLAP[0] and x.is_cuda and (HG_TRAIN[0] or not torch.is_grad_enabled()):
             return self._apply_two_streams(x1, x2, rev)
         if not rev:
             y1 = self.F.run(x2, 'add', x1)                               # y1 = x1 + F(x2)

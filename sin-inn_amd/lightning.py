@@ -152,19 +152,99 @@ def _plain(v):
     return _DROP
 
 
+class _Foreign:
+    """Inert stand-in for a global that a checkpoint names and the restricted loader does not know (a Lightning callback class,
+    a logger, ...): constructing it, calling it or restoring state into it does nothing."""
+    _origin = '?'
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return self
+
+    def __setstate__(self, state):
+        pass
+
+
+def _is_foreign(v):
+    return isinstance(v, _Foreign) or (isinstance(v, type) and issubclass(v, _Foreign))
+
+
+def _strip_foreign(v):
+    """Drop dict entries / list items that are (or are keyed by) foreign stand-ins, recursively."""
+    if isinstance(v, dict):
+        return type(v)((k, _strip_foreign(x)) for k, x in v.items() if not _is_foreign(k) and not _is_foreign(x))
+    if isinstance(v, (list, tuple)):
+        return type(v)(_strip_foreign(x) for x in v if not _is_foreign(x))
+    return v
+
+
+class _StubbingPickle:
+    """``pickle_module`` for torch.load: tensors, containers, primitives and ``argparse.Namespace`` load as usual; EVERY other
+    global resolves to an inert ``_Foreign`` subclass instead of being imported, so nothing from the file can run and a
+    checkpoint written by the reference stack (pytorch_lightning 1.2 ``ModelCheckpoint`` stores ``callbacks: {<class>: state}``,
+    i.e. pickled class globals as dict keys) loads without pytorch_lightning being importable."""
+    __name__ = 'sin_inn_amd.lightning._StubbingPickle'
+    _ALLOWED = {('collections', 'OrderedDict'), ('argparse', 'Namespace'), ('torch', 'Size'), ('torch', 'device'),
+                ('torch._utils', '_rebuild_tensor'), ('torch._utils', '_rebuild_tensor_v2'),
+                ('torch._utils', '_rebuild_parameter'), ('torch._utils', '_rebuild_parameter_with_state'),
+                ('torch._tensor', '_rebuild_from_type_v2'), ('torch.nn.parameter', 'Parameter'), ('torch', 'Tensor'),
+                ('torch.storage', 'UntypedStorage'), ('torch.storage', 'TypedStorage'), ('torch.storage', '_load_from_bytes'),
+                ('numpy.core.multiarray', 'scalar'), ('numpy._core.multiarray', 'scalar'), ('numpy', 'dtype')}
+    foreign_seen = None
+
+    import pickle as _pickle
+
+    class Unpickler(_pickle.Unpickler):
+        def find_class(self, module, name):
+            if (module, name) in _StubbingPickle._ALLOWED:
+                return super().find_class(module, name)
+            if module == 'torch' and (name.endswith('Storage') or isinstance(getattr(torch, name, None), torch.dtype)):
+                return getattr(torch, name)
+            if _StubbingPickle.foreign_seen is not None:
+                _StubbingPickle.foreign_seen.add(f'{module}.{name}')
+            return type(name, (_Foreign,), {'_origin': f'{module}.{name}'})
+
+    @staticmethod
+    def load(f, **kw):
+        return _StubbingPickle.Unpickler(f, **kw).load()
+
+
 def load_checkpoint(path, map_location=None, trust=False):
     """torch.load for checkpoints of this trainer (tensors + primitives) and for Lightning checkpoints written by the
-    reference, which pickle an ``argparse.Namespace`` under 'hyper_parameters' (main.py:127).  Always the restricted
-    unpickler (``weights_only=True``) with exactly that one class allow-listed: a file that needs anything else is refused
-    with the unpickler's own message.  ``trust=True`` (CLI ``--trust_checkpoint``) is the explicit opt-in to the full
-    unpickler -- which can run arbitrary code from the file -- and logs a warning before it does."""
+    reference stack (main.py:127; pytorch_lightning 1.2: an ``argparse.Namespace`` under 'hyper_parameters' and
+    ``callbacks: {<class ModelCheckpoint>: state}``, whose keys are pickled class globals).  First torch's restricted
+    unpickler (``weights_only=True``) with ``argparse.Namespace`` allow-listed; a file it refuses is re-read with a loader that
+    resolves every unknown global to an inert stand-in (nothing from the file is imported or run) and drops the entries that
+    contained one -- so a genuine reference checkpoint resumes without pytorch_lightning installed.  ``trust=True`` (CLI
+    ``--trust_checkpoint``) is the explicit opt-in to the full unpickler -- which can run arbitrary code from the file."""
     import argparse
     import logging
+    import pickle
     if trust:
         logging.warning(f'{path}: loading with the FULL unpickler (--trust_checkpoint): code inside the file can run')
         return torch.load(path, map_location=map_location, weights_only=False)
-    with torch.serialization.safe_globals([argparse.Namespace]):
-        return torch.load(path, map_location=map_location, weights_only=True)
+    try:
+        with torch.serialization.safe_globals([argparse.Namespace]):
+            return torch.load(path, map_location=map_location, weights_only=True)
+    except pickle.UnpicklingError as first:
+        _StubbingPickle.foreign_seen = set()
+        try:
+            ck = torch.load(path, map_location=map_location, weights_only=False, pickle_module=_StubbingPickle)
+        except Exception as second:
+            raise pickle.UnpicklingError(
+                f'{path}: not loadable with the restricted unpickler ({first}) nor with foreign classes stubbed out ({second}). '
+                'If you trust the file, pass --trust_checkpoint (full unpickler: code inside the file can run; the packages it '
+                'names, e.g. pytorch_lightning, must be importable).') from second
+        finally:
+            seen, _StubbingPickle.foreign_seen = sorted(_StubbingPickle.foreign_seen), None
+        logging.warning(f'{path}: entries referring to classes that are not loaded here were dropped: ' + ', '.join(seen[:6]))
+        ck = _strip_foreign(ck)
+        if not isinstance(ck, dict) or 'state_dict' not in ck:
+            raise pickle.UnpicklingError(f'{path}: no state_dict left after dropping foreign entries; pass --trust_checkpoint '
+                                         'if you trust the file (and make the packages it names importable)')
+        return ck
 
 
 class Trainer:
@@ -199,6 +279,19 @@ class Trainer:
                     'optimizer_states': [self.optimizer.state_dict()], 'hyper_parameters': hp}, path)
 
     def fit(self, model, datamodule):
+        # this loop owns the process while it runs: let the model park long-lived objects outside the cyclic collector's reach
+        # (lit_wrapper._maybe_freeze_gc) and give them back when the loop ends
+        had = getattr(model, 'freeze_gc', None)
+        if had is not None:
+            model.freeze_gc = True
+        try:
+            return self._fit(model, datamodule)
+        finally:
+            if had is not None:
+                model.freeze_gc = had
+                getattr(model, 'unfreeze_gc', lambda: None)()
+
+    def _fit(self, model, datamodule):
         device = self._device()
         model.to(device)
         model.trainer = self

@@ -140,14 +140,18 @@ class _PackRegistry:
     def __init__(self):
         self.entries = []
         self.table = None
+        self.generation = 0          # bumped whenever a pack buffer is allocated or dropped: whatever baked pack ADDRESSES into
+                                     # something replayable (lit_wrapper's hipGraph cache) keys on it
 
     def add(self, entry):
         self.entries.append(entry)
         self.table = None
+        self.generation += 1
 
     def discard(self, entry):
         self.entries = [e for e in self.entries if e is not entry]
         self.table = None
+        self.generation += 1
 
     def refresh(self):
         # strong references for the duration of the call: a weakref can die between two derefs (the cyclic GC may run at
@@ -188,25 +192,52 @@ USE_SIDE_STREAM = [True]
 GATE_TAP = [None]       # parity tooling: set to a list -> every differentiable GLOW / DenseBlock forward appends its gates
 
 
-def make_stream(device, priority):
+HELPER_STREAMS = []      # (name, stream) of every stream this package creates: second pass chain, weight gradients, IRN helpers
+
+
+def make_stream(device, priority, name='helper'):
     """A HIP stream at `priority` (lower = higher priority).  torch.cuda.Stream covers {-1, 0}; anything else (a LOW-priority
-    stream, +1 on MI355X) is created through the library and wrapped."""
+    stream, +1 on MI355X) is created through the library and wrapped.  Every stream is registered (HELPER_STREAMS) so that a
+    stream capture can be checked for -- and closed over -- work that one of them still holds (join_capturing_helpers)."""
     if priority in (0, -1):
-        return torch.cuda.Stream(device=device, priority=priority)
-    least, greatest = C.c_int(0), C.c_int(0)
-    with torch.cuda.device(device):
-        _lib.check(_lib.lib().sininn_stream_priority_range(C.byref(least), C.byref(greatest)))
-        prio = max(min(priority, least.value), greatest.value)
-        handle = C.c_void_p()
-        _lib.check(_lib.lib().sininn_stream_create(prio, C.byref(handle)))
-    return torch.cuda.ExternalStream(handle.value, device=device)
+        st = torch.cuda.Stream(device=device, priority=priority)
+    else:
+        least, greatest = C.c_int(0), C.c_int(0)
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().sininn_stream_priority_range(C.byref(least), C.byref(greatest)))
+            prio = max(min(priority, least.value), greatest.value)
+            handle = C.c_void_p()
+            _lib.check(_lib.lib().sininn_stream_create(prio, C.byref(handle)))
+        st = torch.cuda.ExternalStream(handle.value, device=device)
+    HELPER_STREAMS.append((name, st))
+    return st
+
+
+def join_capturing_helpers():
+    """Inside a stream capture, right before it ends: every helper stream of this package that is part of the capture and still
+    holds work the capturing (current) stream does not depend on is joined into it (hipStreamEndCapture refuses -- and on ROCm
+    7.2 was seen to crash on -- a capture with an unjoined stream).  Returns the names of the streams that needed the join: the
+    pass code is supposed to join what it forks, so a non-empty list is a finding, not a routine."""
+    cur = torch.cuda.current_stream()
+    mine = [(n, s) for n, s in HELPER_STREAMS if s.device == cur.device and s.cuda_stream != cur.cuda_stream]
+    if not mine or not torch.cuda.is_current_stream_capturing():
+        return []
+    handles = (C.c_void_p * len(mine))(*[s.cuda_stream for _, s in mine])
+    flags = (C.c_int * len(mine))()
+    _lib.check(_lib.lib().sininn_capture_unjoined(C.c_void_p(cur.cuda_stream), handles, len(mine), flags))
+    loose = []
+    for (name, st), f in zip(mine, flags):
+        if f == 2:
+            cur.wait_stream(st)
+            loose.append(name)
+    return loose
 
 
 def _side_stream(device):
     key = str(device)
     if key not in _SIDE:
         import os
-        _SIDE[key] = make_stream(device, int(os.environ.get('SININN_WGRAD_PRIO', '0')))
+        _SIDE[key] = make_stream(device, int(os.environ.get('SININN_WGRAD_PRIO', '0')), 'weight-gradient stream')
     return _SIDE[key]
 
 
@@ -223,10 +254,13 @@ def join_side_streams():
 
 
 def _grad_buf(p):
-    """The tensor parameter gradients are accumulated into (created on first use, like autograd would)."""
+    """The tensor parameter gradients are accumulated into (created on first use, like autograd would).  Only the block
+    executors call this, and they issue every `+=` into it on the weight-gradient stream: the parameter is tagged so, which is
+    what lets the data-parallel all-reduce order itself behind that stream alone (FusedAdam.flat_grad_buffers)."""
     if p.grad is None:
         p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
     assert p.grad.is_contiguous()
+    p.__dict__['_sininn_executor_grad'] = True
     return p.grad
 
 

@@ -57,10 +57,21 @@ class FusedAdam(torch.optim.Optimizer):
         return [fl['g'] for fl in self._flat]
 
     def flat_grad_buffers(self):
-        """The flat gradient buffers WITHOUT joining the weight-gradient stream, and that stream (None if unused): for the
-        data-parallel all-reduce, which orders itself behind it (dist.allreduce_sum_(..., after=stream))."""
+        """The flat gradient buffers and the stream a collective over them has to be ordered behind.  That is the weight-gradient
+        stream ALONE (no join; dist.allreduce_sum_(..., after=stream)) only while EVERY parameter of the buffers is an
+        executor-owned conv parameter, i.e. all writes into the buffers are issued on that stream (modules._grad_buf tags them).
+        A model with any other trainable parameter -- a torch-native layer whose gradient autograd writes on the main or the
+        second pass stream -- gets (buffers, None) after a join of the streams: the collective is then ordered behind the
+        caller's stream, which has waited for everything."""
         from .modules import side_stream_if_any
-        return [fl['g'] for fl in self._flat], side_stream_if_any(self._flat[0]['g'].device)
+        bufs = [fl['g'] for fl in self._flat]
+        if not self.__dict__.get('_all_executor_owned', False):
+            self.__dict__['_all_executor_owned'] = all(p.__dict__.get('_sininn_executor_grad', False)
+                                                       for fl in self._flat for p in fl['params'])
+        if not self._all_executor_owned:
+            join_side_streams()
+            return bufs, None
+        return bufs, side_stream_if_any(bufs[0].device)
 
     def flat_params(self):
         return [fl['p'] for fl in self._flat]

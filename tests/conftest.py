@@ -23,3 +23,10 @@ def free_port():
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
         sk.bind(('127.0.0.1', 0))
         return sk.getsockname()[1]
+
+
+@pytest.fixture(scope='session')
+def golden_data():
+    """G8-G11: byte / index / flag arithmetic of the reference's prepare.py, data.py, main.py, tcr.py (make_golden_data.py)."""
+    import numpy as np
+    return np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_data.npz'))

@@ -391,6 +391,18 @@ def test_bayer_bin_bit_exact(env, scale, reduction):
     assert st.lr.shape == (3, 32 // (2 * scale), 48 // (2 * scale), 4)
 
 
+@pytest.mark.parametrize('reduction', ['mean', 'sum'])
+@pytest.mark.parametrize('scale', [1, 2, 4])
+def test_bayer_bin_matches_reference_fixture(env, golden_data, scale, reduction):
+    """Fixture G8: the bytes the reference's own datasets/prepare.py (extract_bayer + binning + quantisation, :35-82,164) produced
+    for these frames -- incl. saturated 'sum' blocks and near-black blocks whose truncation differs from rounding."""
+    from sin_inn_amd.functional import bayer_bin
+    frames = golden_data['g8_frames']
+    want = np.stack([golden_data[f'g8_lr_u8_{t}_{reduction}_{scale}'] for t in range(len(frames))])
+    got = bayer_bin(torch.from_numpy(frames).cuda(), scale, reduction)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize('cin,n,hw', [(24, 256, (16, 32)), (256, 96, (12, 20)), (48, 256, (9, 17)), (8, 24, (5, 7)),
                                       (256, 48, (16, 16)), (192, 256, (40, 24)), (64, 128, (19, 33))])
 @pytest.mark.parametrize('cg', [1, 2, 5, 9])    # 32- / 64-column blocks; +4 never / +8 always the 32x32x2 kernel

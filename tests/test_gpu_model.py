@@ -1,6 +1,7 @@
 """GPU parity of the composed path: GLOW block (fwd / inverse / log-det / gradients), the lowered SRF network,
 one full training step (losses, gradients, fused Adam) against the CPU oracle, plus size-independent properties
 at BASELINE config-2 size (256x256, bs 16)."""
+import math
 import types
 
 import pytest
@@ -458,6 +459,152 @@ def test_graph_replay_equals_eager_bitwise(arch, precision):
     assert torch.equal(p_eager, p_graph)
     for a, b in zip(l_eager, l_graph):
         assert abs(a - b) <= 1e-5 * abs(a)             # the loss scalar is reduced with float atomics
+
+
+def test_graph_cache_is_keyed_on_what_a_capture_bakes_in():
+    """loss weights, frozen parameters and pack-buffer addresses are baked into a captured step.  Changing a loss
+    weight (a term appears) or re-homing the weights (new pack buffers) after a capture must not replay the stale graph: the
+    graph run stays bitwise equal to the eager run across both changes."""
+    import lit_wrapper
+    from data import FrameStore
+    from sin_inn_amd.functional import sample_windows
+    from sin_inn_amd.modules import _PACK_REGISTRY
+
+    def run(graph):
+        torch.manual_seed(5)
+        opt = make_opt(num_coupling=1, lr_window=2, architecture='SRF', hip_graph=graph)
+        model = lit_wrapper.SingleVideoINN(3, 32, 32, opt).cuda()
+        optim = model.attach_optimizer()
+        store = FrameStore.synthetic(12, 32, 32).to('cuda')
+        g = torch.Generator().manual_seed(7)
+        zbuf = torch.empty(4, 4, 4, opt.z_dims, device='cuda').permute(0, 3, 1, 2)
+        real = lit_wrapper._latent
+        lit_wrapper._latent = lambda b, zd, h, w, device, temp=1.0: zbuf
+        captures = []
+        try:
+            for i in range(16):
+                if i == 6:
+                    model.opt.lambda_latent_nll = 0.5                                   # a new term in the forward loss
+                if i == 11:                                                             # new pack buffers: drop every cached pack
+                    for blk in model.inn.modules():
+                        if hasattr(blk, '_packs') and hasattr(blk._packs, 'store'):
+                            for e in list(blk._packs.store.values()):
+                                _PACK_REGISTRY.discard(e)
+                            blk._packs.store.clear()
+                            blk.__dict__.pop('_subargs', None)
+                idx = torch.randint(2, 10, (4,), generator=g).cuda()
+                hr, lr = sample_windows(store.hr, store.lr, idx, 2)
+                zbuf.copy_(torch.randn(4, 4, 4, opt.z_dims, generator=g).cuda().permute(0, 3, 1, 2))
+                model.training_step([{'hr': hr, 'lr': lr}, {'hr': hr, 'lr': lr}], 0)
+                captures.append(sum('graph' in v for v in model.__dict__.get('_graphs', {}).values()))
+        finally:
+            lit_wrapper._latent = real
+        torch.cuda.synchronize()
+        return optim.flat_params()[0].clone(), captures
+
+    p_eager, _ = run(False)
+    p_graph, captures = run(True)
+    assert captures[5] == 1 and captures[6] == 1 and captures[10] >= 2, captures     # replaying, then a second capture for the new weights
+    assert captures[11] == 0 and captures[15] == 1, captures                         # stale graphs dropped with the packs, captured again
+    assert torch.equal(p_eager, p_graph)
+
+
+def test_graph_replay_draws_a_fresh_latent_every_step():
+    """The real _latent (torch.randn INSIDE the capture; the other graph tests feed a static buffer): every replay must see new
+    noise -- the philox offset is advanced per replay -- so the reverse-pass loss changes from replay to replay on a FIXED batch
+    and has the spread eager steps on that batch have."""
+    import lit_wrapper
+    from data import FrameStore
+    from sin_inn_amd.functional import sample_windows
+
+    def run(graph):
+        torch.manual_seed(5)
+        torch.cuda.manual_seed(11)
+        opt = make_opt(num_coupling=1, lr_window=2, architecture='SRF', hip_graph=graph)
+        opt.learning_rate = 0.0                         # frozen weights: the loss varies with z only
+        model = lit_wrapper.SingleVideoINN(3, 32, 32, opt).cuda()
+        model.attach_optimizer()
+        store = FrameStore.synthetic(12, 32, 32).to('cuda')
+        hr, lr = sample_windows(store.hr, store.lr, torch.tensor([3, 4, 5, 6], device='cuda', dtype=torch.int32), 2)
+        losses = []
+        for _ in range(14):
+            model.training_step([{'hr': hr, 'lr': lr}, {'hr': hr, 'lr': lr}], 0)
+            losses.append(float(model._logged['train']))
+        return torch.tensor(losses[4:], dtype=torch.float64), any('graph' in v for v in model.__dict__.get('_graphs', {}).values())
+
+    eager, cap_e = run(False)
+    replay, cap_g = run(True)
+    assert cap_g and not cap_e
+    assert len(set(replay.tolist())) == len(replay), 'a replay re-used the latent of the capture'
+    assert abs(float(replay.mean() - eager.mean())) < 4 * float(eager.std()) and 0.25 < float(replay.std() / eager.std()) < 4
+
+
+def test_irn_passes_under_stream_capture_leave_nothing_unjoined():
+    """The capture_end abort of round 3: a stream capture must end with every helper stream joined.  (a) a no-grad
+    IRN inverse pass -- H beside G on a helper stream -- inside a caller's capture: the block joins what it forks (checked on the
+    graph under construction), the replay reproduces the eager output bitwise; (b) a captured IRN training step reports no
+    stream that needed the catch-all join."""
+    import lit_wrapper
+    from data import FrameStore
+    from sin_inn_amd import irn
+    from sin_inn_amd.functional import sample_windows
+    from sin_inn_amd.modules import join_capturing_helpers
+    assert irn.HG_OVERLAP[0]
+    torch.manual_seed(5)
+    opt = make_opt(num_coupling=2, lr_window=2, architecture='IRN', hip_graph=True)
+    model = lit_wrapper.SingleVideoINN(3, 64, 64, opt).cuda()
+    for m in model.inn.modules():                      # IRN is the identity at init (conv5 == 0): make it a network
+        if isinstance(m, irn.DenseBlock):
+            torch.nn.init.normal_(m.conv5.weight, std=0.02)
+    model.attach_optimizer()
+    lr_z = torch.randn(4, 8, 8, 192, device='cuda').permute(0, 3, 1, 2)
+    with torch.no_grad():
+        eager = model.inn(lr_z, rev=True).clone()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode='relaxed'):
+        with torch.no_grad():
+            out = model.inn(lr_z, rev=True)
+        loose = join_capturing_helpers()
+    assert loose == [], loose
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    store = FrameStore.synthetic(12, 64, 64).to('cuda')
+    gen = torch.Generator().manual_seed(7)
+    for _ in range(6):
+        idx = torch.randint(2, 10, (4,), generator=gen).cuda()
+        hr, lr = sample_windows(store.hr, store.lr, idx, 2)
+        model.training_step([{'hr': hr, 'lr': lr}, {'hr': hr, 'lr': lr}], 0)
+    torch.cuda.synchronize()
+    assert any('graph' in v for v in model.__dict__.get('_graphs', {}).values())
+    assert model.__dict__.get('_capture_loose') is None and math.isfinite(float(model._logged['train']))
+
+
+def test_allreduce_is_ordered_behind_the_weight_gradient_stream_only_for_executor_owned_parameters():
+    """FusedAdam.flat_grad_buffers hands the data-parallel all-reduce the weight-gradient stream to order itself
+    behind ONLY while every flat parameter's gradient is written by a block executor (on that stream).  A model with any other
+    trainable parameter gets no stream (the collective then runs behind the caller's stream, which has joined everything)."""
+    import lit_wrapper
+    from data import FrameStore
+    from sin_inn_amd import FusedAdam
+    from sin_inn_amd.functional import sample_windows
+    from sin_inn_amd.modules import side_stream_if_any
+    torch.manual_seed(5)
+    opt = make_opt(num_coupling=1, lr_window=2)
+    model = lit_wrapper.SingleVideoINN(3, 32, 32, opt).cuda()
+    optim = model.attach_optimizer()
+    store = FrameStore.synthetic(12, 32, 32).to('cuda')
+    hr, lr = sample_windows(store.hr, store.lr, torch.tensor([3, 4], device='cuda', dtype=torch.int32), 2)
+    assert optim.flat_grad_buffers()[1] is None        # before any backward nothing is known to be executor-owned: safe order
+    model.training_step([{'hr': hr, 'lr': lr}, {'hr': hr, 'lr': lr}], 0)
+    bufs, stream = optim.flat_grad_buffers()
+    assert stream is not None and stream is side_stream_if_any(hr.device)
+    extra = torch.nn.Linear(4, 4).cuda()               # a torch-native layer: autograd writes its gradient on the caller's stream
+    mixed = FusedAdam(list(model.inn.parameters()) + list(extra.parameters()), lr=1e-4)
+    extra(torch.randn(2, 4, device='cuda')).sum().backward()
+    assert mixed.flat_grad_buffers()[1] is None
 
 
 def test_training_steps_run_ahead_is_bounded():

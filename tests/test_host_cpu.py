@@ -210,13 +210,60 @@ def test_checkpoint_holds_tensors_and_primitives_only(tmp_path):
     ref_path = str(tmp_path / 'ref.ckpt')
     torch.save({'state_dict': m.state_dict(), 'hyper_parameters': {'opt': argparse.Namespace(scale=4)}, 'epoch': 1}, ref_path)
     assert pl.load_checkpoint(ref_path)['hyper_parameters']['opt'].scale == 4
-    # anything beyond tensors / primitives / argparse.Namespace is refused unless the caller opts in explicitly
+    # anything beyond tensors / primitives / argparse.Namespace is never imported or run: the entry that holds it is dropped
+    # (unless the caller opts in to the full unpickler explicitly)
+    other = str(tmp_path / 'other.ckpt')
+    torch.save({'state_dict': m.state_dict(), 'hyper_parameters': {'opt': types.SimpleNamespace(scale=4), 'c': 3}}, other)
+    ck = pl.load_checkpoint(other)
+    assert ck['hyper_parameters'] == {'c': 3} and set(ck['state_dict']) == {'lin.weight', 'lin.bias'}
+    assert pl.load_checkpoint(other, trust=True)['hyper_parameters']['opt'].scale == 4
+
+
+def test_reference_style_lightning_checkpoint_loads_without_lightning(tmp_path):
+    """pytorch_lightning 1.2's ModelCheckpoint stores `callbacks: {<class ModelCheckpoint>: state}` -- dict keys that
+    are pickled class globals of a package that is not installed here.  The file must still resume (the entry is dropped,
+    nothing from the file is imported or executed); a file with no usable state_dict says --trust_checkpoint."""
+    import argparse
     import pickle
-    evil = str(tmp_path / 'evil.ckpt')
-    torch.save({'state_dict': m.state_dict(), 'hyper_parameters': {'opt': types.SimpleNamespace(scale=4)}}, evil)
-    with pytest.raises(pickle.UnpicklingError):
-        pl.load_checkpoint(evil)
-    assert pl.load_checkpoint(evil, trust=True)['hyper_parameters']['opt'].scale == 4
+    from sin_inn_amd import lightning as pl
+    mod = types.ModuleType('fake_lightning_callbacks')
+
+    class ModelCheckpoint:
+        pass
+    ModelCheckpoint.__module__, ModelCheckpoint.__qualname__ = mod.__name__, 'ModelCheckpoint'
+    mod.ModelCheckpoint = ModelCheckpoint
+    sys.modules[mod.__name__] = mod
+    sd = {'inn.w': torch.arange(6.0).reshape(2, 3), 'inn.b': torch.ones(2)}
+    path = str(tmp_path / 'epoch=99.ckpt')
+    try:
+        torch.save({'epoch': 99, 'global_step': 1234, 'pytorch-lightning_version': '1.2.0', 'state_dict': sd,
+                    'callbacks': {ModelCheckpoint: {'best_model_score': torch.tensor(0.5), 'best_model_path': 'x.ckpt'}},
+                    'optimizer_states': [{'state': {0: {'step': 7, 'exp_avg': torch.zeros(3)}}, 'param_groups': [{'lr': 1e-4}]}],
+                    'lr_schedulers': [], 'hyper_parameters': {'c': 3, 'opt': argparse.Namespace(scale=4, fps=10)}}, path)
+    finally:
+        del sys.modules[mod.__name__]                 # as on a box without pytorch_lightning: the global cannot be imported
+    with pytest.raises(Exception):
+        torch.load(path, weights_only=False)          # the plain unpickler needs the package
+    ck = pl.load_checkpoint(path)
+    assert ck['epoch'] == 99 and ck['global_step'] == 1234 and ck['callbacks'] == {}
+    assert torch.equal(ck['state_dict']['inn.w'], sd['inn.w']) and ck['hyper_parameters']['opt'].fps == 10
+    assert ck['optimizer_states'][0]['state'][0]['step'] == 7
+    # code in a file is never run by the default path: a reduce that would call os.system resolves to an inert stand-in
+    marker = tmp_path / 'ran'
+
+    class Boom:
+        def __reduce__(self):
+            return (os.system, (f'touch {marker}',))
+    bad = str(tmp_path / 'bad.ckpt')
+    torch.save({'state_dict': sd, 'payload': Boom()}, bad)
+    ck = pl.load_checkpoint(bad)
+    assert not marker.exists() and 'payload' not in ck and set(ck['state_dict']) == set(sd)
+    # nothing usable left -> the error names the opt-in
+    empty = str(tmp_path / 'empty.ckpt')
+    torch.save({'state_dict': Boom()}, empty)
+    with pytest.raises(pickle.UnpicklingError, match='--trust_checkpoint'):
+        pl.load_checkpoint(empty)
+    assert not marker.exists()
 
 
 def test_test_mode_loads_strictly_and_tolerates_only_freia_bookkeeping():
@@ -347,6 +394,29 @@ def test_32_bit_staging_offsets_are_range_checked_on_the_host():
     a.inp, a.w, a.out = fake, fake, fake
     rc = lib.sininn_conv(C.byref(a), None)
     assert rc != 0 and b'exceeds the 2 GB' in lib.sininn_last_error(), lib.sininn_last_error()
+
+
+def test_group_major_layout_is_chosen_only_where_the_kernels_can_address_it():
+    """the executor's layout predicate must imply the kernels' own range checks -- a shape beyond them takes the
+    row-major hidden layout instead of failing in sininn_conv with 'channel-group stride too large' (host-only, no launch)."""
+    import ctypes as C
+    import sin_inn_amd
+    from sin_inn_amd import _lib
+    lib = _lib.lib()
+    fake = 0x7f0000000000
+    assert lib.sininn_glow_group_major_fits(16, 64, 64) == 1 and lib.sininn_glow_group_major_fits(16, 180, 320) == 1   # cfg 1 / 4
+    assert lib.sininn_glow_group_major_fits(16, 512, 512) == 0 and lib.sininn_glow_group_major_fits(16, 1024, 1024) == 0
+
+    def conv_refuses_stride(b, h, w):
+        a = _lib.ConvArgs(B=b, H=h, W=w, ksize=3, Cin=256, in_stride=8, Np=64, N=64, out_stride=64, winograd=1, mode=_lib.CONV_LINEAR)
+        a.in_group_stride = b * h * w * 8 if b * h * w * 8 < 2 ** 31 else 2 ** 31 - 8
+        a.inp, a.w, a.out = fake, fake, fake
+        rc = lib.sininn_conv(C.byref(a), None)
+        return rc != 0 and b'group stride too large' in lib.sininn_last_error()
+    for b, h, w in ((16, 64, 64), (16, 256, 256), (15, 512, 512), (16, 511, 512), (16, 512, 512), (3, 1200, 1160), (1, 2040, 2040)):
+        fits = lib.sininn_glow_group_major_fits(b, h, w) == 1
+        assert not (fits and conv_refuses_stride(b, h, w)), (b, h, w)       # chosen => addressable
+    assert conv_refuses_stride(16, 512, 512)                                # the check the predicate has to stay inside
 
 
 def test_frame_store_refuses_a_clip_that_does_not_start_at_frame_0(tmp_path):
