@@ -385,7 +385,13 @@ class InvBlockExp(nn.Module):
         # underfilled -- IRN inverse pass at batch 40: 7.43 -> 6.46 ms).  A training step already runs two pass chains and the
         # weight-gradient stream; H beside G on top of that measured slower (21.0 -> 23.4 ms: two more streams, the tail as a
         # kernel of its own), so training keeps the single-chain block with the tail fused into G's conv5.
-        if HG_OVERLAP[0] and x.is_cuda and (HG_TRAIN[0] or not torch.is_grad_enabled()):
+        # Never inside a stream capture: the fork / join below makes the helper stream wait for this stream AND this stream wait
+        # for the helper; when this stream is not the capture's origin (the second pass chain of a captured training step, any
+        # stream a caller forked), the HIP runtime bundled with torch 2.10+rocm7.0 links the two streams into each other's
+        # parallelCaptureStreams_ and hip::Stream::EndCapture() recurses over that 2-cycle until the stack overflows -- the
+        # capture_end abort of round 3 (tools/capture_diag.py dumps the lists, tools/capture_topology.hip reproduces it).
+        if HG_OVERLAP[0] and x.is_cuda and (HG_TRAIN[0] or not torch.is_grad_enabled()) and \
+                (HG_TRAIN[0] or not torch.cuda.is_current_stream_capturing()):
             return self._apply_two_streams(x1, x2, rev)
         if not rev:
             y1 = self.F.run(x2, 'add', x1)                               # y1 = x1 + F(x2)
