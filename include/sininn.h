@@ -183,6 +183,21 @@ int sininn_conv(const sininn_conv_args* args, void* stream);
 int sininn_conv_pair_k1_supported(const sininn_conv_args* first, const sininn_conv_args* second);
 int sininn_conv_pair_k1(const sininn_conv_args* first, const sininn_conv_args* second, void* stream);
 
+/* The whole BACKWARD of a fp32 1x1 conv subnet of a GLOW half-coupling in one persistent launch + one slab reduce (round 4;
+ * subnet_conv_1x1, archs.py:15-17, differentiated inside FrEIA's GLOWCouplingBlock, archs.py:56-64):
+ *   h = relu(x W1^T + b1) is RECOMPUTED from the subnet's input (the forward pass need not store it: pass first->out == NULL to
+ *   sininn_conv_pair_k1), dh = (dr W2) . [h > 0] never leaves the chip, dx = dh W1 goes through d1's epilogue (ADD / ADD_CBWD_*),
+ *   and gw2 / gb2 / gw1 / gb1 (OIHW, +=; any of them may be NULL) are summed from per-block slabs in a fixed order.
+ * recompute: {in = x, in_stride, Cin, w = forward pack of conv1 [256][Cin], bias, Np = 256, B, H, W, ksize = 1}; d2 / d1: the two
+ * data-gradient convs exactly as for sininn_conv_pair_k1 (d2: in = dr [.. 2 Co], w = data-gradient pack of conv2; d1: Cin = 256,
+ * w = data-gradient pack of conv1, Np = pad16(Cin of conv1), the epilogue fields); d2->mask / d2->out / d1->in are ignored.
+ * Shapes served: (Cin of conv1, 2 Co) in {(8, 16), (16, 32), (24, 48)} -- sininn_conv_sub1_bwd_workspace_bytes returns 0 for any
+ * other.  dx / the fused coupling backward are bitwise what sininn_conv_pair_k1(d2, d1) produces from the stored h; the weight
+ * gradients agree with sininn_wgrad up to fp32 summation order.  no_dx != 0: the data gradient of conv1 is not needed. */
+size_t sininn_conv_sub1_bwd_workspace_bytes(int cin, int co);
+int sininn_conv_sub1_bwd(const sininn_conv_args* recompute, const sininn_conv_args* d2, const sininn_conv_args* d1, int no_dx,
+                         float* gw2, float* gb2, float* gw1, float* gb1, void* workspace, size_t workspace_bytes, void* stream);
+
 /* The 3x3 twin for passes that keep nothing for a backward (ABI v4): the WHOLE 3x3 conv subnet (subnet_conv, archs.py:11-13) +
  * affine coupling + log-det of a GLOW half-coupling (archs.py:56-64) in one launch on the mixed-precision path.  `first`:
  * ksize 3, bf16 weights, fp32 input, mode RELU, 256 output channels, out == NULL (the hidden tile lives in LDS only);

@@ -125,6 +125,7 @@ _SIGS = {
     'sininn_conv_test_hooks': (None, [C.c_int, C.c_int]),
     'sininn_wgrad_test_hooks': (None, [C.c_int]),
     'sininn_pair_k1_test_hook': (None, [C.c_int]),
+    'sininn_sub1_bwd_test_hook': (None, [C.c_int]),
     'sininn_wgrad_workspace_bytes': (C.c_size_t, [C.c_int] * 6),
     'sininn_wgrad': (C.c_int, [c_f, C.c_int, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                c_f, c_f, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -150,6 +151,9 @@ _SIGS = {
     'sininn_conv_sub3_supported': (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs)]),
     'sininn_conv_sub3': (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs), C.c_void_p]),
     'sininn_conv_pair_k1': (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs), C.c_void_p]),
+    'sininn_conv_sub1_bwd_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int]),
+    'sininn_conv_sub1_bwd': (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs), C.POINTER(ConvArgs), C.c_int, c_f, c_f, c_f, c_f,
+                                       C.c_void_p, C.c_size_t, C.c_void_p]),
     'sininn_dense_workspace_bytes': (C.c_size_t, [C.c_int] * 5),
     'sininn_dense_forward': (C.c_int, [C.POINTER(DenseArgs), C.c_void_p]),
     'sininn_dense_backward': (C.c_int, [C.POINTER(DenseArgs), C.c_void_p, C.c_void_p]),

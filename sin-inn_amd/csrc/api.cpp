@@ -20,6 +20,11 @@ void set_error(const char* fmt, ...) {
 
 int conv_launch(const sininn_conv_args* a, hipStream_t st);
 int conv_pair_k1_supported(const sininn_conv_args* f, const sininn_conv_args* s);
+size_t conv_sub1_bwd_workspace_bytes(int cond_cin, int co);
+int conv_sub1_bwd_launch(const sininn_conv_args* rc, const sininn_conv_args* d2, const sininn_conv_args* d1, int no_dx, void* ws,
+                         size_t ws_bytes, int* slabs_out, hipStream_t st);
+int conv_sub1_bwd_reduce(int cond_cin, int co, const void* ws, int slabs, float* gw2, float* gb2, float* gw1, float* gb1, hipStream_t st);
+void conv_sub1_bwd_enable(int on);
 int conv_pair_k1_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st);
 void conv_pair_k1_enable(int on);
 int conv_sub3_bf16_supported(const sininn_conv_args* f, const sininn_conv_args* s);
@@ -292,6 +297,17 @@ int sininn_conv_pair_k1_supported(const sininn_conv_args* first, const sininn_co
 int sininn_conv_pair_k1(const sininn_conv_args* first, const sininn_conv_args* second, void* stream) {
   return conv_pair_k1_launch(first, second, ST(stream));
 }
+
+size_t sininn_conv_sub1_bwd_workspace_bytes(int cin, int co) { return conv_sub1_bwd_workspace_bytes(cin, co); }
+int sininn_conv_sub1_bwd(const sininn_conv_args* recompute, const sininn_conv_args* d2, const sininn_conv_args* d1, int no_dx,
+                         float* gw2, float* gb2, float* gw1, float* gb1, void* workspace, size_t workspace_bytes, void* stream) {
+  int slabs = 0;
+  if (int rc = conv_sub1_bwd_launch(recompute, d2, d1, no_dx, workspace, workspace_bytes, &slabs, ST(stream))) return rc;
+  if (!gw2 && !gb2 && !gw1 && !gb1) return 0;
+  return conv_sub1_bwd_reduce(recompute->Cin, d2->Cin / 2, workspace, slabs, gw2, gb2, gw1, gb1, ST(stream));
+}
+// test hook: the block executor's fused 1x1 subnet backward on / off (A/B against the pair + grouped weight-gradient path)
+void sininn_sub1_bwd_test_hook(int on) { conv_sub1_bwd_enable(on); }
 
 /* test hook (not part of the documented surface): force tile configuration / channel chunk */
 void sininn_conv_test_hooks(int force_cfg, int force_ck) { conv_set_test_hooks(force_cfg, force_ck); }

@@ -1,0 +1,475 @@
+// The whole backward pass of a 1x1 conv subnet of a GLOW half-coupling in ONE persistent launch (reference: subnet_conv_1x1,
+// archs.py:15-17, differentiated inside FrEIA's GLOWCouplingBlock, archs.py:56-64):
+//     h   = relu(x W1^T + b1)                   recomputed from the subnet's input x -- the forward pass did not store it
+//     dW2 += h^T dr      db2 += sum_p dr        weight / bias gradient of conv2
+//     dh  = (dr W2) . [h > 0]                   data gradient of conv2 with the ReLU mask, never leaves the chip
+//     dx  = dh W1  (+ skip gradient / + fused coupling backward of the other half: the shared epilogue)
+//     dW1 += dh^T x      db1 += sum_p dh        weight / bias gradient of conv1
+// The five-launch path it replaces (fused data-gradient pair + grouped weight-gradient kernel + slab reduce, with the forward
+// pass storing h) moves the 256-channel hidden tensors through HBM five times per half-coupling -- h written by the forward
+// pass, re-read as the ReLU mask and by conv2's weight gradient, dh written and re-read by conv1's weight gradient: 335 MB at
+// BASELINE configs[1], level 0, against 31 MB of x / dr / dx -- and its 1x1 classes sat at 0.17 - 0.32 of the f32 matrix pipe.
+//
+// Block = 256 threads, persistent over 32-pixel tiles (2 x 16 pixels).  Per tile, on v_mfma_f32_16x16x4_f32:
+//   stage 0  x tile [32][K1] and dr tile [32][K2] -> LDS (raw buffer loads, zero fill outside the image)
+//   stage R  h  = relu(x W1^T + b1): wave w owns hidden columns [64 w, 64 w + 64) -- the SAME k order and accumulator split as
+//            stage 1 of conv_pair_k1_kernel, so the recomputed h is bitwise the h the forward pass used
+//   stage W2 dW2[n][c] += sum_p dr[p][n] h[p][c]: rows = the wave's 64 hidden channels, one 16-byte LDS read per lane supplies the
+//            A operands of four row tiles (row i of tile t <-> channel 64 w + 4 i + t), k = 4 pixels per MFMA; accumulators stay
+//            in registers for the lifetime of the block
+//   stage 2  dh = (dr W2) . [h > 0] written IN PLACE over h (an element's mask is the element it overwrites, and a wave only ever
+//            touches its own 64 columns of the tile in stages R / W2 / 2: no block barrier between them)
+//   stage 3  dx tile = dh W1 (K = 256; W1's data-gradient pack lives in LDS for the lifetime of the block) -> the shared epilogue
+//            (conv_epilogue_tile: ADD / ADD_CBWD_*), identical arithmetic to stage 2 of conv_pair_k1_kernel
+//   stage W1 dW1[n][c] += sum_p dh[p][n] x[p][c]; the x tile carries a column of ones behind its K1 channels, so db1 falls out of
+//            the same MFMAs
+// At the end a block writes its partial gradients as ONE slab; sub1_reduce_kernel sums the slabs in a fixed order into the OIHW
+// gradients (bitwise reproducible, no float atomics) -- on the weight-gradient stream, like every other += into a gradient.
+#include <cstdlib>
+#include "conv_mfma_impl.h"
+
+namespace sininn {
+
+int conv_prepare(const sininn_conv_args* a, ConvDev& d);
+
+constexpr int S1_HID = 256;            // hidden channels (SININN_HIDDEN)
+constexpr int S1_HS = S1_HID + 4;      // floats per pixel row of the hidden tile in LDS
+constexpr int S1_P = 32;               // pixels per tile (2 x 16)
+constexpr int S1_MAX_BLOCKS = 512;     // persistent blocks == slabs (two per CU)
+
+struct Sub1Dev {
+  ConvDev r;        // recompute: in = x (the subnet's input), w = W1 forward pack [256][K1], bias = b1
+  ConvDev a;        // data gradient of conv2: in = dr [.. K2], w = W2 data-gradient pack [256][K2]
+  ConvDev b;        // data gradient of conv1: w = W1 data-gradient pack [pad16(K1)][256] + the epilogue descriptor
+  float* slab;      // [blocks][slab_floats]
+  int ntiles, no_dx;
+};
+
+template <int K1, int K2>
+struct Sub1Shape {
+  static constexpr int K1R = (K1 + 15) / 16 * 16;          // stage R walks K in steps of 16
+  static constexpr int NU1 = (K1 + 16) / 16;               // 16-column tiles of [x | 1] (weight gradient of conv1 + db1)
+  static constexpr int XD = K1R > 16 * NU1 ? K1R : 16 * NU1;
+  static constexpr int XS = XD + 4;                         // floats per pixel row of the x tile
+  static constexpr int DS = K2 + 4;                         // ... of the dr tile
+  static constexpr int NU2 = K2 / 16;
+  static constexpr int NP1 = K1R;                           // columns of the data gradient of conv1 (pad16)
+  static constexpr int NT2 = NP1 / 16;
+  static constexpr int W1S = 16 * NU1;                      // slab row of dW1: [K1 channels | db1 | zero pad]
+  static constexpr int SLAB = K2 * S1_HID + S1_HID * W1S + 64;   // dW2 [K2][256] | dW1 [256][W1S] | db2 [64]
+  static constexpr size_t LDS = (size_t)(S1_P * S1_HS + S1_P * DS + S1_P * XS + NP1 * S1_HS) * sizeof(float);
+};
+
+template <int K1, int K2>
+__global__ __launch_bounds__(256, 2) void conv_sub1_bwd_kernel(Sub1Dev q) {
+  using SH = Sub1Shape<K1, K2>;
+  constexpr int P = S1_P, MT = 2, HS = S1_HS, DS = SH::DS, XS = SH::XS, NU1 = SH::NU1, NU2 = SH::NU2, NP1 = SH::NP1, NT2 = SH::NT2;
+  constexpr int NS1 = SH::K1R / 16, NS2 = K2 / 16;
+  static_assert(K1 % 8 == 0 && K1 <= 24 && K2 % 16 == 0 && K2 <= 48, "conv_sub1_bwd: shape");
+  const ConvDev& pr = q.r;
+  const ConvDev& pa = q.a;
+  const ConvDev& pb = q.b;
+  extern __shared__ __attribute__((aligned(16))) float smem_sub1[];
+  float* const hs = smem_sub1;                      // [P][HS]: h, then dh; later T[P][NP1 + 4]
+  float* const drs = hs + P * HS;                   // [P][DS]
+  float* const xs = drs + P * DS;                   // [P][XS]: x | 1 | 0...
+  float* const wd = xs + P * XS;                    // [NP1][HS]: W1 data-gradient pack
+  __shared__ float red[4];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, kq = lane >> 4;
+  const int cw = wave * 64;                         // this wave's hidden columns
+
+  // ---- once per block: W1's data-gradient pack -> LDS ----------------------------------------------------------------------
+  if (!q.no_dx) {
+    for (int f = tid; f < NP1 * (S1_HID / 4); f += 256) {
+      const int n = f / (S1_HID / 4), c = (f - n * (S1_HID / 4)) * 4;
+      *reinterpret_cast<f32x4*>(wd + n * HS + c) = *reinterpret_cast<const f32x4*>(pb.w + (size_t)n * S1_HID + c);
+    }
+  }
+  f32x4 b1q;                                        // bias of the wave's columns cw + 16 n + li
+#pragma unroll
+  for (int n = 0; n < 4; ++n) b1q[n] = pr.bias ? pr.bias[cw + 16 * n + li] : 0.f;
+
+  // weight fragments straight from L2 (every block reads the same few KB), as in conv_pair_k1_kernel
+  const __amdgpu_buffer_rsrc_t w1_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.w), 0, S1_HID * K1 * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w2_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pa.w), 0, S1_HID * K2 * 4, 0x00020000);
+  unsigned woff1[4], woff2[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    woff1[n] = (unsigned)(((cw + n * 16 + li) * K1 + 4 * kq) * 4);
+    woff2[n] = (unsigned)(((cw + n * 16 + li) * K2 + 4 * kq) * 4);
+  }
+
+  // ---- gradient accumulators of the block (registers) ----------------------------------------------------------------------
+  f32x4 accW2[4][NU2], accW1[4][NU1];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int u = 0; u < NU2; ++u) accW2[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NU1; ++u) accW1[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  float accb2 = 0.f;
+
+  const int tiles_img = pr.tiles_x * pr.tiles_y;
+  for (int tile = blockIdx.x; tile < q.ntiles; tile += gridDim.x) {
+    const int b = tile / tiles_img;
+    const int trem = tile - b * tiles_img;
+    const int ty = trem / pr.tiles_x, tx = trem - ty * pr.tiles_x;
+    const int y0 = ty * 2, x0 = tx * 16;
+
+    // W1 fragments of stage R are requested before the tile is staged (they depend on nothing of it)
+    f32x4 bf1[NS1][4];
+#pragma unroll
+    for (int s = 0; s < NS1; ++s) {
+      const bool live = 16 * s + 4 * kq < K1;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) bf1[s][n] = buf_load4(w1_rs, live ? woff1[n] : BUF_OOB, (unsigned)(64 * s));
+    }
+
+    // ---- stage 0: x tile and dr tile -> LDS -----------------------------------------------------------------------------
+    {
+      const size_t img = (size_t)b * pr.H * pr.W;
+      const __amdgpu_buffer_rsrc_t x_rs = buf_rsrc(pr.in + img * pr.in_stride);
+      const __amdgpu_buffer_rsrc_t d_rs = buf_rsrc(pa.in + img * pa.in_stride);
+      constexpr int QX = K1 / 4, QD = K2 / 4;
+      constexpr int FX = (P * QX + 255) / 256, FD = (P * QD + 255) / 256;
+      f32x4 vx[FX], vd[FD];
+#pragma unroll
+      for (int u = 0; u < FX; ++u) {
+        const int f = tid + 256 * u;
+        const int pl = f / QX, c = (f - pl * QX) * 4;
+        const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+        const unsigned off = (f < P * QX && gy < pr.H && gx < pr.W) ? (unsigned)(((gy * pr.W + gx) * pr.in_stride + c) * 4) : BUF_OOB;
+        vx[u] = buf_load4(x_rs, off, 0u);
+      }
+#pragma unroll
+      for (int u = 0; u < FD; ++u) {
+        const int f = tid + 256 * u;
+        const int pl = f / QD, c = (f - pl * QD) * 4;
+        const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+        const unsigned off = (f < P * QD && gy < pa.H && gx < pa.W) ? (unsigned)(((gy * pa.W + gx) * pa.in_stride + c) * 4) : BUF_OOB;
+        vd[u] = buf_load4(d_rs, off, 0u);
+      }
+#pragma unroll
+      for (int u = 0; u < FX; ++u) {
+        const int f = tid + 256 * u;
+        const int pl = f / QX, c = (f - pl * QX) * 4;
+        if (f < P * QX) *reinterpret_cast<f32x4*>(xs + pl * XS + c) = vx[u];
+      }
+#pragma unroll
+      for (int u = 0; u < FD; ++u) {
+        const int f = tid + 256 * u;
+        const int pl = f / QD, c = (f - pl * QD) * 4;
+        if (f < P * QD) *reinterpret_cast<f32x4*>(drs + pl * DS + c) = vd[u];
+      }
+      // behind the K1 channels: a 1 for pixels inside the image (db1 = sum_p dh rides on the MFMAs of stage W1), zeros after it
+      constexpr int QP = (SH::XD - K1) / 4;
+      if (tid < P * QP) {
+        const int pl = tid / QP, c = K1 + (tid - pl * QP) * 4;
+        const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c == K1 && gy < pr.H && gx < pr.W) v[0] = 1.f;
+        *reinterpret_cast<f32x4*>(xs + pl * XS + c) = v;
+      }
+    }
+    __syncthreads();                                 // (A) tiles staged; the previous tile's epilogue is done with T
+
+    // ---- stage R: h[P][64 of this wave] = relu(x W1^T + b1) -> hs ---------------------------------------------------------
+    // (one row tile at a time: the two row tiles share the weight fragments, and 32 accumulator registers are live instead of 64;
+    // every accumulator still sees the k-steps in the order conv_pair_k1_kernel feeds them)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      f32x4 accs[2][4];
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) accs[k][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NS1; ++s) {
+        const f32x4 af = *reinterpret_cast<const f32x4*>(xs + (m * 16 + li) * XS + 16 * s + 4 * kq);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+            accs[j % 2][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf1[s][n][j], accs[j % 2][n], 0, 0, 0);
+      }
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = (accs[0][n][r] + accs[1][n][r]) + b1q[n];
+          hs[(m * 16 + 4 * kq + r) * HS + cw + n * 16 + li] = fmaxf(v, 0.f);
+        }
+    }
+    // W2 fragments of stage 2: requested now, used after the MFMAs of stage W2
+    f32x4 bf2[NS2][4];
+#pragma unroll
+    for (int s = 0; s < NS2; ++s)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) bf2[s][n] = buf_load4(w2_rs, woff2[n], (unsigned)(64 * s));
+
+    // ---- stage W2: dW2[n][c] += sum_p dr[p][n] h[p][c] over this wave's 64 channels (wave-private columns of hs) ----------
+#pragma unroll
+    for (int ks = 0; ks < P / 4; ++ks) {
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(hs + (4 * ks + kq) * HS + cw + 4 * li);
+      float bu[NU2];
+#pragma unroll
+      for (int u = 0; u < NU2; ++u) bu[u] = drs[(4 * ks + kq) * DS + 16 * u + li];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < NU2; ++u)
+          accW2[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t], bu[u], accW2[t][u], 0, 0, 0);
+    }
+    {   // db2 partial: thread (column tid % 64, pixel group tid / 64)
+      const int col = tid & 63;
+      if (col < K2) {
+#pragma unroll
+        for (int i = 0; i < P / 4; ++i) accb2 += drs[(wave * (P / 4) + i) * DS + col];
+      }
+    }
+
+    // ---- stage 2: dh = (dr W2) . [h > 0], in place over this wave's columns of hs ----------------------------------------
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      f32x4 accs[2][4];
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) accs[k][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NS2; ++s) {
+        const f32x4 af = *reinterpret_cast<const f32x4*>(drs + (m * 16 + li) * DS + 16 * s + 4 * kq);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+            accs[j % 2][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf2[s][n][j], accs[j % 2][n], 0, 0, 0);
+      }
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* const e = hs + (m * 16 + 4 * kq + r) * HS + cw + n * 16 + li;
+          const float v = accs[0][n][r] + accs[1][n][r];
+          *e = *e > 0.f ? v : 0.f;
+        }
+    }
+    __syncthreads();                                 // (C) the whole dh tile is in LDS
+
+    // ---- stage 3: dx tile = dh W1 (K = 256): wave -> row tile wave % 2, column tile wave / 2 (as conv_pair_k1_kernel) ---------
+    const int mt3 = wave & 1, nt3 = wave >> 1;
+    f32x4 acc3[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc3[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (!q.no_dx && nt3 < NT2) {
+#pragma unroll 4
+      for (int s = 0; s < S1_HID / 16; ++s) {
+        const f32x4 af = *reinterpret_cast<const f32x4*>(hs + (mt3 * 16 + li) * HS + 16 * s + 4 * kq);
+        const f32x4 bf = *reinterpret_cast<const f32x4*>(wd + (nt3 * 16 + li) * HS + 16 * s + 4 * kq);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc3[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[j], acc3[j], 0, 0, 0);
+      }
+    }
+    // ---- stage W1: dW1[n][c] += sum_p dh[p][n] [x | 1][p][c] over this wave's 64 hidden channels ---------------------------
+#pragma unroll
+    for (int ks = 0; ks < P / 4; ++ks) {
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(hs + (4 * ks + kq) * HS + cw + 4 * li);
+      float bu[NU1];
+#pragma unroll
+      for (int u = 0; u < NU1; ++u) bu[u] = xs[(4 * ks + kq) * XS + 16 * u + li];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < NU1; ++u)
+          accW1[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t], bu[u], accW1[t][u], 0, 0, 0);
+    }
+    __syncthreads();                                 // (D) every wave is done with hs, xs, drs
+    if (!q.no_dx) {
+      constexpr int TS = NP1 + 4;
+      float* const T = hs;
+      if (nt3 < NT2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc3[0][r];
+#pragma unroll
+          for (int k = 1; k < 4; ++k) v += acc3[k][r];
+          T[(mt3 * 16 + 4 * kq + r) * TS + nt3 * 16 + li] = v;
+        }
+      }
+      __syncthreads();                               // (E)
+      conv_epilogue_tile<2, NP1, 8, 256>(pb, T, b, y0, x0, 0, tid, red);
+    }
+  }
+
+  // ---- the block's partial gradients -> its slab ------------------------------------------------------------------------------
+  float* const slab = q.slab + (size_t)blockIdx.x * SH::SLAB;
+  // lane (li, kq), row tile t, register r of dW2's tile u holds dW2[n = 16 u + li][c = cw + 16 kq + 4 r + t]: the four t are four
+  // consecutive channels of one OIHW row
+#pragma unroll
+  for (int u = 0; u < NU2; ++u)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const f32x4 v = {accW2[0][u][r], accW2[1][u][r], accW2[2][u][r], accW2[3][u][r]};
+      *reinterpret_cast<f32x4*>(slab + (16 * u + li) * S1_HID + cw + 16 * kq + 4 * r) = v;
+    }
+  float* const slab1 = slab + K2 * S1_HID;
+  // ... and of dW1's tile u: dW1[n = cw + 16 kq + 4 r + t][c = 16 u + li]
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int u = 0; u < NU1; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slab1[(cw + 16 * kq + 4 * r + t) * SH::W1S + 16 * u + li] = accW1[t][u][r];
+  // db2: the four pixel groups of a column in a fixed order
+  __syncthreads();
+  hs[tid] = accb2;
+  __syncthreads();
+  if (tid < 64) slab[K2 * S1_HID + S1_HID * SH::W1S + tid] = tid < K2 ? ((hs[tid] + hs[64 + tid]) + (hs[128 + tid] + hs[192 + tid])) : 0.f;
+}
+
+// gw2 / gb2 / gw1 / gb1 += sum over the slabs, in a fixed association: eight interleaved groups of slabs, each summed in
+// ascending order by one thread, the eight partial sums added as a balanced tree.
+template <int K1, int K2>
+__global__ __launch_bounds__(256) void sub1_reduce_kernel(const float* __restrict__ slabs, int S, float* __restrict__ gw2,
+                                                          float* __restrict__ gb2, float* __restrict__ gw1, float* __restrict__ gb1) {
+  using SH = Sub1Shape<K1, K2>;
+  constexpr int E2 = K2 * S1_HID / 4, E1 = S1_HID * SH::W1S / 4, EB = 16, ET = E2 + E1 + EB;
+  __shared__ f32x4 part[8][32];
+  const int tid = threadIdx.x, g = tid >> 5, el = tid & 31;
+  const int e = blockIdx.x * 32 + el;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+  if (e < ET) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(slabs) + e;
+    constexpr size_t slab4 = SH::SLAB / 4;
+    int s = g;
+#pragma unroll 4
+    for (; s + 8 < S; s += 16) { a0 += src[(size_t)s * slab4]; a1 += src[(size_t)(s + 8) * slab4]; }
+    if (s < S) a0 += src[(size_t)s * slab4];
+    a0 += a1;
+  }
+  part[g][el] = a0;
+  __syncthreads();
+  if (tid < 32 && e < ET) {
+    const f32x4 tot = ((part[0][el] + part[1][el]) + (part[2][el] + part[3][el])) + ((part[4][el] + part[5][el]) + (part[6][el] + part[7][el]));
+    if (e < E2) {
+      if (gw2) {
+        if ((reinterpret_cast<uintptr_t>(gw2) & 15) == 0) *reinterpret_cast<f32x4*>(gw2 + (size_t)e * 4) += tot;
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) gw2[(size_t)e * 4 + j] += tot[j];
+        }
+      }
+    } else if (e < E2 + E1) {
+      const int idx = (e - E2) * 4, n = idx / SH::W1S, c = idx - n * SH::W1S;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (c + j < K1) { if (gw1) gw1[n * K1 + c + j] += tot[j]; }
+        else if (c + j == K1) { if (gb1) gb1[n] += tot[j]; }
+      }
+    } else if (gb2) {
+      const int idx = (e - E2 - E1) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (idx + j < K2) gb2[idx + j] += tot[j];
+    }
+  }
+}
+
+static bool g_sub1_enabled = getenv("SININN_SUB1_BWD") == nullptr || atoi(getenv("SININN_SUB1_BWD")) != 0;   // A/B switch
+void conv_sub1_bwd_enable(int on) { g_sub1_enabled = on != 0; }
+bool conv_sub1_bwd_enabled() { return g_sub1_enabled; }
+
+static bool shape_ok(int k1, int k2) { return (k1 == 8 && k2 == 16) || (k1 == 16 && k2 == 32) || (k1 == 24 && k2 == 48); }
+
+// Shapes the fused backward serves: a fp32 1x1 subnet with K1 = Cin of conv1 and K2 = 2 * Co columns of conv2 in {(8, 16),
+// (16, 32), (24, 48)} -- level 0 of the SRF network (C = 48: 24 | 24) and the small networks of the tests.  Wider subnets (level 1: 96 / 192) would need
+// 300 accumulator registers per lane for the two weight gradients and stay on the data-gradient pair + grouped weight gradients.
+int conv_sub1_bwd_shape_supported(int ksize, int dtype, int cond_cin, int co) {
+  return g_sub1_enabled && ksize == 1 && dtype == 0 && shape_ok(cond_cin, 2 * co);
+}
+
+size_t conv_sub1_bwd_workspace_bytes(int cond_cin, int co) {
+  if (!shape_ok(cond_cin, 2 * co)) return 0;
+  const int nu1 = (cond_cin + 16) / 16;
+  return (size_t)S1_MAX_BLOCKS * ((size_t)2 * co * S1_HID + (size_t)S1_HID * 16 * nu1 + 64) * sizeof(float);
+}
+
+template <int K1, int K2>
+static int sub1_launch(Sub1Dev& q, int* blocks_out, hipStream_t st) {
+  using SH = Sub1Shape<K1, K2>;
+  auto k = conv_sub1_bwd_kernel<K1, K2>;
+  static_assert(SH::LDS <= 80 * 1024, "conv_sub1_bwd: two blocks per CU need <= 80 KB of LDS each");
+  if (SH::LDS > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SH::LDS);
+    if (e != hipSuccess) { set_error("conv_sub1_bwd: cannot raise the LDS limit to %zu", SH::LDS); return 1; }
+  }
+  const int blocks = q.ntiles < S1_MAX_BLOCKS ? q.ntiles : S1_MAX_BLOCKS;
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(256), SH::LDS, st, q);
+  SININN_LAUNCH_CHECK("conv_sub1_bwd");
+  *blocks_out = blocks;
+  return 0;
+}
+
+template <int K1, int K2>
+static int sub1_reduce(const float* slabs, int S, float* gw2, float* gb2, float* gw1, float* gb1, hipStream_t st) {
+  using SH = Sub1Shape<K1, K2>;
+  constexpr int ET = K2 * S1_HID / 4 + S1_HID * SH::W1S / 4 + 16;
+  hipLaunchKernelGGL((sub1_reduce_kernel<K1, K2>), dim3((ET + 31) / 32), dim3(256), 0, st, slabs, S, gw2, gb2, gw1, gb1);
+  SININN_LAUNCH_CHECK("sub1_reduce");
+  return 0;
+}
+
+// rc: the recompute conv (x -> h: in, in_stride, Cin, w = forward pack [256][Cin], bias); d2 / d1: the two data-gradient convs as
+// the block executor describes them for the pair kernel.  Writes `*slabs_out` slabs into ws.
+int conv_sub1_bwd_launch(const sininn_conv_args* rc, const sininn_conv_args* d2, const sininn_conv_args* d1, int no_dx, void* ws,
+                         size_t ws_bytes, int* slabs_out, hipStream_t st) {
+  SININN_CHECK(rc && d2 && d1 && ws && slabs_out, "conv_sub1_bwd: null argument");
+  const int K1 = rc->Cin, K2 = d2->Cin;
+  SININN_CHECK(shape_ok(K1, K2), "conv_sub1_bwd: unsupported subnet shape (Cin %d, 2 Co %d)", K1, K2);
+  SININN_CHECK(rc->ksize == 1 && d2->ksize == 1 && d1->ksize == 1 && !rc->w_bf16 && !d2->w_bf16 && !d1->w_bf16 && !rc->winograd &&
+               !d2->winograd && !d1->winograd && !rc->in_bf16 && !d2->in_bf16, "conv_sub1_bwd: fp32 1x1 convs only");
+  SININN_CHECK(rc->Np == S1_HID && d2->Np == S1_HID && d1->Cin == S1_HID && d1->N == K1 && d1->Np == (K1 + 15) / 16 * 16,
+               "conv_sub1_bwd: the three convs do not form a subnet backward");
+  SININN_CHECK(rc->B == d2->B && rc->H == d2->H && rc->W == d2->W && rc->B == d1->B && rc->H == d1->H && rc->W == d1->W, "conv_sub1_bwd: shapes differ");
+  SININN_CHECK(rc->in_stride % 4 == 0 && d2->in_stride % 4 == 0 && aligned16(rc->in) && aligned16(d2->in) && aligned16(d1->w) && aligned16(ws),
+               "conv_sub1_bwd: operands must be 16-byte aligned with strides that are multiples of 4 floats");
+  SININN_CHECK((unsigned long long)rc->H * rc->W * (rc->in_stride > d2->in_stride ? rc->in_stride : d2->in_stride) * 4ull < (1ull << 31),
+               "conv_sub1_bwd: one image of an operand exceeds the 2 GB a block addresses (raw buffer staging)");
+  SININN_CHECK(ws_bytes >= conv_sub1_bwd_workspace_bytes(K1, K2 / 2), "conv_sub1_bwd: workspace too small (%zu < %zu)", ws_bytes,
+               conv_sub1_bwd_workspace_bytes(K1, K2 / 2));
+  Sub1Dev q;
+  alignas(16) static float dummy[4] = {0.f, 0.f, 0.f, 0.f};   // conv_prepare insists on pointers the kernel never follows
+  sininn_conv_args ra = *rc;
+  ra.mode = SININN_CONV_RELU; ra.out = dummy; ra.out_stride = S1_HID; ra.N = S1_HID;
+  if (int e = conv_prepare(&ra, q.r)) return e;
+  sininn_conv_args da = *d2;
+  da.mode = SININN_CONV_LINEAR; da.mask = nullptr; da.out = dummy; da.out_stride = S1_HID; da.N = S1_HID;
+  if (int e = conv_prepare(&da, q.a)) return e;
+  sininn_conv_args db = *d1;
+  db.in = dummy; db.in_stride = S1_HID;
+  if (no_dx) { db.mode = SININN_CONV_LINEAR; db.out = dummy; db.out_stride = K1; db.addend = nullptr; db.addend_map = nullptr; }
+  if (int e = conv_prepare(&db, q.b)) return e;
+  q.r.tiles_x = q.a.tiles_x = q.b.tiles_x = (rc->W + 15) / 16;
+  q.r.tiles_y = q.a.tiles_y = q.b.tiles_y = (rc->H + 1) / 2;
+  q.ntiles = q.r.tiles_x * q.r.tiles_y * rc->B;
+  q.no_dx = no_dx ? 1 : 0;
+  q.slab = static_cast<float*>(ws);
+  q.r.stamp = q.a.stamp = q.b.stamp = nullptr;
+  if (K1 == 8) return sub1_launch<8, 16>(q, slabs_out, st);
+  if (K1 == 16) return sub1_launch<16, 32>(q, slabs_out, st);
+  return sub1_launch<24, 48>(q, slabs_out, st);
+}
+
+int conv_sub1_bwd_reduce(int cond_cin, int co, const void* ws, int slabs, float* gw2, float* gb2, float* gw1, float* gb1, hipStream_t st) {
+  SININN_CHECK(shape_ok(cond_cin, 2 * co) && ws && slabs > 0 && slabs <= S1_MAX_BLOCKS, "conv_sub1_bwd_reduce: bad arguments");
+  const float* s = static_cast<const float*>(ws);
+  if (cond_cin == 8) return sub1_reduce<8, 16>(s, slabs, gw2, gb2, gw1, gb1, st);
+  if (cond_cin == 16) return sub1_reduce<16, 32>(s, slabs, gw2, gb2, gw1, gb1, st);
+  return sub1_reduce<24, 48>(s, slabs, gw2, gb2, gw1, gb1, st);
+}
+
+}  // namespace sininn

@@ -41,6 +41,13 @@ static std::mutex g_ev_mutex;
 struct EventRing { hipEvent_t ev[64]; bool ready = false; unsigned next = 0; };
 static EventRing g_rings[16];
 
+// conv_sub1_bwd.hip: the whole backward of a fp32 1x1 subnet in one persistent launch (h recomputed, dh on chip)
+int conv_sub1_bwd_shape_supported(int ksize, int dtype, int cond_cin, int co);
+size_t conv_sub1_bwd_workspace_bytes(int cond_cin, int co);
+int conv_sub1_bwd_launch(const sininn_conv_args* rc, const sininn_conv_args* d2, const sininn_conv_args* d1, int no_dx, void* ws,
+                         size_t ws_bytes, int* slabs_out, hipStream_t st);
+int conv_sub1_bwd_reduce(int cond_cin, int co, const void* ws, int slabs, float* gw2, float* gb2, float* gw1, float* gb1, hipStream_t st);
+
 int order_after(hipStream_t waiter, hipStream_t producer) {
   if (waiter == producer) return 0;
   int dev = 0;
@@ -182,6 +189,12 @@ static bool group_major_hidden(const sininn_glow_args* a, const sininn_subnet* n
   return g_group_major && a->dtype == 0 && a->ksize == 3 && (net->winograd & 15) == 15 && group_major_fits(M, a->W) && wgrad_grouping_enabled();
 }
 
+// The subnet of this half runs its backward as ONE persistent launch that recomputes h (conv_sub1_bwd.hip): the forward pass then
+// does not store the hidden tensor.  A property of the shape alone, so the forward and the backward call agree on it.
+static bool fused_sub1(const sininn_glow_args* a, int cond_cin, int co) {
+  return conv_sub1_bwd_shape_supported(a->ksize, a->dtype, cond_cin, co) != 0;
+}
+
 struct Half {                 // one half-coupling in execution order
   const sininn_subnet* net;
   int cond_off;               // offset of the conditioning channels in x (-1: the first half's compact output)
@@ -216,7 +229,7 @@ size_t glow_saved_floats(int B, int H, int W, int C, int dtype) {
   return 2 * align64(hid) + 3 * align64(M * big) + 64;
 }
 
-struct Scratch { float *dr_b, *dh_b, *dy_first, *dr_a, *dh_a; void* ws; size_t ws_bytes; size_t total_bytes; };
+struct Scratch { float *dr_b, *dh_b, *dy_first, *dr_a, *dh_a; void* ws; size_t ws_bytes; void* slab[2]; size_t slab_bytes[2]; size_t total_bytes; };
 static Scratch scratch_layout(void* basep, int B, int H, int W, int C, int ksize, int co_a, int co_b) {
   const size_t M = (size_t)B * H * W;
   float* base = static_cast<float*>(basep);
@@ -260,7 +273,16 @@ static Scratch scratch_layout(void* basep, int B, int H, int W, int C, int ksize
   }
   s.ws = base + o;
   s.ws_bytes = w;
-  s.total_bytes = o * sizeof(float) + w;
+  // slabs of the fused 1x1 subnet backward (conv_sub1_bwd.hip), one region per half: the reduce of the first-processed half runs
+  // on the weight-gradient stream while the second half's kernel fills its own region
+  size_t so = (o * sizeof(float) + w + 255) / 256 * 256;
+  const int cond_cin[2] = {C - co_a, co_a}, cos[2] = {co_a, co_b};
+  for (int i = 0; i < 2; ++i) {
+    s.slab_bytes[i] = ksize == 1 ? conv_sub1_bwd_workspace_bytes(cond_cin[i], cos[i]) : 0;
+    s.slab[i] = reinterpret_cast<char*>(base) + so;
+    so += (s.slab_bytes[i] + 255) / 256 * 256;
+  }
+  s.total_bytes = so;
   return s;
 }
 
@@ -306,8 +328,22 @@ int glow_hidden_gates(const sininn_glow_args* a, int which, unsigned char* gates
   Half hv[2];
   halves_of(a, hv);
   Saved sv = saved_layout(a->saved, M, hv[0].co, hv[1].co, a->dtype == 1);
-  const float* h = which == 0 ? sv.h_a : sv.h_b;
+  float* h = which == 0 ? sv.h_a : sv.h_b;
   const int gm = group_major_hidden(a, hv[which].net) ? 1 : 0;
+  {
+    // a subnet whose backward recomputes h (conv_sub1_bwd.hip) did not store it: conv1 is run again into the (reserved, unused)
+    // slot of `saved` -- from the input the forward pass read: x for the first half, the saved compact output for the second
+    const int cond_cin = which == 0 ? a->C - hv[0].co : hv[0].co;
+    if (fused_sub1(a, cond_cin, hv[which].co)) {
+      sininn_conv_args c1 = {};
+      if (which == 0) { c1.in = a->x + hv[0].cond_off; c1.in_stride = a->C; }
+      else { c1.in = sv.ybuf; c1.in_stride = hv[0].co; }
+      c1.Cin = cond_cin; c1.w = hv[which].net->w1; c1.bias = hv[which].net->b1; c1.Np = SININN_HIDDEN;
+      c1.B = a->B; c1.H = a->H; c1.W = a->W; c1.ksize = 1; c1.mode = SININN_CONV_RELU;
+      c1.out = h; c1.out_stride = SININN_HIDDEN; c1.N = SININN_HIDDEN;
+      if (int rc = conv_launch(&c1, st)) return rc;
+    }
+  }
   const int64_t total = (int64_t)M * SININN_HIDDEN;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(hidden_gates_kernel, dim3(blocks), dim3(256), 0, st, h, (int64_t)M, gm, a->dtype == 1 ? 1 : 0, gates);
@@ -364,8 +400,9 @@ int glow_forward(const sininn_glow_args* a, hipStream_t st) {
       }
     }
     // 1x1 subnets (fp32): both convs in one launch, the hidden tile stays in LDS between them (conv_pair_k1.hip)
-    if (conv_pair_k1_supported(&c1, &c2) && (a->no_save || conv_pair_k1_preferred(&c1))) {
-      if (a->no_save) c1.out = nullptr;              // ... and then the hidden tensor never reaches HBM
+    const bool recompute = fused_sub1(a, c1.Cin, h.co);      // the backward recomputes h from this half's input
+    if (conv_pair_k1_supported(&c1, &c2) && (a->no_save || recompute || conv_pair_k1_preferred(&c1))) {
+      if (a->no_save || recompute) c1.out = nullptr; // ... and then the hidden tensor never reaches HBM
       ClassScope sc(PC_COUPLE, a->ksize, conv_flops(M, a->ksize, c1.Cin, SININN_HIDDEN) + conv_flops(M, a->ksize, SININN_HIDDEN, 2 * h.co), st);
       if (int rc = conv_pair_k1_launch(&c1, &c2, st)) return rc;
       continue;
@@ -441,7 +478,8 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
     }
     const bool gm = group_major_hidden(a, net);
     const int gs = gm ? (int)(M * 8) : 0;
-    if (net->gw2) {
+    const bool fused = fused_sub1(a, cond_cin, h.co);       // conv_sub1_bwd.hip: its weight gradients come out of the same launch
+    if (net->gw2 && !fused) {
       if (grouped) add_item(hbuf, SININN_HIDDEN, SININN_HIDDEN, dr, 2 * h.co, 2 * h.co, net->gw2, net->gb2, bf16 ? 1 : 0, 0, gs, 0);
       else {
         if (int rc = order_after(wst, st)) return rc;
@@ -474,6 +512,25 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
       d1.v = fuse->vy; d1.v_stride = fuse->vy_stride; d1.sbuf = const_cast<float*>(fuse->s);
       d1.out2 = a->dx + hv[0].base; d1.out2_stride = C;
       d1.logdet = const_cast<float*>(a->gld); d1.Co = cond_cin; d1.clamp = a->clamp;
+    }
+    if (fused) {
+      // fp32 1x1 subnet at a shape the persistent kernel serves: h is recomputed from `cond`, dh stays on chip, both data
+      // gradients and both weight gradients come out of one launch; the slab reduce joins the other += on the weight-gradient stream
+      sininn_conv_args rc = {};
+      rc.in = cond; rc.in_stride = cond_stride; rc.Cin = cond_cin; rc.w = net->w1; rc.bias = net->b1; rc.Np = SININN_HIDDEN;
+      rc.B = B; rc.H = H; rc.W = W; rc.ksize = 1; rc.mode = SININN_CONV_RELU;
+      const int which = (&h == &hv[0]) ? 0 : 1;
+      int slabs = 0;
+      {
+        ClassScope scp(PC_DGRAD2, k, 2.0 * (conv_flops(M, k, 2 * h.co, SININN_HIDDEN) + conv_flops(M, k, SININN_HIDDEN, cond_cin)), st);
+        if (int rc_ = conv_sub1_bwd_launch(&rc, &d2, &d1, skip_d1 ? 1 : 0, sc.slab[which], sc.slab_bytes[which], &slabs, st)) return rc_;
+      }
+      if (net->gw1 || net->gw2) {
+        if (int rc_ = order_after(wst, st)) return rc_;
+        ClassScope scp(PC_WGRAD, k, 0.0, wst);
+        if (int rc_ = conv_sub1_bwd_reduce(cond_cin, h.co, sc.slab[which], slabs, net->gw2, net->gb2, net->gw1, net->gb1, wst)) return rc_;
+      }
+      return 0;
     }
     const bool pair = !skip_d1 && conv_pair_k1_supported(&d2, &d1);
     if (pair) {

@@ -565,6 +565,85 @@ def test_conv_pair_c_abi_matches_two_launches(env, co, hw):
     assert lib.sininn_conv_pair_k1_supported(C.byref(f3), C.byref(s1)) == 0
 
 
+# ---------------------------------------------------------------------------------------------------
+# the whole backward of a 1x1 subnet in one persistent launch (sininn_conv_sub1_bwd): h recomputed, dh on chip
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('co,b,hw,no_dx', [(24, 2, (13, 21), False), (24, 16, (64, 64), False), (8, 3, (9, 33), False), (16, 1, (2, 16), False),
+                                           (24, 2, (7, 40), True)])
+def test_fused_1x1_subnet_backward_c_abi(env, co, b, hw, no_dx):
+    """dx: BITWISE what the data-gradient pair produces from the h the forward pair stored (the recompute uses the same k order);
+    weight / bias gradients: the torch matmul reference at 1e-4 (max-norm), accumulated (+=) onto non-zero gradients; partial
+    tiles (odd sizes), more tiles than persistent blocks (16 x 64 x 64 = 2048 tiles on 512 blocks), a single tile."""
+    import ctypes as C
+    S, O, dev = env
+    from sin_inn_amd import _lib, ops
+    lib = _lib.lib()
+    torch.manual_seed(co + b)
+    h, w = hw
+    k1, k2, m = co, 2 * co, b * h * w
+    cx = 2 * co + 8                                               # x lives inside a wider tensor (channel offset 8)
+    xfull = torch.randn(m, cx, device=dev)
+    conv1 = torch.nn.Conv2d(k1, 256, 1).to(dev)
+    conv2 = torch.nn.Conv2d(256, k2, 1).to(dev)
+    with torch.no_grad():
+        conv2.weight.mul_(0.3)
+    pk1 = ops.pack_conv(conv1.weight.detach(), conv1.bias.detach(), None, True)
+    pk2 = ops.pack_conv(conv2.weight.detach(), conv2.bias.detach(), ops.coupling_colmap(co, dev), True)
+    dr = torch.randn(m, k2, device=dev)
+    addend = torch.randn(m, k1, device=dev)
+
+    def args(**kw):
+        a = _lib.ConvArgs()
+        for k, v in kw.items():
+            setattr(a, 'inp' if k == 'in_' else k, v)
+        return a
+    common = dict(B=b, H=h, W=w, ksize=1)
+    # the h the forward pass would have used: stage 1 of the pair kernel (second conv: a throw-away linear conv)
+    hid = torch.zeros(m, 256, device=dev)
+    dump = torch.zeros(m, k2, device=dev)
+    f = args(in_=ops.ptr(xfull, 8), in_stride=cx, Cin=k1, w=ops.ptr(pk1[0]), bias=ops.ptr(pk1[1]), Np=256, mode=_lib.CONV_RELU,
+             out=ops.ptr(hid), out_stride=256, N=256, **common)
+    s2 = args(in_=ops.ptr(hid), in_stride=256, Cin=256, w=ops.ptr(pk2[0]), bias=ops.ptr(pk2[1]), Np=k2, mode=_lib.CONV_LINEAR,
+              out=ops.ptr(dump), out_stride=k2, N=k2, **common)
+    _lib.check(lib.sininn_conv_pair_k1(C.byref(f), C.byref(s2), ops._stream()))
+
+    def dgrad_descs(dx, dh):
+        d2 = args(in_=ops.ptr(dr), in_stride=k2, Cin=k2, w=ops.ptr(pk2[2]), Np=256, mode=_lib.CONV_MASK, out=ops.ptr(dh), out_stride=256,
+                  N=256, mask=ops.ptr(hid), mask_stride=256, **common)
+        d1 = args(in_=ops.ptr(dh), in_stride=256, Cin=256, w=ops.ptr(pk1[2]), Np=ops.pad16(k1), mode=_lib.CONV_ADD, out=ops.ptr(dx),
+                  out_stride=k1, N=k1, addend=ops.ptr(addend), addend_stride=k1, **common)
+        return d2, d1
+    dx_ref, dh_ref = torch.zeros(m, k1, device=dev), torch.zeros(m, 256, device=dev)
+    d2, d1 = dgrad_descs(dx_ref, dh_ref)
+    _lib.check(lib.sininn_conv_pair_k1(C.byref(d2), C.byref(d1), ops._stream()))
+
+    g0 = [torch.randn_like(conv2.weight), torch.randn_like(conv2.bias), torch.randn_like(conv1.weight), torch.randn_like(conv1.bias)]
+    gw2, gb2, gw1, gb1 = (g.clone().contiguous() for g in g0)
+    dx = torch.full((m, k1), float('nan'), device=dev)
+    rc = args(in_=ops.ptr(xfull, 8), in_stride=cx, Cin=k1, w=ops.ptr(pk1[0]), bias=ops.ptr(pk1[1]), Np=256, **common)
+    d2f, d1f = dgrad_descs(dx, dh_ref)
+    d2f.mask, d2f.out, d1f.inp = None, None, None                 # ignored by the fused kernel: h is recomputed, dh stays on chip
+    nbytes = lib.sininn_conv_sub1_bwd_workspace_bytes(k1, co)
+    assert nbytes > 0 and lib.sininn_conv_sub1_bwd_workspace_bytes(96, 96) == 0
+    ws = torch.empty(nbytes // 4, device=dev)
+    _lib.check(lib.sininn_conv_sub1_bwd(C.byref(rc), C.byref(d2f), C.byref(d1f), int(no_dx), ops.ptr(gw2), ops.ptr(gb2), ops.ptr(gw1),
+                                        ops.ptr(gb1), ops.ptr(ws), nbytes, ops._stream()))
+    torch.cuda.synchronize()
+    if no_dx:
+        assert bool(torch.isnan(dx).all())                         # untouched
+    else:
+        assert torch.equal(dx, dx_ref)
+    x = xfull[:, 8:8 + k1].double()
+    hd, dhd, drd = hid.double(), dh_ref.double(), dr.double()
+    want = [g0[0].double() + (drd.t() @ hd).reshape(k2, 256, 1, 1), g0[1].double() + drd.sum(0),
+            g0[2].double() + (dhd.t() @ x).reshape(256, k1, 1, 1), g0[3].double() + dhd.sum(0)]
+    for got, ref_ in zip((gw2, gb2, gw1, gb1), want):
+        assert relerr(got, ref_.float()) < 1e-4
+    # unsupported shapes are refused, not mis-run
+    bad = args(in_=ops.ptr(xfull, 8), in_stride=cx, Cin=k1, w=ops.ptr(pk1[0]), bias=ops.ptr(pk1[1]), Np=256, B=b, H=h, W=w, ksize=3)
+    assert lib.sininn_conv_sub1_bwd(C.byref(bad), C.byref(d2f), C.byref(d1f), 0, None, None, None, None, ops.ptr(ws), nbytes, ops._stream()) != 0
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_sample_pairs_planar_is_bit_exact(dtype):
     """frame-pair sampler of the flow path: (clip[idx], clip[idx + gap]) / 255 as planar (n,3,H,W), fp32 bit-exact with the

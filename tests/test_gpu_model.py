@@ -121,6 +121,42 @@ def test_fused_1x1_pair_matches_the_two_launch_path(rev, channels, hw, precision
     assert relerr(res[0][3], res[0][0]) < tol
 
 
+@pytest.mark.parametrize('rev', [False, True])
+@pytest.mark.parametrize('channels,hw', [(48, (13, 21)), (48, (64, 64)), (16, (9, 33)), (32, (5, 16))])
+def test_fused_1x1_subnet_backward_matches_the_pair_path(rev, channels, hw):
+    """Round 4: fp32 1x1 subnets at the level-0 shapes run their WHOLE backward as one persistent launch (conv_sub1_bwd.hip: h
+    recomputed from the input, dh on chip, both data gradients and both weight gradients) and their forward without storing h.
+    Same block, same inputs with the switch off (data-gradient pair + grouped weight gradients, h stored): outputs, log-det and
+    the input gradient agree to summation order of the FORWARD pair (the backward itself is bitwise the pair's), every parameter
+    gradient to 1e-4 (another slab partition); gradients accumulate (+=) over two backward passes."""
+    import archs
+    import sin_inn_amd as S
+    from sin_inn_amd import _lib
+    torch.manual_seed(channels + hw[0])
+    h, w = hw
+    blk = S.GLOWCouplingBlock([(channels, h, w)], subnet_constructor=archs.subnet_conv_1x1, clamp=1.2)
+    for p in blk.parameters():
+        p.data.mul_(3.0)
+    blk.cuda()
+    x = torch.randn(2, channels, h, w, device='cuda')
+    wgt, ld_w = torch.randn_like(x), torch.randn(2, device='cuda')
+    res = []
+    try:
+        for fused in (1, 0):
+            _lib.lib().sininn_sub1_bwd_test_hook(fused)
+            blk.zero_grad()
+            for _ in range(2):                          # twice: the gradients accumulate
+                xg = x.clone().requires_grad_(True)
+                y = blk([xg], rev=rev)[0]
+                ((y * wgt).sum() + (blk.last_jac * ld_w).sum()).backward()
+            S.modules.join_side_streams()
+            res.append([y.detach(), blk.last_jac.detach().clone(), xg.grad] + [p.grad.clone() for p in blk.parameters()])
+    finally:
+        _lib.lib().sininn_sub1_bwd_test_hook(1)
+    for i, (a, b) in enumerate(zip(*res)):
+        assert relerr(a, b) < (1e-5 if i < 3 else 1e-4), i
+
+
 @pytest.mark.parametrize('num_coupling', [1, 2])
 def test_srflow_network_and_gradients(num_coupling):
     import archs
