@@ -10,15 +10,17 @@
 // pass, re-read as the ReLU mask and by conv2's weight gradient, dh written and re-read by conv1's weight gradient: 335 MB at
 // BASELINE configs[1], level 0, against 31 MB of x / dr / dx -- and its 1x1 classes sat at 0.17 - 0.32 of the f32 matrix pipe.
 //
-// Block = 256 threads, persistent over 32-pixel tiles (2 x 16 pixels).  Per tile, on v_mfma_f32_16x16x4_f32:
+// Block = 512 threads (8 waves, one block per CU), persistent over 64-pixel tiles (4 x 16 pixels); the wave's weight fragments of
+// stage R / stage 2 live in registers for the lifetime of the block, a tile's x / dr are requested while the previous tile is being
+// processed, the side inputs of its epilogue at its start.  Per tile, on v_mfma_f32_16x16x4_f32:
 //   stage 0  x tile [32][K1] and dr tile [32][K2] -> LDS (raw buffer loads, zero fill outside the image)
-//   stage R  h  = relu(x W1^T + b1): wave w owns hidden columns [64 w, 64 w + 64) -- the SAME k order and accumulator split as
+//   stage R  h  = relu(x W1^T + b1): wave w owns hidden columns [32 w, 32 w + 32) -- the SAME k order and accumulator split as
 //            stage 1 of conv_pair_k1_kernel, so the recomputed h is bitwise the h the forward pass used
-//   stage W2 dW2[n][c] += sum_p dr[p][n] h[p][c]: rows = the wave's 64 hidden channels, one 16-byte LDS read per lane supplies the
-//            A operands of four row tiles (row i of tile t <-> channel 64 w + 4 i + t), k = 4 pixels per MFMA; accumulators stay
+//   stage W2 dW2[n][c] += sum_p dr[p][n] h[p][c]: rows = the wave's 32 hidden channels, one 8-byte LDS read per lane supplies the
+//            A operands of two row tiles (row i of tile t <-> channel 32 w + 2 i + t), k = 4 pixels per MFMA; accumulators stay
 //            in registers for the lifetime of the block
 //   stage 2  dh = (dr W2) . [h > 0] written IN PLACE over h (an element's mask is the element it overwrites, and a wave only ever
-//            touches its own 64 columns of the tile in stages R / W2 / 2: no block barrier between them)
+//            touches its own 32 columns of the tile in stages R / W2 / 2: no block barrier between them)
 //   stage 3  dx tile = dh W1 (K = 256; W1's data-gradient pack lives in LDS for the lifetime of the block) -> the shared epilogue
 //            (conv_epilogue_tile: ADD / ADD_CBWD_*), identical arithmetic to stage 2 of conv_pair_k1_kernel
 //   stage W1 dW1[n][c] += sum_p dh[p][n] x[p][c]; the x tile carries a column of ones behind its K1 channels, so db1 falls out of
@@ -34,8 +36,9 @@ int conv_prepare(const sininn_conv_args* a, ConvDev& d);
 
 constexpr int S1_HID = 256;            // hidden channels (SININN_HIDDEN)
 constexpr int S1_HS = S1_HID + 4;      // floats per pixel row of the hidden tile in LDS
-constexpr int S1_P = 32;               // pixels per tile (2 x 16)
-constexpr int S1_MAX_BLOCKS = 512;     // persistent blocks == slabs (two per CU)
+constexpr int S1_P = 64;               // pixels per tile (4 x 16)
+constexpr int S1_NTHR = 512;           // 8 waves: wave w owns hidden columns [32 w, 32 w + 32)
+constexpr int S1_MAX_BLOCKS = 256;     // persistent blocks == slabs (one per CU: 122 KB of LDS)
 
 struct Sub1Dev {
   ConvDev r;        // recompute: in = x (the subnet's input), w = W1 forward pack [256][K1], bias = b1
@@ -56,56 +59,76 @@ struct Sub1Shape {
   static constexpr int NP1 = K1R;                           // columns of the data gradient of conv1 (pad16)
   static constexpr int NT2 = NP1 / 16;
   static constexpr int W1S = 16 * NU1;                      // slab row of dW1: [K1 channels | db1 | zero pad]
-  static constexpr int SLAB = K2 * S1_HID + S1_HID * W1S + 64;   // dW2 [K2][256] | dW1 [256][W1S] | db2 [64]
-  static constexpr size_t LDS = (size_t)(S1_P * S1_HS + S1_P * DS + S1_P * XS + NP1 * S1_HS) * sizeof(float);
+  static constexpr int SLAB = K2 * S1_HID + S1_HID * W1S + 64;   // dW2 [K2][256] | dW1^T [W1S][256] (row K1 = db1) | db2 [64]
+  static constexpr size_t LDS = (size_t)(S1_P * S1_HS + 2 * (S1_P * DS + S1_P * XS) + NP1 * S1_HS + S1_P * (NP1 + 4)) * sizeof(float);
 };
 
-template <int K1, int K2>
-__global__ __launch_bounds__(256, 2) void conv_sub1_bwd_kernel(Sub1Dev q) {
+template <int K1, int K2, bool STAMP>
+__global__ __launch_bounds__(S1_NTHR) void conv_sub1_bwd_kernel(Sub1Dev q) {
   using SH = Sub1Shape<K1, K2>;
-  constexpr int P = S1_P, MT = 2, HS = S1_HS, DS = SH::DS, XS = SH::XS, NU1 = SH::NU1, NU2 = SH::NU2, NP1 = SH::NP1, NT2 = SH::NT2;
-  constexpr int NS1 = SH::K1R / 16, NS2 = K2 / 16;
+  constexpr int P = S1_P, MT = 4, HS = S1_HS, DS = SH::DS, XS = SH::XS, NU1 = SH::NU1, NU2 = SH::NU2, NP1 = SH::NP1, NT2 = SH::NT2;
+  constexpr int NS1 = SH::K1R / 16, NS2 = K2 / 16, NTHR = S1_NTHR;
   static_assert(K1 % 8 == 0 && K1 <= 24 && K2 % 16 == 0 && K2 <= 48, "conv_sub1_bwd: shape");
   const ConvDev& pr = q.r;
   const ConvDev& pa = q.a;
   const ConvDev& pb = q.b;
   extern __shared__ __attribute__((aligned(16))) float smem_sub1[];
-  float* const hs = smem_sub1;                      // [P][HS]: h, then dh; later T[P][NP1 + 4]
-  float* const drs = hs + P * HS;                   // [P][DS]
-  float* const xs = drs + P * DS;                   // [P][XS]: x | 1 | 0...
-  float* const wd = xs + P * XS;                    // [NP1][HS]: W1 data-gradient pack
-  __shared__ float red[4];
+  float* const hs = smem_sub1;                      // [P][HS]: h, then dh
+  float* const drs0 = hs + P * HS;                  // 2 x [P][DS]  (double-buffered: the next tile is staged while this one computes)
+  float* const xs0 = drs0 + 2 * P * DS;             // 2 x [P][XS]: x | 1 | 0...
+  float* const wd = xs0 + 2 * P * XS;               // [NP1][HS]: W1 data-gradient pack
+  float* const T = wd + NP1 * HS;                   // [P][NP1 + 4]: the dx tile on its way to the epilogue
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, kq = lane >> 4;
-  const int cw = wave * 64;                         // this wave's hidden columns
+  const int cw = wave * 32;                         // this wave's hidden columns
 
-  // ---- once per block: W1's data-gradient pack -> LDS ----------------------------------------------------------------------
+  // phase stamps (diagnostic build of the kernel, STAMP: d1->stamp -> 2 x 16 words from thread 0 / thread 448 -- wave 0 / wave 7:
+  // 0 top of tile, 1 stage R, 2 stage W2, 3 stage 2, 4 stage 3, 5 stage W1, 6 epilogue, 7 slab write, 8 total, 9 tiles, 10 next
+  // tile -> LDS (incl. the wait for its loads), 11 requests, 12 barrier C, 13 T write, 14 barrier E).  Deltas are summed in
+  // registers and written once at the end of the block: an atomic per phase sits in the same in-order counter as the loads whose
+  // latency is being measured (tools/bench_sub1.py)
+  const bool stamping = STAMP && pb.stamp != nullptr && (tid == 0 || tid == 448);
+  unsigned ph[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) ph[k] = 0u;
+  unsigned long long tprev = stamping ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long tstart = tprev;
+  auto mark = [&](int k) {
+    if constexpr (STAMP) {
+      if (stamping) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph[k] += (unsigned)(t - tprev); tprev = t; }
+    }
+  };
+
+  // ---- once per block: W1's data-gradient pack -> LDS; the wave's weight fragments of stage R and stage 2 -> registers -------
   if (!q.no_dx) {
-    for (int f = tid; f < NP1 * (S1_HID / 4); f += 256) {
+    for (int f = tid; f < NP1 * (S1_HID / 4); f += NTHR) {
       const int n = f / (S1_HID / 4), c = (f - n * (S1_HID / 4)) * 4;
       *reinterpret_cast<f32x4*>(wd + n * HS + c) = *reinterpret_cast<const f32x4*>(pb.w + (size_t)n * S1_HID + c);
     }
   }
-  f32x4 b1q;                                        // bias of the wave's columns cw + 16 n + li
+  float b1q[2];                                     // bias of the wave's columns cw + 16 n + li
 #pragma unroll
-  for (int n = 0; n < 4; ++n) b1q[n] = pr.bias ? pr.bias[cw + 16 * n + li] : 0.f;
-
-  // weight fragments straight from L2 (every block reads the same few KB), as in conv_pair_k1_kernel
-  const __amdgpu_buffer_rsrc_t w1_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.w), 0, S1_HID * K1 * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t w2_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pa.w), 0, S1_HID * K2 * 4, 0x00020000);
-  unsigned woff1[4], woff2[4];
+  for (int n = 0; n < 2; ++n) b1q[n] = pr.bias ? pr.bias[cw + 16 * n + li] : 0.f;
+  f32x4 bf1[NS1][2], bf2[NS2][2];                   // B operands: W[column cw + 16 n + li][16 s + 4 kq .. + 3]
+  {
+    const __amdgpu_buffer_rsrc_t w1_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.w), 0, S1_HID * K1 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w2_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pa.w), 0, S1_HID * K2 * 4, 0x00020000);
 #pragma unroll
-  for (int n = 0; n < 4; ++n) {
-    woff1[n] = (unsigned)(((cw + n * 16 + li) * K1 + 4 * kq) * 4);
-    woff2[n] = (unsigned)(((cw + n * 16 + li) * K2 + 4 * kq) * 4);
+    for (int n = 0; n < 2; ++n) {
+      const unsigned o1 = (unsigned)(((cw + n * 16 + li) * K1 + 4 * kq) * 4), o2 = (unsigned)(((cw + n * 16 + li) * K2 + 4 * kq) * 4);
+#pragma unroll
+      for (int s = 0; s < NS1; ++s) bf1[s][n] = buf_load4(w1_rs, 16 * s + 4 * kq < K1 ? o1 : BUF_OOB, (unsigned)(64 * s));
+#pragma unroll
+      for (int s = 0; s < NS2; ++s) bf2[s][n] = buf_load4(w2_rs, o2, (unsigned)(64 * s));
+    }
   }
 
   // ---- gradient accumulators of the block (registers) ----------------------------------------------------------------------
-  f32x4 accW2[4][NU2], accW1[4][NU1];
+  f32x4 accW2[2][NU2], accW1[2][NU1];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
+  for (int t = 0; t < 2; ++t) {
 #pragma unroll
     for (int u = 0; u < NU2; ++u) accW2[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -113,144 +136,170 @@ __global__ __launch_bounds__(256, 2) void conv_sub1_bwd_kernel(Sub1Dev q) {
   }
   float accb2 = 0.f;
 
+  // ---- staging slots of a thread (the same for every tile) and the global loads of a tile ------------------------------------
+  constexpr int QX = K1 / 4, QD = K2 / 4;
+  constexpr int FX = (P * QX + NTHR - 1) / NTHR, FD = (P * QD + NTHR - 1) / NTHR;
   const int tiles_img = pr.tiles_x * pr.tiles_y;
-  for (int tile = blockIdx.x; tile < q.ntiles; tile += gridDim.x) {
+  auto issue_tile = [&](int tile, f32x4 (&vx)[FX], f32x4 (&vd)[FD]) {
+    const bool live = tile < q.ntiles;
+    const int b = live ? tile / tiles_img : 0;
+    const int trem = tile - b * tiles_img;
+    const int ty = trem / pr.tiles_x, tx = trem - ty * pr.tiles_x;
+    const int y0 = ty * 4, x0 = tx * 16;
+    const size_t img = (size_t)b * pr.H * pr.W;
+    const __amdgpu_buffer_rsrc_t x_rs = buf_rsrc(pr.in + img * pr.in_stride);
+    const __amdgpu_buffer_rsrc_t d_rs = buf_rsrc(pa.in + img * pa.in_stride);
+#pragma unroll
+    for (int u = 0; u < FX; ++u) {
+      const int f = tid + NTHR * u;
+      const int pl = f / QX, c = (f - pl * QX) * 4;
+      const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+      const unsigned off = (live && f < P * QX && gy < pr.H && gx < pr.W) ? (unsigned)(((gy * pr.W + gx) * pr.in_stride + c) * 4) : BUF_OOB;
+      vx[u] = buf_load4(x_rs, off, 0u);
+    }
+#pragma unroll
+    for (int u = 0; u < FD; ++u) {
+      const int f = tid + NTHR * u;
+      const int pl = f / QD, c = (f - pl * QD) * 4;
+      const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+      const unsigned off = (live && f < P * QD && gy < pa.H && gx < pa.W) ? (unsigned)(((gy * pa.W + gx) * pa.in_stride + c) * 4) : BUF_OOB;
+      vd[u] = buf_load4(d_rs, off, 0u);
+    }
+  };
+
+  // ---- the epilogue of stage 3 on one quad per thread (pixel tid / 8, columns 4 (tid % 8) ..): the modes the block executor
+  // uses, with every global side input requested at the START of the tile.  Arithmetic and stores are conv_epilogue_tile's.
+  const int e_pl = tid >> 3, e_q = tid & 7, e_col = 4 * e_q;
+  const int emode = pb.mode;
+  const bool e_cbwd = emode == SININN_CONV_ADD_CBWD_FWD || emode == SININN_CONV_ADD_CBWD_INV;
+  const bool e_fast = !q.no_dx;                     // alignment / mode requirements of the quad epilogue: checked on the host
+  int amap[4] = {e_col, e_col + 1, e_col + 2, e_col + 3};
+  f32x4 e_bq = {0.f, 0.f, 0.f, 0.f};
+  if (e_fast && e_col < pb.N) {
+    if (pb.addend_map) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) amap[j] = pb.addend_map[e_col + j];
+    }
+    if (pb.bias) e_bq = *reinterpret_cast<const f32x4*>(pb.bias + e_col);
+  }
+
+  // regs -> LDS of a staged tile (+ the column of ones / zeros behind the K1 channels: a 1 for pixels inside the image, so that
+  // db1 = sum_p dh rides on the MFMAs of stage W1)
+  auto store_tile = [&](int tile, int buf, const f32x4 (&vx)[FX], const f32x4 (&vd)[FD]) {
+    float* const xs = xs0 + buf * (P * XS);
+    float* const drs = drs0 + buf * (P * DS);
+#pragma unroll
+    for (int u = 0; u < FX; ++u) {
+      const int f = tid + NTHR * u;
+      const int pl = f / QX, c = (f - pl * QX) * 4;
+      if (f < P * QX) *reinterpret_cast<f32x4*>(xs + pl * XS + c) = vx[u];
+    }
+#pragma unroll
+    for (int u = 0; u < FD; ++u) {
+      const int f = tid + NTHR * u;
+      const int pl = f / QD, c = (f - pl * QD) * 4;
+      if (f < P * QD) *reinterpret_cast<f32x4*>(drs + pl * DS + c) = vd[u];
+    }
+    constexpr int QP = (SH::XD - K1) / 4;
+    if (tid < P * QP) {
+      const int b = tile / tiles_img;
+      const int trem = tile - b * tiles_img;
+      const int ty = trem / pr.tiles_x, tx = trem - ty * pr.tiles_x;
+      const int pl = tid / QP, c = K1 + (tid - pl * QP) * 4;
+      const int gy = ty * 4 + (pl >> 4), gx = tx * 16 + (pl & 15);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (c == K1 && gy < pr.H && gx < pr.W) v[0] = 1.f;
+      *reinterpret_cast<f32x4*>(xs + pl * XS + c) = v;
+    }
+  };
+
+  // ---- software pipeline over the block's tiles: tile t computes from LDS buffer t & 1 while tile t + 1 (requested during tile
+  // t - 1) is written into the other buffer and tile t + 2 is requested; two block barriers per tile ------------------------------
+  f32x4 vx[FX], vd[FD];
+  issue_tile(blockIdx.x, vx, vd);
+  store_tile(blockIdx.x, 0, vx, vd);
+  issue_tile(blockIdx.x + gridDim.x, vx, vd);
+  __syncthreads();
+  int buf = 0;
+  for (int tile = blockIdx.x; tile < q.ntiles; tile += gridDim.x, buf ^= 1) {
     const int b = tile / tiles_img;
     const int trem = tile - b * tiles_img;
     const int ty = trem / pr.tiles_x, tx = trem - ty * pr.tiles_x;
-    const int y0 = ty * 2, x0 = tx * 16;
+    const int y0 = ty * 4, x0 = tx * 16;
+    const float* const xs = xs0 + buf * (P * XS);
+    const float* const drs = drs0 + buf * (P * DS);
+    mark(0);
 
-    // W1 fragments of stage R are requested before the tile is staged (they depend on nothing of it)
-    f32x4 bf1[NS1][4];
-#pragma unroll
-    for (int s = 0; s < NS1; ++s) {
-      const bool live = 16 * s + 4 * kq < K1;
-#pragma unroll
-      for (int n = 0; n < 4; ++n) bf1[s][n] = buf_load4(w1_rs, live ? woff1[n] : BUF_OOB, (unsigned)(64 * s));
-    }
-
-    // ---- stage 0: x tile and dr tile -> LDS -----------------------------------------------------------------------------
-    {
-      const size_t img = (size_t)b * pr.H * pr.W;
-      const __amdgpu_buffer_rsrc_t x_rs = buf_rsrc(pr.in + img * pr.in_stride);
-      const __amdgpu_buffer_rsrc_t d_rs = buf_rsrc(pa.in + img * pa.in_stride);
-      constexpr int QX = K1 / 4, QD = K2 / 4;
-      constexpr int FX = (P * QX + 255) / 256, FD = (P * QD + 255) / 256;
-      f32x4 vx[FX], vd[FD];
-#pragma unroll
-      for (int u = 0; u < FX; ++u) {
-        const int f = tid + 256 * u;
-        const int pl = f / QX, c = (f - pl * QX) * 4;
-        const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
-        const unsigned off = (f < P * QX && gy < pr.H && gx < pr.W) ? (unsigned)(((gy * pr.W + gx) * pr.in_stride + c) * 4) : BUF_OOB;
-        vx[u] = buf_load4(x_rs, off, 0u);
-      }
-#pragma unroll
-      for (int u = 0; u < FD; ++u) {
-        const int f = tid + 256 * u;
-        const int pl = f / QD, c = (f - pl * QD) * 4;
-        const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
-        const unsigned off = (f < P * QD && gy < pa.H && gx < pa.W) ? (unsigned)(((gy * pa.W + gx) * pa.in_stride + c) * 4) : BUF_OOB;
-        vd[u] = buf_load4(d_rs, off, 0u);
-      }
-#pragma unroll
-      for (int u = 0; u < FX; ++u) {
-        const int f = tid + 256 * u;
-        const int pl = f / QX, c = (f - pl * QX) * 4;
-        if (f < P * QX) *reinterpret_cast<f32x4*>(xs + pl * XS + c) = vx[u];
-      }
-#pragma unroll
-      for (int u = 0; u < FD; ++u) {
-        const int f = tid + 256 * u;
-        const int pl = f / QD, c = (f - pl * QD) * 4;
-        if (f < P * QD) *reinterpret_cast<f32x4*>(drs + pl * DS + c) = vd[u];
-      }
-      // behind the K1 channels: a 1 for pixels inside the image (db1 = sum_p dh rides on the MFMAs of stage W1), zeros after it
-      constexpr int QP = (SH::XD - K1) / 4;
-      if (tid < P * QP) {
-        const int pl = tid / QP, c = K1 + (tid - pl * QP) * 4;
-        const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (c == K1 && gy < pr.H && gx < pr.W) v[0] = 1.f;
-        *reinterpret_cast<f32x4*>(xs + pl * XS + c) = v;
-      }
-    }
-    __syncthreads();                                 // (A) tiles staged; the previous tile's epilogue is done with T
-
-    // ---- stage R: h[P][64 of this wave] = relu(x W1^T + b1) -> hs ---------------------------------------------------------
-    // (one row tile at a time: the two row tiles share the weight fragments, and 32 accumulator registers are live instead of 64;
-    // every accumulator still sees the k-steps in the order conv_pair_k1_kernel feeds them)
+    // ---- stage R: h[P][32 of this wave] = relu(x W1^T + b1) -> hs (one row tile at a time; every accumulator sees the k-steps in
+    // the order conv_pair_k1_kernel feeds them, so this h is bitwise the h of the forward pass) ---------------------------------
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      f32x4 accs[2][4];
+      f32x4 accs[2][2];
 #pragma unroll
       for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) accs[k][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < 2; ++n) accs[k][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < NS1; ++s) {
         const f32x4 af = *reinterpret_cast<const f32x4*>(xs + (m * 16 + li) * XS + 16 * s + 4 * kq);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int n = 0; n < 4; ++n)
+          for (int n = 0; n < 2; ++n)
             accs[j % 2][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf1[s][n][j], accs[j % 2][n], 0, 0, 0);
       }
 #pragma unroll
-      for (int n = 0; n < 4; ++n)
+      for (int n = 0; n < 2; ++n)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float v = (accs[0][n][r] + accs[1][n][r]) + b1q[n];
           hs[(m * 16 + 4 * kq + r) * HS + cw + n * 16 + li] = fmaxf(v, 0.f);
         }
     }
-    // W2 fragments of stage 2: requested now, used after the MFMAs of stage W2
-    f32x4 bf2[NS2][4];
-#pragma unroll
-    for (int s = 0; s < NS2; ++s)
-#pragma unroll
-      for (int n = 0; n < 4; ++n) bf2[s][n] = buf_load4(w2_rs, woff2[n], (unsigned)(64 * s));
+    mark(1);
 
-    // ---- stage W2: dW2[n][c] += sum_p dr[p][n] h[p][c] over this wave's 64 channels (wave-private columns of hs) ----------
-#pragma unroll
+    // ---- stage W2: dW2[n][c] += sum_p dr[p][n] h[p][c] over this wave's 32 channels (wave-private columns of hs): one 8-byte LDS
+    // read per lane supplies the A operands of two row tiles (row i of tile t <-> channel cw + 2 i + t), k = 4 pixels per MFMA ----
+#pragma unroll 4
     for (int ks = 0; ks < P / 4; ++ks) {
-      const f32x4 a4 = *reinterpret_cast<const f32x4*>(hs + (4 * ks + kq) * HS + cw + 4 * li);
+      const f32x2 a2 = *reinterpret_cast<const f32x2*>(hs + (4 * ks + kq) * HS + cw + 2 * li);
       float bu[NU2];
 #pragma unroll
       for (int u = 0; u < NU2; ++u) bu[u] = drs[(4 * ks + kq) * DS + 16 * u + li];
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int u = 0; u < NU2; ++u)
-          accW2[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t], bu[u], accW2[t][u], 0, 0, 0);
+          accW2[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[t], bu[u], accW2[t][u], 0, 0, 0);
     }
     {   // db2 partial: thread (column tid % 64, pixel group tid / 64)
       const int col = tid & 63;
       if (col < K2) {
 #pragma unroll
-        for (int i = 0; i < P / 4; ++i) accb2 += drs[(wave * (P / 4) + i) * DS + col];
+        for (int i = 0; i < P / 8; ++i) accb2 += drs[(wave * (P / 8) + i) * DS + col];
       }
     }
+    mark(2);
 
     // ---- stage 2: dh = (dr W2) . [h > 0], in place over this wave's columns of hs ----------------------------------------
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      f32x4 accs[2][4];
+      f32x4 accs[2][2];
 #pragma unroll
       for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) accs[k][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < 2; ++n) accs[k][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < NS2; ++s) {
         const f32x4 af = *reinterpret_cast<const f32x4*>(drs + (m * 16 + li) * DS + 16 * s + 4 * kq);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int n = 0; n < 4; ++n)
+          for (int n = 0; n < 2; ++n)
             accs[j % 2][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf2[s][n][j], accs[j % 2][n], 0, 0, 0);
       }
 #pragma unroll
-      for (int n = 0; n < 4; ++n)
+      for (int n = 0; n < 2; ++n)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float* const e = hs + (m * 16 + 4 * kq + r) * HS + cw + n * 16 + li;
@@ -258,10 +307,44 @@ __global__ __launch_bounds__(256, 2) void conv_sub1_bwd_kernel(Sub1Dev q) {
           *e = *e > 0.f ? v : 0.f;
         }
     }
-    __syncthreads();                                 // (C) the whole dh tile is in LDS
+    mark(3);
+    // the next tile (requested one tile ago) -> the other LDS buffer; the tile after it is requested
+    if (tile + (int)gridDim.x < q.ntiles) {
+      store_tile(tile + gridDim.x, buf ^ 1, vx, vd);
+      mark(10);
+      issue_tile(tile + 2 * gridDim.x, vx, vd);
+    }
+    // side inputs of this tile's epilogue: requested HERE -- half a tile after the previous tile's epilogue stores and half a tile
+    // before they are used.  One counter covers vector loads and stores on this chip and a register that is the data or address
+    // of a store in flight may not be overwritten before the store has completed: requested at the top of the tile, these loads
+    // waited for the previous epilogue's stores (9 k clocks per tile in the phase stamps).  Raw buffer loads relative to the
+    // image (a quad outside the image / beyond N carries BUF_OOB and reads zeros): no branch around a load.
+    const int e_gy = y0 + (e_pl >> 4), e_gx = x0 + (e_pl & 15);
+    const bool e_live = e_fast && e_col < pb.N && e_gy < pb.H && e_gx < pb.W;
+    const size_t e_img = (size_t)b * pb.H * pb.W;
+    const unsigned e_ip = (unsigned)(e_gy * pb.W + e_gx);            // pixel inside the image
+    const size_t e_pix = e_img + e_ip;
+    f32x4 e_ad, e_u, e_s;
+    {
+      const __amdgpu_buffer_rsrc_t ad_rs = buf_rsrc(pb.addend + e_img * pb.addend_stride);
+      if (pb.addend_map) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          e_ad[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ad_rs, (int)(e_live ? (e_ip * pb.addend_stride + amap[j]) * 4u : BUF_OOB), 0, 0));
+      } else {
+        e_ad = buf_load4(ad_rs, e_live ? (e_ip * pb.addend_stride + e_col) * 4u : BUF_OOB, 0u);
+      }
+      const bool cb = e_live && e_cbwd;
+      e_u = buf_load4(buf_rsrc((e_cbwd ? pb.v : pb.addend) + e_img * (e_cbwd ? pb.v_stride : 0)), cb ? (e_ip * pb.v_stride + e_col) * 4u : BUF_OOB, 0u);
+      e_s = buf_load4(buf_rsrc((e_cbwd ? pb.sbuf : pb.addend) + e_img * (e_cbwd ? pb.Co : 0)), cb ? (e_ip * pb.Co + e_col) * 4u : BUF_OOB, 0u);
+    }
+    __builtin_amdgcn_sched_barrier(0);               // the requests above stay above: their latency is what stage 3 / W1 hide
+    mark(11);
+    __syncthreads();                                 // (C) the whole dh tile is in LDS (and the next tile's x / dr)
+    mark(12);
 
-    // ---- stage 3: dx tile = dh W1 (K = 256): wave -> row tile wave % 2, column tile wave / 2 (as conv_pair_k1_kernel) ---------
-    const int mt3 = wave & 1, nt3 = wave >> 1;
+    // ---- stage 3: dx tile = dh W1 (K = 256): wave -> row tile wave % 4, column tile wave / 4; the k order of conv_pair_k1_kernel ---
+    const int mt3 = wave & 3, nt3 = wave >> 2;
     f32x4 acc3[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc3[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -274,23 +357,23 @@ __global__ __launch_bounds__(256, 2) void conv_sub1_bwd_kernel(Sub1Dev q) {
         for (int j = 0; j < 4; ++j) acc3[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[j], acc3[j], 0, 0, 0);
       }
     }
-    // ---- stage W1: dW1[n][c] += sum_p dh[p][n] [x | 1][p][c] over this wave's 64 hidden channels ---------------------------
-#pragma unroll
+    mark(4);
+    // ---- stage W1: dW1[n][c] += sum_p dh[p][n] [x | 1][p][c] over this wave's 32 hidden channels ---------------------------
+#pragma unroll 4
     for (int ks = 0; ks < P / 4; ++ks) {
-      const f32x4 a4 = *reinterpret_cast<const f32x4*>(hs + (4 * ks + kq) * HS + cw + 4 * li);
+      const f32x2 a2 = *reinterpret_cast<const f32x2*>(hs + (4 * ks + kq) * HS + cw + 2 * li);
       float bu[NU1];
 #pragma unroll
       for (int u = 0; u < NU1; ++u) bu[u] = xs[(4 * ks + kq) * XS + 16 * u + li];
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int u = 0; u < NU1; ++u)
-          accW1[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t], bu[u], accW1[t][u], 0, 0, 0);
+          accW1[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[t], bu[u], accW1[t][u], 0, 0, 0);
     }
-    __syncthreads();                                 // (D) every wave is done with hs, xs, drs
+    mark(5);
     if (!q.no_dx) {
       constexpr int TS = NP1 + 4;
-      float* const T = hs;
       if (nt3 < NT2) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -300,35 +383,85 @@ __global__ __launch_bounds__(256, 2) void conv_sub1_bwd_kernel(Sub1Dev q) {
           T[(mt3 * 16 + 4 * kq + r) * TS + nt3 * 16 + li] = v;
         }
       }
-      __syncthreads();                               // (E)
-      conv_epilogue_tile<2, NP1, 8, 256>(pb, T, b, y0, x0, 0, tid, red);
     }
+    mark(13);
+    __syncthreads();                                 // (E) the dx tile is in T; every wave is done with hs and this tile's x / dr
+    mark(14);
+    // the side inputs are waited for HERE, by every wave and before any store is issued: a wave that skipped the epilogue below
+    // (no live quad) would otherwise carry the pending loads to the top of the next tile, where the first instruction that reuses
+    // one of their registers has to wait for them -- and, the counter being shared and in order, for this tile's stores
+    asm volatile("" :: "v"(e_ad), "v"(e_u), "v"(e_s));
+    if (!q.no_dx) {
+      constexpr int TS = NP1 + 4;
+      if (e_live) {
+        f32x4 val = *reinterpret_cast<const f32x4*>(T + e_pl * TS + e_col);
+        val += e_bq;
+        if (pb.addend_map) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) val[j] += e_ad[j];
+        } else {
+          val += e_ad;
+        }
+        if (!e_cbwd) {
+          *reinterpret_cast<f32x4*>(pb.out + e_pix * pb.out_stride + e_col) = val;
+        } else {
+          const float gl = pb.logdet ? pb.logdet[b] : 0.f;
+          f32x4 o_a, o_b, o_c;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float g = val[j], u = e_u[j], sv = e_s[j];
+            const float L = glow_log_e(sv, pb.clamp), dL = glow_dlog_e(sv, pb.clamp);
+            const float e = expf(L);
+            if (emode == SININN_CONV_ADD_CBWD_FWD) { o_c[j] = g * e; o_b[j] = g; o_a[j] = (g * u * e + gl) * dL; }
+            else { o_c[j] = g / e; o_b[j] = -o_c[j]; o_a[j] = -(g * u + gl) * dL; }
+          }
+          *reinterpret_cast<f32x4*>(pb.out + e_pix * pb.out_stride + e_col) = o_a;
+          *reinterpret_cast<f32x4*>(pb.out + e_pix * pb.out_stride + pb.Co + e_col) = o_b;
+          *reinterpret_cast<f32x4*>(pb.out2 + e_pix * pb.out2_stride + e_col) = o_c;
+        }
+      }
+    }
+    mark(6);
+    if (stamping) ph[9] += 1u;
   }
 
   // ---- the block's partial gradients -> its slab ------------------------------------------------------------------------------
   float* const slab = q.slab + (size_t)blockIdx.x * SH::SLAB;
-  // lane (li, kq), row tile t, register r of dW2's tile u holds dW2[n = 16 u + li][c = cw + 16 kq + 4 r + t]: the four t are four
+  // lane (li, kq), row tile t, register r of dW2's tile u holds dW2[n = 16 u + li][c = cw + 8 kq + 2 r + t]: the two t are two
   // consecutive channels of one OIHW row
 #pragma unroll
   for (int u = 0; u < NU2; ++u)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const f32x4 v = {accW2[0][u][r], accW2[1][u][r], accW2[2][u][r], accW2[3][u][r]};
-      *reinterpret_cast<f32x4*>(slab + (16 * u + li) * S1_HID + cw + 16 * kq + 4 * r) = v;
+      const f32x2 v = {accW2[0][u][r], accW2[1][u][r]};
+      *reinterpret_cast<f32x2*>(slab + (16 * u + li) * S1_HID + cw + 8 * kq + 2 * r) = v;
     }
   float* const slab1 = slab + K2 * S1_HID;
-  // ... and of dW1's tile u: dW1[n = cw + 16 kq + 4 r + t][c = 16 u + li]
+  // ... and of dW1's tile u: dW1[n = cw + 8 kq + 2 r + t][c = 16 u + li], written TRANSPOSED as [c][n] so that the two t are again
+  // two consecutive floats (8-byte stores like dW2's; the reduce kernel puts the 256 x K1 matrix back into OIHW order)
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int u = 0; u < NU1; ++u)
 #pragma unroll
-    for (int u = 0; u < NU1; ++u)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) slab1[(cw + 16 * kq + 4 * r + t) * SH::W1S + 16 * u + li] = accW1[t][u][r];
-  // db2: the four pixel groups of a column in a fixed order
+    for (int r = 0; r < 4; ++r) {
+      const f32x2 v = {accW1[0][u][r], accW1[1][u][r]};
+      *reinterpret_cast<f32x2*>(slab1 + (16 * u + li) * S1_HID + cw + 8 * kq + 2 * r) = v;
+    }
+  // db2: the eight pixel groups of a column in a fixed order
   __syncthreads();
   hs[tid] = accb2;
   __syncthreads();
-  if (tid < 64) slab[K2 * S1_HID + S1_HID * SH::W1S + tid] = tid < K2 ? ((hs[tid] + hs[64 + tid]) + (hs[128 + tid] + hs[192 + tid])) : 0.f;
+  if (tid < 64)
+    slab[K2 * S1_HID + S1_HID * SH::W1S + tid] =
+        tid < K2 ? (((hs[tid] + hs[64 + tid]) + (hs[128 + tid] + hs[192 + tid])) + ((hs[256 + tid] + hs[320 + tid]) + (hs[384 + tid] + hs[448 + tid]))) : 0.f;
+  if constexpr (STAMP) {
+    if (stamping) {
+      mark(7);
+      ph[8] = (unsigned)(tprev - tstart);
+      unsigned long long* const w = pb.stamp + (tid == 0 ? 0 : 16);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) atomicAdd(w + k, (unsigned long long)ph[k]);
+    }
+  }
 }
 
 // gw2 / gb2 / gw1 / gb1 += sum over the slabs, in a fixed association: eight interleaved groups of slabs, each summed in
@@ -364,11 +497,11 @@ __global__ __launch_bounds__(256) void sub1_reduce_kernel(const float* __restric
         }
       }
     } else if (e < E2 + E1) {
-      const int idx = (e - E2) * 4, n = idx / SH::W1S, c = idx - n * SH::W1S;
+      const int idx = (e - E2) * 4, c = idx / S1_HID, n = idx - c * S1_HID;     // slab row c = input channel (row K1: db1), 4 outputs n
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (c + j < K1) { if (gw1) gw1[n * K1 + c + j] += tot[j]; }
-        else if (c + j == K1) { if (gb1) gb1[n] += tot[j]; }
+        if (c < K1) { if (gw1) gw1[(n + j) * K1 + c] += tot[j]; }
+        else if (c == K1) { if (gb1) gb1[n + j] += tot[j]; }
       }
     } else if (gb2) {
       const int idx = (e - E2 - E1) * 4;
@@ -401,14 +534,14 @@ size_t conv_sub1_bwd_workspace_bytes(int cond_cin, int co) {
 template <int K1, int K2>
 static int sub1_launch(Sub1Dev& q, int* blocks_out, hipStream_t st) {
   using SH = Sub1Shape<K1, K2>;
-  auto k = conv_sub1_bwd_kernel<K1, K2>;
-  static_assert(SH::LDS <= 80 * 1024, "conv_sub1_bwd: two blocks per CU need <= 80 KB of LDS each");
+  auto k = q.b.stamp ? conv_sub1_bwd_kernel<K1, K2, (K1 == 24)> : conv_sub1_bwd_kernel<K1, K2, false>;
+  static_assert(SH::LDS <= 160 * 1024, "conv_sub1_bwd: LDS");
   if (SH::LDS > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SH::LDS);
     if (e != hipSuccess) { set_error("conv_sub1_bwd: cannot raise the LDS limit to %zu", SH::LDS); return 1; }
   }
   const int blocks = q.ntiles < S1_MAX_BLOCKS ? q.ntiles : S1_MAX_BLOCKS;
-  hipLaunchKernelGGL(k, dim3(blocks), dim3(256), SH::LDS, st, q);
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(S1_NTHR), SH::LDS, st, q);
   SININN_LAUNCH_CHECK("conv_sub1_bwd");
   *blocks_out = blocks;
   return 0;
@@ -441,6 +574,17 @@ int conv_sub1_bwd_launch(const sininn_conv_args* rc, const sininn_conv_args* d2,
                "conv_sub1_bwd: one image of an operand exceeds the 2 GB a block addresses (raw buffer staging)");
   SININN_CHECK(ws_bytes >= conv_sub1_bwd_workspace_bytes(K1, K2 / 2), "conv_sub1_bwd: workspace too small (%zu < %zu)", ws_bytes,
                conv_sub1_bwd_workspace_bytes(K1, K2 / 2));
+  if (!no_dx) {
+    // the kernel's own epilogue (one quad per thread, side inputs requested a tile ahead) serves the modes the block executor uses
+    const bool cbwd = d1->mode == SININN_CONV_ADD_CBWD_FWD || d1->mode == SININN_CONV_ADD_CBWD_INV;
+    SININN_CHECK(cbwd || d1->mode == SININN_CONV_ADD, "conv_sub1_bwd: d1->mode must be ADD or ADD_CBWD_* (got %d)", d1->mode);
+    SININN_CHECK(d1->mask == nullptr && d1->out_map == nullptr && d1->out && d1->addend && d1->out_stride % 4 == 0 && aligned16(d1->out) &&
+                 (d1->addend_map != nullptr || (d1->addend_stride % 4 == 0 && aligned16(d1->addend))) && (!d1->bias || aligned16(d1->bias)),
+                 "conv_sub1_bwd: d1 needs 16-byte aligned out / addend with strides that are multiples of 4, no mask, no out_map");
+    if (cbwd)
+      SININN_CHECK(d1->Co % 4 == 0 && d1->v_stride % 4 == 0 && d1->out2_stride % 4 == 0 && d1->v && d1->sbuf && d1->out2 && aligned16(d1->v) &&
+                   aligned16(d1->sbuf) && aligned16(d1->out2), "conv_sub1_bwd: ADD_CBWD needs 16-byte aligned v / sbuf / out2");
+  }
   Sub1Dev q;
   alignas(16) static float dummy[4] = {0.f, 0.f, 0.f, 0.f};   // conv_prepare insists on pointers the kernel never follows
   sininn_conv_args ra = *rc;
@@ -454,11 +598,12 @@ int conv_sub1_bwd_launch(const sininn_conv_args* rc, const sininn_conv_args* d2,
   if (no_dx) { db.mode = SININN_CONV_LINEAR; db.out = dummy; db.out_stride = K1; db.addend = nullptr; db.addend_map = nullptr; }
   if (int e = conv_prepare(&db, q.b)) return e;
   q.r.tiles_x = q.a.tiles_x = q.b.tiles_x = (rc->W + 15) / 16;
-  q.r.tiles_y = q.a.tiles_y = q.b.tiles_y = (rc->H + 1) / 2;
+  q.r.tiles_y = q.a.tiles_y = q.b.tiles_y = (rc->H + 3) / 4;
   q.ntiles = q.r.tiles_x * q.r.tiles_y * rc->B;
   q.no_dx = no_dx ? 1 : 0;
   q.slab = static_cast<float*>(ws);
-  q.r.stamp = q.a.stamp = q.b.stamp = nullptr;
+  q.r.stamp = q.a.stamp = nullptr;
+  q.b.stamp = d1->stamp;                          // diagnostic phase stamps (10 words)
   if (K1 == 8) return sub1_launch<8, 16>(q, slabs_out, st);
   if (K1 == 16) return sub1_launch<16, 32>(q, slabs_out, st);
   return sub1_launch<24, 48>(q, slabs_out, st);

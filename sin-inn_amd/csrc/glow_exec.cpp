@@ -332,7 +332,10 @@ int glow_hidden_gates(const sininn_glow_args* a, int which, unsigned char* gates
   const int gm = group_major_hidden(a, hv[which].net) ? 1 : 0;
   {
     // a subnet whose backward recomputes h (conv_sub1_bwd.hip) did not store it: conv1 is run again into the (reserved, unused)
-    // slot of `saved` -- from the input the forward pass read: x for the first half, the saved compact output for the second
+    // slot of `saved` -- from the input the forward pass read: x for the first half, the saved compact output for the second --
+    // and with the arithmetic the forward pass and the backward recompute use: stage 1 of the pair kernel (a stand-alone conv
+    // sums in another order, and a unit within rounding distance of 0 would then report a gate the passes did not take).  The
+    // pair's second conv is a throw-away linear conv into the other, equally unused hidden slot.
     const int cond_cin = which == 0 ? a->C - hv[0].co : hv[0].co;
     if (fused_sub1(a, cond_cin, hv[which].co)) {
       sininn_conv_args c1 = {};
@@ -341,7 +344,12 @@ int glow_hidden_gates(const sininn_glow_args* a, int which, unsigned char* gates
       c1.Cin = cond_cin; c1.w = hv[which].net->w1; c1.bias = hv[which].net->b1; c1.Np = SININN_HIDDEN;
       c1.B = a->B; c1.H = a->H; c1.W = a->W; c1.ksize = 1; c1.mode = SININN_CONV_RELU;
       c1.out = h; c1.out_stride = SININN_HIDDEN; c1.N = SININN_HIDDEN;
-      if (int rc = conv_launch(&c1, st)) return rc;
+      sininn_conv_args c2 = {};
+      c2.in = h; c2.in_stride = SININN_HIDDEN; c2.Cin = SININN_HIDDEN; c2.w = hv[which].net->w2; c2.Np = 2 * hv[which].co;
+      c2.B = a->B; c2.H = a->H; c2.W = a->W; c2.ksize = 1; c2.mode = SININN_CONV_LINEAR;
+      c2.out = which == 0 ? sv.h_b : sv.h_a; c2.out_stride = 2 * hv[which].co; c2.N = 2 * hv[which].co;
+      SININN_CHECK(conv_pair_k1_supported(&c1, &c2), "glow_hidden_gates: the 1x1 pair kernel is switched off (needed to reproduce the recomputed h)");
+      if (int rc = conv_pair_k1_launch(&c1, &c2, st)) return rc;
     }
   }
   const int64_t total = (int64_t)M * SININN_HIDDEN;

@@ -1,0 +1,94 @@
+"""Per-launch time and phase split of the fused 1x1 subnet backward (sininn_conv_sub1_bwd) at a level-0 shape, beside the
+launches it replaces (data-gradient pair + the two weight gradients).   python tools/bench_sub1.py [--b 16 --hw 64]"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--b', type=int, default=16)
+    ap.add_argument('--hw', type=int, default=64)
+    ap.add_argument('--co', type=int, default=24)
+    ap.add_argument('--reps', type=int, default=20)
+    ap.add_argument('--no-dx', action='store_true')
+    a = ap.parse_args()
+    import sin_inn_amd
+    from sin_inn_amd import _lib, ops
+    lib = _lib.lib()
+    dev = torch.device('cuda')
+    co, b, h, w = a.co, a.b, a.hw, a.hw
+    k1, k2, m = co, 2 * co, b * h * w
+    torch.manual_seed(0)
+    x = torch.randn(m, 2 * co, device=dev)
+    conv1 = torch.nn.Conv2d(k1, 256, 1).to(dev)
+    conv2 = torch.nn.Conv2d(256, k2, 1).to(dev)
+    pk1 = ops.pack_conv(conv1.weight.detach(), conv1.bias.detach(), None, True)
+    pk2 = ops.pack_conv(conv2.weight.detach(), conv2.bias.detach(), ops.coupling_colmap(co, dev), True)
+    dr = torch.randn(m, k2, device=dev)
+    addend = torch.randn(m, k1, device=dev)
+    hid = torch.randn(m, 256, device=dev)
+    dh = torch.empty(m, 256, device=dev)
+    dx = torch.empty(m, k1, device=dev)
+    gw2, gb2 = torch.zeros(k2, 256, 1, 1, device=dev), torch.zeros(k2, device=dev)
+    gw1, gb1 = torch.zeros(256, k1, 1, 1, device=dev), torch.zeros(256, device=dev)
+    stamps = torch.zeros(32, dtype=torch.int64, device=dev)
+
+    def args(**kw):
+        q = _lib.ConvArgs()
+        for k, v in kw.items():
+            setattr(q, 'inp' if k == 'in_' else k, v)
+        return q
+    common = dict(B=b, H=h, W=w, ksize=1)
+    rc = args(in_=ops.ptr(x, co), in_stride=2 * co, Cin=k1, w=ops.ptr(pk1[0]), bias=ops.ptr(pk1[1]), Np=256, **common)
+    d2 = args(in_=ops.ptr(dr), in_stride=k2, Cin=k2, w=ops.ptr(pk2[2]), Np=256, mode=_lib.CONV_MASK, out=ops.ptr(dh), out_stride=256,
+              N=256, mask=ops.ptr(hid), mask_stride=256, **common)
+    d1 = args(in_=ops.ptr(dh), in_stride=256, Cin=256, w=ops.ptr(pk1[2]), Np=ops.pad16(k1), mode=_lib.CONV_ADD, out=ops.ptr(dx),
+              out_stride=k1, N=k1, addend=ops.ptr(addend), addend_stride=k1, **common)
+    nbytes = lib.sininn_conv_sub1_bwd_workspace_bytes(k1, co)
+    ws = torch.empty(nbytes // 4, device=dev)
+
+    def fused(stamp=False):
+        d1.stamp = stamps.data_ptr() if stamp else None
+        _lib.check(lib.sininn_conv_sub1_bwd(C.byref(rc), C.byref(d2), C.byref(d1), int(a.no_dx), ops.ptr(gw2), ops.ptr(gb2), ops.ptr(gw1),
+                                            ops.ptr(gb1), ops.ptr(ws), nbytes, ops._stream()))
+        d1.stamp = None
+
+    def old():
+        _lib.check(lib.sininn_conv_pair_k1(C.byref(d2), C.byref(d1), ops._stream()))
+        ops.wgrad_group([(hid, 0, 256, 256, dr, 0, k2, k2, gw2, gb2), (x, co, 2 * co, k1, dh, 0, 256, 256, gw1, gb1)], b, h, w, 1)
+
+    def timeit(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / a.reps * 1e3
+    print(f'shape: batch {b}, {h}x{w}, Cin {k1}, 2Co {k2}: M = {m}')
+    print(f'fused backward + reduce : {timeit(fused):8.1f} us')
+    print(f'pair + grouped wgrad    : {timeit(old):8.1f} us')
+    stamps.zero_()
+    fused(True)
+    torch.cuda.synchronize()
+    st = stamps.cpu().tolist()
+    names = ['staging (+ barrier A)', 'stage R', 'stage W2 + db2', 'stage 2 (+ mask RMW)', 'barrier C + stage 3', 'stage W1',
+             'barrier D + T + epilogue', 'slab write', 'total']
+    tiles = max(st[9], 1)
+    names += ['(tiles)', 'store_tile (vmcnt wait + LDS writes)', 'issue next + side loads', 'barrier C', 'T write', 'barrier E']
+    print(f'phase clocks per tile ({tiles} tiles):                      wave 0      wave 7')
+    for i, n in enumerate(names):
+        if i != 9:
+            print(f'  {i:2d} {n:40s} {st[i] / tiles:10.0f}  {st[16 + i] / tiles:10.0f}')
+
+
+if __name__ == '__main__':
+    main()
