@@ -183,6 +183,15 @@ int sininn_conv(const sininn_conv_args* args, void* stream);
 int sininn_conv_pair_k1_supported(const sininn_conv_args* first, const sininn_conv_args* second);
 int sininn_conv_pair_k1(const sininn_conv_args* first, const sininn_conv_args* second, void* stream);
 
+/* The fp32 1x1 subnet + affine coupling + log-det of a GLOW half-coupling as ONE persistent launch (round 4; subnet_conv_1x1,
+ * archs.py:15-17, inside FrEIA's GLOWCouplingBlock, archs.py:56-64): the twin of sininn_conv_pair_k1 for the shapes
+ * (Cin of conv1, 2 Co) in {(8, 16), (16, 32), (24, 48)} -- level 0 of the SRF network.  A block per CU keeps conv2's pack in LDS and
+ * its conv1 fragments in registers over all of its 64-pixel tiles; the hidden tensor is never stored (first->out is ignored: the
+ * matching backward, sininn_conv_sub1_bwd, recomputes it).  first: mode RELU; second: mode COUPLE_FWD / COUPLE_INV, described as
+ * for sininn_conv_pair_k1.  Same values as the pair up to fp32 summation order (K = 256 is summed in two halves). */
+int sininn_conv_sub1_fwd_supported(const sininn_conv_args* first, const sininn_conv_args* second);
+int sininn_conv_sub1_fwd(const sininn_conv_args* first, const sininn_conv_args* second, void* stream);
+
 /* The whole BACKWARD of a fp32 1x1 conv subnet of a GLOW half-coupling in one persistent launch + one slab reduce (round 4;
  * subnet_conv_1x1, archs.py:15-17, differentiated inside FrEIA's GLOWCouplingBlock, archs.py:56-64):
  *   h = relu(x W1^T + b1) is RECOMPUTED from the subnet's input (the forward pass need not store it: pass first->out == NULL to

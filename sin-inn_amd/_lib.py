@@ -151,6 +151,8 @@ _SIGS = {
     'sininn_conv_sub3_supported': (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs)]),
     'sininn_conv_sub3': (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs), C.c_void_p]),
     'sininn_conv_pair_k1': (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs), C.c_void_p]),
+    'sininn_conv_sub1_fwd_supported': (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs)]),
+    'sininn_conv_sub1_fwd': (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs), C.c_void_p]),
     'sininn_conv_sub1_bwd_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int]),
     'sininn_conv_sub1_bwd': (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs), C.POINTER(ConvArgs), C.c_int, c_f, c_f, c_f, c_f,
                                        C.c_void_p, C.c_size_t, C.c_void_p]),

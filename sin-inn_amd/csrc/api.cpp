@@ -25,6 +25,8 @@ int conv_sub1_bwd_launch(const sininn_conv_args* rc, const sininn_conv_args* d2,
                          size_t ws_bytes, int* slabs_out, hipStream_t st);
 int conv_sub1_bwd_reduce(int cond_cin, int co, const void* ws, int slabs, float* gw2, float* gb2, float* gw1, float* gb1, hipStream_t st);
 void conv_sub1_bwd_enable(int on);
+int conv_sub1_fwd_supported(const sininn_conv_args* f, const sininn_conv_args* s);
+int conv_sub1_fwd_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st);
 int conv_pair_k1_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st);
 void conv_pair_k1_enable(int on);
 int conv_sub3_bf16_supported(const sininn_conv_args* f, const sininn_conv_args* s);
@@ -298,6 +300,8 @@ int sininn_conv_pair_k1(const sininn_conv_args* first, const sininn_conv_args* s
   return conv_pair_k1_launch(first, second, ST(stream));
 }
 
+int sininn_conv_sub1_fwd_supported(const sininn_conv_args* first, const sininn_conv_args* second) { return conv_sub1_fwd_supported(first, second); }
+int sininn_conv_sub1_fwd(const sininn_conv_args* first, const sininn_conv_args* second, void* stream) { return conv_sub1_fwd_launch(first, second, ST(stream)); }
 size_t sininn_conv_sub1_bwd_workspace_bytes(int cin, int co) { return conv_sub1_bwd_workspace_bytes(cin, co); }
 int sininn_conv_sub1_bwd(const sininn_conv_args* recompute, const sininn_conv_args* d2, const sininn_conv_args* d1, int no_dx,
                          float* gw2, float* gb2, float* gw1, float* gb1, void* workspace, size_t workspace_bytes, void* stream) {

@@ -464,6 +464,164 @@ __global__ __launch_bounds__(S1_NTHR) void conv_sub1_bwd_kernel(Sub1Dev q) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The FORWARD of the same subnet + affine coupling + log-det, persistent (north_star's fused coupling kernel for the 1x1 subnets):
+//     h = relu(x W1^T + b1)  ->  (s | t) = h W2^T + b2  ->  y = e(s) v + t  (inverse: (v - t) / e(s)),  log-det += sum log e(s)
+// The pair kernel it replaces at these shapes (conv_pair_k1_kernel, 2048 blocks of 32 pixels) spends 58 - 62 us per launch on
+// 15 us of MFMA work: every block walks K = 256 of the second GEMM through a chain of L2 round trips for the weight fragments.
+// Here a block (512 threads, one per CU) keeps W2's pack in LDS and its W1 fragments in registers for all of its 64-pixel tiles:
+//   stage 1  h[64][32 of this wave] -> hs: the code of stage R above (bitwise the h the backward recomputes)
+//   stage 2  K = 256 split in two halves over the two wave quads; wave (g, m): row tile m, all column tiles, K half g;
+//            A = hs (16-byte reads), B = W2 pack rows from LDS; the two partial tiles T0 / T1 are summed by the shared
+//            coupling epilogue (conv_epilogue_tile's T2 operand): same fixed order every run
+// The next tile's x is requested one tile ahead and written into the other half of a double buffer; two block barriers per tile.
+template <int K1, int N2, int HT>
+__global__ __launch_bounds__(S1_NTHR) void conv_sub1_fwd_kernel(Sub1Dev q) {
+  constexpr int P = S1_P, MT = 4, HS = S1_HS, NTHR = S1_NTHR;
+  constexpr int K1R = (K1 + 15) / 16 * 16, XS = K1R + 4, NS1 = K1R / 16, NU2 = N2 / 16, TS = N2 + 4;
+  static_assert(K1 % 8 == 0 && K1 <= 24 && N2 % 16 == 0 && N2 <= 48, "conv_sub1_fwd: shape");
+  const ConvDev& pr = q.r;                          // conv1: in = x, w = forward pack [256][K1], bias
+  const ConvDev& pb = q.b;                          // conv2: w = forward pack [N2][256] (s | t interleaved) + the coupling epilogue
+  extern __shared__ __attribute__((aligned(16))) float smem_sub1f[];
+  float* const hs = smem_sub1f;                     // [P][HS]
+  float* const xs0 = hs + P * HS;                   // 2 x [P][XS]
+  float* const w2s = xs0 + 2 * P * XS;              // [N2][HS]
+  float* const T0 = w2s + N2 * HS;                  // 2 x [P][TS]: the two K halves of the output tile
+  float* const T1 = T0 + P * TS;
+  __shared__ float red[NTHR / 64];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, kq = lane >> 4;
+  const int cw = wave * 32;
+
+  for (int f = tid; f < N2 * (S1_HID / 4); f += NTHR) {
+    const int n = f / (S1_HID / 4), c = (f - n * (S1_HID / 4)) * 4;
+    *reinterpret_cast<f32x4*>(w2s + n * HS + c) = *reinterpret_cast<const f32x4*>(pb.w + (size_t)n * S1_HID + c);
+  }
+  float b1q[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) b1q[n] = pr.bias ? pr.bias[cw + 16 * n + li] : 0.f;
+  f32x4 bf1[NS1][2];
+  {
+    const __amdgpu_buffer_rsrc_t w1_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.w), 0, S1_HID * K1 * 4, 0x00020000);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const unsigned o1 = (unsigned)(((cw + n * 16 + li) * K1 + 4 * kq) * 4);
+#pragma unroll
+      for (int s = 0; s < NS1; ++s) bf1[s][n] = buf_load4(w1_rs, 16 * s + 4 * kq < K1 ? o1 : BUF_OOB, (unsigned)(64 * s));
+    }
+  }
+
+  constexpr int QX = K1 / 4, FX = (P * QX + NTHR - 1) / NTHR;
+  const int tiles_img = pr.tiles_x * pr.tiles_y;
+  auto issue_tile = [&](int tile, f32x4 (&vx)[FX]) {
+    const bool live = tile < q.ntiles;
+    const int b = live ? tile / tiles_img : 0;
+    const int trem = tile - b * tiles_img;
+    const int ty = trem / pr.tiles_x, tx = trem - ty * pr.tiles_x;
+    const __amdgpu_buffer_rsrc_t x_rs = buf_rsrc(pr.in + (size_t)b * pr.H * pr.W * pr.in_stride);
+#pragma unroll
+    for (int u = 0; u < FX; ++u) {
+      const int f = tid + NTHR * u;
+      const int pl = f / QX, c = (f - pl * QX) * 4;
+      const int gy = ty * 4 + (pl >> 4), gx = tx * 16 + (pl & 15);
+      const unsigned off = (live && f < P * QX && gy < pr.H && gx < pr.W) ? (unsigned)(((gy * pr.W + gx) * pr.in_stride + c) * 4) : BUF_OOB;
+      vx[u] = buf_load4(x_rs, off, 0u);
+    }
+  };
+  auto store_tile = [&](int buf, const f32x4 (&vx)[FX]) {
+    float* const xs = xs0 + buf * (P * XS);
+#pragma unroll
+    for (int u = 0; u < FX; ++u) {
+      const int f = tid + NTHR * u;
+      const int pl = f / QX, c = (f - pl * QX) * 4;
+      if (f < P * QX) *reinterpret_cast<f32x4*>(xs + pl * XS + c) = vx[u];
+    }
+    if constexpr (K1R > K1) {                        // the k-quads of stage 1 beyond K1 meet zero weights: they must hold finite values
+      constexpr int QP = (K1R - K1) / 4;
+      if (tid < P * QP) {
+        const int pl = tid / QP, c = K1 + (tid - pl * QP) * 4;
+        *reinterpret_cast<f32x4*>(xs + pl * XS + c) = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+
+  f32x4 vx[FX];
+  issue_tile(blockIdx.x, vx);
+  store_tile(0, vx);
+  issue_tile(blockIdx.x + gridDim.x, vx);
+  __syncthreads();
+  int buf = 0;
+  const int g2 = wave >> 2, m2 = wave & 3;          // stage 2: K half, row tile
+  for (int tile = blockIdx.x; tile < q.ntiles; tile += gridDim.x, buf ^= 1) {
+    const int b = tile / tiles_img;
+    const int trem = tile - b * tiles_img;
+    const int ty = trem / pr.tiles_x, tx = trem - ty * pr.tiles_x;
+    const int y0 = ty * 4, x0 = tx * 16;
+    const float* const xs = xs0 + buf * (P * XS);
+
+    // ---- stage 1 (== stage R of the backward kernel) ---------------------------------------------------------------------------
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      f32x4 accs[2][2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) accs[k][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NS1; ++s) {
+        const f32x4 af = *reinterpret_cast<const f32x4*>(xs + (m * 16 + li) * XS + 16 * s + 4 * kq);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+            accs[j % 2][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf1[s][n][j], accs[j % 2][n], 0, 0, 0);
+      }
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = (accs[0][n][r] + accs[1][n][r]) + b1q[n];
+          hs[(m * 16 + 4 * kq + r) * HS + cw + n * 16 + li] = fmaxf(v, 0.f);
+        }
+    }
+    // the next tile (requested one tile ago) -> the other buffer; the tile after it is requested
+    if (tile + (int)gridDim.x < q.ntiles) {
+      store_tile(buf ^ 1, vx);
+      issue_tile(tile + 2 * gridDim.x, vx);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                                 // (B) the whole h tile is in LDS (and the next tile's x)
+
+    // ---- stage 2: this wave's K half of out[row tile m2][all N2 columns] ---------------------------------------------------------
+    f32x4 acc[NU2];
+#pragma unroll
+    for (int u = 0; u < NU2; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int s = 0; s < S1_HID / 32; ++s) {
+      const int k0 = 128 * g2 + 16 * s + 4 * kq;
+      const f32x4 af = *reinterpret_cast<const f32x4*>(hs + (m2 * 16 + li) * HS + k0);
+      f32x4 bf[NU2];
+#pragma unroll
+      for (int u = 0; u < NU2; ++u) bf[u] = *reinterpret_cast<const f32x4*>(w2s + (u * 16 + li) * HS + k0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int u = 0; u < NU2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[u][j], acc[u], 0, 0, 0);
+    }
+    {
+      float* const T = g2 ? T1 : T0;
+#pragma unroll
+      for (int u = 0; u < NU2; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[(m2 * 16 + 4 * kq + r) * TS + u * 16 + li] = acc[u][r];
+    }
+    __syncthreads();                                 // (E) both partial tiles are in LDS; every wave is done with hs
+    conv_epilogue_tile<4, N2, HT, NTHR>(pb, T0, b, y0, x0, 0, tid, red, T1);
+  }
+}
+
 // gw2 / gb2 / gw1 / gb1 += sum over the slabs, in a fixed association: eight interleaved groups of slabs, each summed in
 // ascending order by one thread, the eight partial sums added as a balanced tree.
 template <int K1, int K2>
@@ -615,6 +773,60 @@ int conv_sub1_bwd_reduce(int cond_cin, int co, const void* ws, int slabs, float*
   if (cond_cin == 8) return sub1_reduce<8, 16>(s, slabs, gw2, gb2, gw1, gb1, st);
   if (cond_cin == 16) return sub1_reduce<16, 32>(s, slabs, gw2, gb2, gw1, gb1, st);
   return sub1_reduce<24, 48>(s, slabs, gw2, gb2, gw1, gb1, st);
+}
+
+// ---- forward --------------------------------------------------------------------------------------------------------------------
+template <int K1, int N2, int HT>
+static int sub1_fwd_launch(Sub1Dev& q, hipStream_t st) {
+  constexpr int K1R = (K1 + 15) / 16 * 16;
+  constexpr size_t lds = (size_t)(S1_P * S1_HS + 2 * S1_P * (K1R + 4) + N2 * S1_HS + 2 * S1_P * (N2 + 4)) * sizeof(float);
+  static_assert(lds + 64 <= 160 * 1024, "conv_sub1_fwd: LDS");
+  auto k = conv_sub1_fwd_kernel<K1, N2, HT>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("conv_sub1_fwd: cannot raise the LDS limit to %zu", lds); return 1; }
+  }
+  const int blocks = q.ntiles < S1_MAX_BLOCKS ? q.ntiles : S1_MAX_BLOCKS;
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(S1_NTHR), lds, st, q);
+  SININN_LAUNCH_CHECK("conv_sub1_fwd");
+  return 0;
+}
+
+// first: conv1 of the subnet (mode RELU; `out` is ignored: the hidden tensor is never stored), second: conv2 with a coupling
+// epilogue (COUPLE_FWD / COUPLE_INV), described as for sininn_conv_pair_k1.
+int conv_sub1_fwd_supported(const sininn_conv_args* f, const sininn_conv_args* s) {
+  if (!g_sub1_enabled || !f || !s) return 0;
+  if (f->ksize != 1 || s->ksize != 1 || f->w_bf16 || s->w_bf16 || f->winograd || s->winograd || f->in_bf16 || s->in_bf16 || f->out_bf16) return 0;
+  if (f->in_group_stride > 0 || f->out_group_stride > 0 || s->in_group_stride > 0) return 0;
+  if (f->mode != SININN_CONV_RELU || !(s->mode == SININN_CONV_COUPLE_FWD || s->mode == SININN_CONV_COUPLE_INV)) return 0;
+  if (f->Np != S1_HID || f->N != S1_HID || s->Cin != S1_HID) return 0;
+  if (f->B != s->B || f->H != s->H || f->W != s->W) return 0;
+  return shape_ok(f->Cin, s->Np) ? 1 : 0;
+}
+
+int conv_sub1_fwd_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st) {
+  SININN_CHECK(conv_sub1_fwd_supported(f, s), "conv_sub1_fwd: unsupported subnet (check sininn_conv_sub1_fwd_supported first)");
+  SININN_CHECK((unsigned long long)f->H * f->W * f->in_stride * 4ull < (1ull << 31),
+               "conv_sub1_fwd: one image of the input exceeds the 2 GB a block addresses (raw buffer staging)");
+  Sub1Dev q;
+  alignas(16) static float dummy[4] = {0.f, 0.f, 0.f, 0.f};
+  sininn_conv_args fa = *f;
+  fa.out = dummy; fa.out_stride = S1_HID;
+  if (int e = conv_prepare(&fa, q.r)) return e;
+  sininn_conv_args sa = *s;
+  sa.in = dummy; sa.in_stride = S1_HID;
+  if (int e = conv_prepare(&sa, q.b)) return e;
+  q.a = q.b;
+  q.r.tiles_x = q.b.tiles_x = (f->W + 15) / 16;
+  q.r.tiles_y = q.b.tiles_y = (f->H + 3) / 4;
+  q.ntiles = q.r.tiles_x * q.r.tiles_y * f->B;
+  q.no_dx = 0; q.slab = nullptr;
+  q.r.stamp = q.b.stamp = nullptr;
+  const bool ht16 = s->col_tile == 32;
+  SININN_CHECK(!ht16 || s->Co % 16 == 0, "conv_sub1_fwd: col_tile 32 needs Co %% 16 == 0");
+  if (f->Cin == 8) return ht16 ? sub1_fwd_launch<8, 16, 16>(q, st) : sub1_fwd_launch<8, 16, 8>(q, st);
+  if (f->Cin == 16) return ht16 ? sub1_fwd_launch<16, 32, 16>(q, st) : sub1_fwd_launch<16, 32, 8>(q, st);
+  return ht16 ? sub1_fwd_launch<24, 48, 16>(q, st) : sub1_fwd_launch<24, 48, 8>(q, st);
 }
 
 }  // namespace sininn

@@ -41,12 +41,14 @@ static std::mutex g_ev_mutex;
 struct EventRing { hipEvent_t ev[64]; bool ready = false; unsigned next = 0; };
 static EventRing g_rings[16];
 
-// conv_sub1_bwd.hip: the whole backward of a fp32 1x1 subnet in one persistent launch (h recomputed, dh on chip)
+// conv_sub1.hip: the whole backward of a fp32 1x1 subnet in one persistent launch (h recomputed, dh on chip)
 int conv_sub1_bwd_shape_supported(int ksize, int dtype, int cond_cin, int co);
 size_t conv_sub1_bwd_workspace_bytes(int cond_cin, int co);
 int conv_sub1_bwd_launch(const sininn_conv_args* rc, const sininn_conv_args* d2, const sininn_conv_args* d1, int no_dx, void* ws,
                          size_t ws_bytes, int* slabs_out, hipStream_t st);
 int conv_sub1_bwd_reduce(int cond_cin, int co, const void* ws, int slabs, float* gw2, float* gb2, float* gw1, float* gb1, hipStream_t st);
+int conv_sub1_fwd_supported(const sininn_conv_args* f, const sininn_conv_args* s);
+int conv_sub1_fwd_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st);
 
 int order_after(hipStream_t waiter, hipStream_t producer) {
   if (waiter == producer) return 0;
@@ -189,7 +191,7 @@ static bool group_major_hidden(const sininn_glow_args* a, const sininn_subnet* n
   return g_group_major && a->dtype == 0 && a->ksize == 3 && (net->winograd & 15) == 15 && group_major_fits(M, a->W) && wgrad_grouping_enabled();
 }
 
-// The subnet of this half runs its backward as ONE persistent launch that recomputes h (conv_sub1_bwd.hip): the forward pass then
+// The subnet of this half runs its backward as ONE persistent launch that recomputes h (conv_sub1.hip): the forward pass then
 // does not store the hidden tensor.  A property of the shape alone, so the forward and the backward call agree on it.
 static bool fused_sub1(const sininn_glow_args* a, int cond_cin, int co) {
   return conv_sub1_bwd_shape_supported(a->ksize, a->dtype, cond_cin, co) != 0;
@@ -273,7 +275,7 @@ static Scratch scratch_layout(void* basep, int B, int H, int W, int C, int ksize
   }
   s.ws = base + o;
   s.ws_bytes = w;
-  // slabs of the fused 1x1 subnet backward (conv_sub1_bwd.hip), one region per half: the reduce of the first-processed half runs
+  // slabs of the fused 1x1 subnet backward (conv_sub1.hip), one region per half: the reduce of the first-processed half runs
   // on the weight-gradient stream while the second half's kernel fills its own region
   size_t so = (o * sizeof(float) + w + 255) / 256 * 256;
   const int cond_cin[2] = {C - co_a, co_a}, cos[2] = {co_a, co_b};
@@ -331,7 +333,7 @@ int glow_hidden_gates(const sininn_glow_args* a, int which, unsigned char* gates
   float* h = which == 0 ? sv.h_a : sv.h_b;
   const int gm = group_major_hidden(a, hv[which].net) ? 1 : 0;
   {
-    // a subnet whose backward recomputes h (conv_sub1_bwd.hip) did not store it: conv1 is run again into the (reserved, unused)
+    // a subnet whose backward recomputes h (conv_sub1.hip) did not store it: conv1 is run again into the (reserved, unused)
     // slot of `saved` -- from the input the forward pass read: x for the first half, the saved compact output for the second --
     // and with the arithmetic the forward pass and the backward recompute use: stage 1 of the pair kernel (a stand-alone conv
     // sums in another order, and a unit within rounding distance of 0 would then report a gate the passes did not take).  The
@@ -409,6 +411,12 @@ int glow_forward(const sininn_glow_args* a, hipStream_t st) {
     }
     // 1x1 subnets (fp32): both convs in one launch, the hidden tile stays in LDS between them (conv_pair_k1.hip)
     const bool recompute = fused_sub1(a, c1.Cin, h.co);      // the backward recomputes h from this half's input
+    if (recompute && conv_sub1_fwd_supported(&c1, &c2)) {
+      // ... and the forward is the persistent twin of that kernel: conv1 -> conv2 -> coupling + log-det, weights resident on chip
+      ClassScope sc(PC_COUPLE, a->ksize, conv_flops(M, a->ksize, c1.Cin, SININN_HIDDEN) + conv_flops(M, a->ksize, SININN_HIDDEN, 2 * h.co), st);
+      if (int rc = conv_sub1_fwd_launch(&c1, &c2, st)) return rc;
+      continue;
+    }
     if (conv_pair_k1_supported(&c1, &c2) && (a->no_save || recompute || conv_pair_k1_preferred(&c1))) {
       if (a->no_save || recompute) c1.out = nullptr; // ... and then the hidden tensor never reaches HBM
       ClassScope sc(PC_COUPLE, a->ksize, conv_flops(M, a->ksize, c1.Cin, SININN_HIDDEN) + conv_flops(M, a->ksize, SININN_HIDDEN, 2 * h.co), st);
@@ -486,7 +494,7 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
     }
     const bool gm = group_major_hidden(a, net);
     const int gs = gm ? (int)(M * 8) : 0;
-    const bool fused = fused_sub1(a, cond_cin, h.co);       // conv_sub1_bwd.hip: its weight gradients come out of the same launch
+    const bool fused = fused_sub1(a, cond_cin, h.co);       // conv_sub1.hip: its weight gradients come out of the same launch
     if (net->gw2 && !fused) {
       if (grouped) add_item(hbuf, SININN_HIDDEN, SININN_HIDDEN, dr, 2 * h.co, 2 * h.co, net->gw2, net->gb2, bf16 ? 1 : 0, 0, gs, 0);
       else {

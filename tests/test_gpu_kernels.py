@@ -514,7 +514,7 @@ def test_conv_kernels_at_baseline_config_shapes(env, cin, n, hw):
 # ---------------------------------------------------------------------------------------------------
 # fused 1x1 conv pair through the C ABI (sininn_conv_pair_k1) against two sininn_conv launches on the same packs
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('co,hw', [(24, (13, 21)), (96, (6, 18)), (8, (9, 33))])
+@pytest.mark.parametrize('co,hw', [(24, (13, 21)), (96, (6, 18)), (8, (9, 33)), (16, (70, 50)), (24, (64, 64))])
 def test_conv_pair_c_abi_matches_two_launches(env, co, hw):
     import ctypes as C
     S, O, dev = env
@@ -558,6 +558,30 @@ def test_conv_pair_c_abi_matches_two_launches(env, co, hw):
     assert float(ng[0].abs().max()) == 0.0
     for a, r in zip(ng[1:], ref[1:]):
         assert relerr(a, r) < 1e-5
+    # the persistent twin for the level-0 shapes (sininn_conv_sub1_fwd): same outputs, s and log-det, both coupling directions
+    for mode in (_lib.CONV_COUPLE_FWD, _lib.CONV_COUPLE_INV):
+        outs = []
+        for persistent in (False, True):
+            out = torch.zeros(m, c, device=dev); y2 = torch.zeros(m, co, device=dev)
+            sb = torch.zeros(m, co, device=dev); ld = torch.zeros(b, device=dev)
+            common = dict(B=b, H=h, W=w, ksize=1)
+            f = args(in_=ops.ptr(x, co), in_stride=c, Cin=co, w=ops.ptr(w1), bias=ops.ptr(b1), Np=256, mode=_lib.CONV_RELU, out_stride=256,
+                     N=256, **common)
+            s = args(in_=ops.ptr(x), in_stride=256, Cin=256, w=ops.ptr(w2), bias=ops.ptr(b2), Np=2 * co, mode=mode, out=ops.ptr(out),
+                     out_stride=c, v=ops.ptr(x), v_stride=c, sbuf=ops.ptr(sb), logdet=ops.ptr(ld), Co=co, clamp=1.2, out2=ops.ptr(y2),
+                     out2_stride=co, col_tile=ops.coupling_tile(co), **common)
+            if persistent:
+                assert lib.sininn_conv_sub1_fwd_supported(C.byref(f), C.byref(s)) == (1 if co in (8, 16, 24) else 0)
+                if co not in (8, 16, 24):
+                    assert lib.sininn_conv_sub1_fwd(C.byref(f), C.byref(s), ops._stream()) != 0
+                    continue
+                _lib.check(lib.sininn_conv_sub1_fwd(C.byref(f), C.byref(s), ops._stream()))
+            else:
+                _lib.check(lib.sininn_conv_pair_k1(C.byref(f), C.byref(s), ops._stream()))
+            outs.append((out[:, :co], y2, sb, ld))
+        if len(outs) == 2:
+            for a, r in zip(outs[1], outs[0]):
+                assert relerr(a, r) < 1e-5
     # a 3x3 first conv is not a pair
     f3 = args(in_=ops.ptr(x, co), in_stride=c, Cin=co, w=ops.ptr(w1), bias=ops.ptr(b1), Np=256, mode=_lib.CONV_RELU, out_stride=256,
               N=256, B=b, H=h, W=w, ksize=3)

@@ -124,7 +124,7 @@ def test_fused_1x1_pair_matches_the_two_launch_path(rev, channels, hw, precision
 @pytest.mark.parametrize('rev', [False, True])
 @pytest.mark.parametrize('channels,hw', [(48, (13, 21)), (48, (64, 64)), (16, (9, 33)), (32, (5, 16))])
 def test_fused_1x1_subnet_backward_matches_the_pair_path(rev, channels, hw):
-    """Round 4: fp32 1x1 subnets at the level-0 shapes run their WHOLE backward as one persistent launch (conv_sub1_bwd.hip: h
+    """Round 4: fp32 1x1 subnets at the level-0 shapes run their WHOLE backward as one persistent launch (conv_sub1.hip: h
     recomputed from the input, dh on chip, both data gradients and both weight gradients) and their forward without storing h.
     Same block, same inputs with the switch off (data-gradient pair + grouped weight gradients, h stored): outputs, log-det and
     the input gradient agree to summation order of the FORWARD pair (the backward itself is bitwise the pair's), every parameter
