@@ -205,11 +205,12 @@ def rehearse(args, rank, ws):
     if ws > 1:
         torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
     assert abs(float(flat[0]) - (ws + 1) / 2.0) < 1e-5
+    ranks = rank_table(None)
     if rank == 0:
         line = json.dumps({'metric': 'training frames/sec at 256x256 bs=16', 'value': None, 'unit': 'frames/s', 'n_gpus': ws,
                           'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': float(dt) / args.steps * 1e3,
                           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
-                          'data': 'synthetic', 'rehearsal': True,
+                          'data': 'synthetic', 'rehearsal': True, 'distributed': distributed_record(ranks, None, float(dt) / args.steps * 1e3),
                           'config': {'workload': 'REHEARSAL of the multi-rank plumbing on CPU (gloo): no kernels run',
                                      'global_batch': ws * args.batch, 'parallelism': f'dp{ws}'}})
         sys.stdout.write(line + '\n')                     # one write: the ranks share the launcher's stdout pipe
@@ -217,10 +218,44 @@ def rehearse(args, rank, ws):
     return 0
 
 
+def rank_table(device_index):
+    """One record per rank (gathered on every rank): which process drove which GPU.  Lets the reader of an N-GPU line check that
+    N distinct devices took part (PCI address), not N ranks on one card."""
+    import torch.distributed as dist
+    rec = {'rank': int(os.environ.get('RANK', '0')), 'local_rank': int(os.environ.get('LOCAL_RANK', '0')), 'pid': os.getpid(),
+           'host': os.uname().nodename}
+    if device_index is not None:
+        pr = torch.cuda.get_device_properties(device_index)
+        rec.update(device=f'cuda:{device_index}', name=pr.name,
+                   pci=(f'{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}' if hasattr(pr, 'pci_bus_id') else None))
+    else:
+        rec.update(device='cpu')
+    if not (dist.is_available() and dist.is_initialized()):
+        return [rec]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, rec)
+    return out
+
+
+def distributed_record(ranks, allreduce_ms, max_step_ms):
+    import torch.distributed as dist
+    on = dist.is_available() and dist.is_initialized()
+    return {'world_size': dist.get_world_size() if on else 1, 'backend': dist.get_backend() if on else None, 'ranks': ranks,
+            'distinct_devices': len({(r.get('host'), r.get('pci') or r.get('device')) for r in ranks}),
+            'allreduce_ms_per_step': allreduce_ms,
+            'allreduce_note': 'HIP events per step, rank 0: from the last weight-gradient kernel (the stream the collective is ordered '
+                              'behind) to the reduced flat gradient being visible to the stream that launches Adam',
+            'ms_per_step_max_over_ranks': max_step_ms,
+            'collective': 'one all-reduce (sum) of the flat fp32 gradient buffer per step; 1/world folded into the Adam launch'}
+
+
 CONFIGS = {
     # BASELINE.json configs[i] -> workload presets (height, width, -c, precision, per-GPU batch)
     1: dict(height=256, width=256, num_coupling=4, precision='fp32', batch=16,
             name='BASELINE configs[1]: 8-block INN (SRF, -c 4 x 2 levels), 256x256x3, fp32'),
+    2: dict(height=256, width=256, num_coupling=4, precision='fp32', batch=16,
+            name='BASELINE configs[2]: the configs[1] clip at global batch 128 = 16 per GPU x 8 GPUs (run with --gpus 8; with fewer '
+                 'GPUs the per-GPU work is the same and the global batch is 16 x N), one RCCL all-reduce of the flat gradient per step'),
     3: dict(height=512, width=512, num_coupling=4, precision='bf16', batch=16,
             name='BASELINE configs[3] shape: INN at 512x512x3 (SRF, -c 4 x 2 levels), bf16 conv subnets / fp32 flow'),
     4: dict(height=720, width=1280, num_coupling=12, precision='bf16', batch=16,
@@ -277,7 +312,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', type=int, default=1, choices=sorted(CONFIGS), help='BASELINE.json configs[] index: 1 = the headline '
-                    '(256x256 bs 16 fp32), 3 = 512x512 bf16, 4 = 720p -c 12 bf16')
+                    '(256x256 bs 16 fp32), 2 = the same per GPU under data parallel (bs 128 on 8 GPUs), 3 = 512x512 bf16, 4 = 720p -c 12 bf16')
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the config preset)')
     ap.add_argument('--size', type=int, default=None, help='square frame size override')
     ap.add_argument('--height', type=int, default=None)
@@ -298,6 +333,9 @@ def main():
                     'every step first warps the neighbouring frame of each sample by a resident flow field and takes the photometric '
                     'metric against the sample (flow_warp_l1, bf16 images / fp32 flow, video-interpolation/trainer.py:61-62) and '
                     'its gradient w.r.t. the flow, then runs the INN training step on the batch')
+    ap.add_argument('--with-tcr', action='store_true', help='lambda_bwd_tcr = 1: every step also runs the transformation-consistency branch '
+                    '(reference lit_wrapper.py:58-72: per iteration two more inverse passes, two affine warps, an MSE and a backward)')
+    ap.add_argument('--tcr-iters', type=int, default=1, help='TCR samples per step with --with-tcr (reference default: 5)')
     ap.add_argument('--graph', choices=['on', 'off'], default='off', help='replay the pass chains of a step as one hipGraph '
                     '(lit_wrapper: captured after 3 eager steps; a refused capture falls back to eager launches)')
     ap.add_argument('--no-overlap', action='store_true', help='diagnostic: single stream (no pass / wgrad overlap)')
@@ -344,6 +382,8 @@ def main():
     opt.precision = args.precision
     opt.architecture = args.arch
     opt.hip_graph = args.graph == 'on'
+    if args.with_tcr:
+        opt.lambda_bwd_tcr, opt.tcr_iters = 1.0, args.tcr_iters
     if opt.hip_graph:
         args.warmup = max(args.warmup, 5)        # 3 eager steps + the capturing one + a replay before the timed region
     irn = args.arch == 'IRN'
@@ -432,6 +472,9 @@ def main():
     barrier()
     print(f'[bench] rank {rank}: warm-up done', file=sys.stderr, flush=True)
     clocks_before = gpu_clocks(local)
+    ranks = rank_table(local)
+    assert len(ranks) == ws == args.gpus, f'--gpus {args.gpus}: {len(ranks)} ranks answered, world size {ws}'
+    sdist.TIMING[0] = [] if ws > 1 else None
     timer.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -441,6 +484,10 @@ def main():
     dt = time.perf_counter() - t0
     clocks_after = gpu_clocks(local)
     timer.stop()
+    allreduce_ms = None
+    if sdist.TIMING[0]:
+        allreduce_ms = sum(a.elapsed_time(b) for a, b in sdist.TIMING[0]) / len(sdist.TIMING[0])
+    sdist.TIMING[0] = None
     if ws > 1:
         t = torch.tensor([dt], device=dev if torch.distributed.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -511,9 +558,19 @@ def main():
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
     traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, 'profiles', 'traffic_dominant.json')   # PMC pass is a separate rocprofv3 run (committed)
-    if os.path.isfile(tpath) and args.config == 1 and not custom:
+    if os.path.isfile(tpath) and args.config in (1, 2) and not custom:
         tj = json.load(open(tpath))
         traffic, traffic_src = tj.get('hbm_bytes_per_launch'), tj.get('source')
+    # rocprofv3's duration of the same kernels from the committed trace of this build (profiles/roofline_kernels.json, written by
+    # tools/refresh_profiles.sh from profiles/*_single_stream_by_grid.csv with the commit it was measured at): `frac` is computed
+    # from THAT when it is there -- a number the reader can re-derive from profiles/ -- and the live stamp window is kept beside it
+    rk = None
+    rpath = os.path.join(ROOT, 'profiles', 'roofline_kernels.json')
+    if os.path.isfile(rpath) and args.config in (1, 2) and not custom and not bf16 and not irn:
+        rk = json.load(open(rpath))
+    kms_live = kms
+    if rk and rk.get('named'):
+        kms = rk['named']['avg_us'] * 1e-3
     if kms:
         ach = flops / (kms * 1e-3) / 1e12
         hid_bytes = 2.0 if bf16 else 4.0
@@ -530,7 +587,11 @@ def main():
                 'frac': executed / peak, 'traffic': traffic, 'traffic_source': traffic_src,
                 'kernel': kernel,
                 'achieved_algorithmic': ach, 'frac_algorithmic': ach / peak,
-                'launches_timed': tm.count, 'avg_ms': kms, 'avg_ms_source': kms_src,
+                'launches_timed': tm.count, 'avg_ms': kms,
+                'avg_ms_source': (f"rocprofv3 --kernel-trace of `bench.py --no-overlap` on commit {rk.get('commit')}: {rk['named']['kernel']} "
+                                  f"grid {rk['named']['grid']}, {rk['named']['calls']} calls ({rk.get('source')})") if rk and rk.get('named') else kms_src,
+                'avg_ms_rocprof': rk['named']['avg_us'] * 1e-3 if rk and rk.get('named') else None,
+                'avg_ms_execution_window': kms_live, 'avg_ms_execution_window_source': kms_src,
                 'avg_ms_hip_events': kms_events,
                 'timed_region': {'launches': timer.count, 'avg_ms_execution_window': timer.stamp_ms,
                                  'avg_ms_hip_events': timer.mean_event_ms(),
@@ -553,6 +614,24 @@ def main():
                        'note': 'FLOP/B far above the ridge: the kernel is matrix-pipe-bound, this fraction is low by nature'}
         roof['classes'] = classes
         roof['single_stream_ms_per_step'] = iso_ms
+        if not bf16:
+            # the kernel that is dominant BY TIME: the grouped Winograd weight gradient of a 3x3 block (four convs, one launch)
+            wg = next((c for c in classes if c['class'].startswith('3x3 weight gradients')), None)
+            wflops = 2.0 * m0 * 9 * (24 * 256 + 256 * 48) * 2          # per block, either level: SURVEY 8d (43.49 GFLOP)
+            wms_live = wg['ms_per_step'] / max(wg['launches_per_step'], 1) if wg else None
+            wms_prof = rk['by_time']['avg_us'] * 1e-3 if rk and rk.get('by_time') else None
+            wms = wms_prof or wms_live
+            if wms:
+                roof['dominant_by_time'] = {
+                    'kernel': 'wgrad_wino_group_kernel<4,2> (the four 3x3 weight gradients of a GLOW block in one launch, Winograd F(2x2,3x3) '
+                              'on v_mfma_f32_16x16x4_f32, + ordered slab reduce)',
+                    'bound': 'mfma', 'peak': peak, 'unit': 'TFLOP/s', 'alg_flops_per_launch': wflops, 'executed_flops_per_launch': wflops / 2.25,
+                    'avg_ms': wms, 'avg_ms_rocprof': wms_prof, 'avg_ms_live_event_bracket_incl_reduce': wms_live,
+                    'avg_ms_source': (f"rocprofv3 --kernel-trace on commit {rk.get('commit')}: grid {rk['by_time']['grid']}, "
+                                      f"{rk['by_time']['calls']} calls, {rk['by_time']['percent']} % of the GPU time of a single-stream step "
+                                      f"({rk.get('source')})") if wms_prof else 'HIP-event bracket of the class (kernel + reduce), single-stream steps',
+                    'achieved': wflops / 2.25 / (wms * 1e-3) / 1e12, 'frac': wflops / 2.25 / (wms * 1e-3) / 1e12 / peak,
+                    'achieved_algorithmic': wflops / (wms * 1e-3) / 1e12}
         # whole-step algorithmic rate (train step = 6 x forward FLOPs)
         fwd = 0.0
         for lvl, (mm, cc) in enumerate(((m0, 48), (m0 // 4, 192))):
@@ -596,13 +675,17 @@ def main():
                       'baseline_config': args.config, 'height': args.height, 'width': args.width,
                       'global_batch': ws * b, 'num_coupling': args.num_coupling, 'architecture': args.arch, 'parallelism': f'dp{ws}'},
            'roofline': roof}
+    out['distributed'] = distributed_record(ranks, allreduce_ms, ms_per_step)
+    if args.with_tcr:
+        out['config']['workload'] += f'; + the TCR branch (lambda_bwd_tcr 1, {args.tcr_iters} iteration(s) per step)'
+        out['config']['with_tcr'] = args.tcr_iters
     out['gpu_clocks'] = {'before_timed_region': clocks_before, 'after_timed_region': clocks_after,
                          'source': '/sys/class/drm/card*/device/pp_dpm_{sclk,mclk} (active level), gpu_busy_percent'}
     out['config']['hip_graph'] = bool(args.graph == 'on' and any('graph' in v for v in model.__dict__.get('_graphs', {}).values()))
     if args.with_flow:
         out['config']['workload'] += '; preceded in every step by the pair_flow warp + photometric metric + flow gradient on the batch'
         out['config']['with_flow'] = True
-    if args.config != 1 or custom:
+    if args.config not in (1, 2) or custom:
         out['metric'] = f'training frames/sec at {args.width}x{args.height} bs={b}' + (' (IRN architecture)' if irn else '')
     if not args.no_cpu_baseline and ws == 1:
         out['cpu_baseline'] = cpu_baseline(args, opt)

@@ -45,6 +45,12 @@ def init_from_env(backend=None, allow_single=False):
     return world()
 
 
+# bench.py sets TIMING[0] = [] around its timed region: every gradient all-reduce then appends a (start, end) pair of HIP events --
+# start on the stream the collective is ordered behind (it fires when the last weight-gradient kernel has finished), end on the
+# caller's stream right after it has been made to wait for the collective (it fires when the reduced buffer is visible to Adam).
+TIMING = [None]
+
+
 def allreduce_mean_(flat_buffers):
     """In-place average of each flat gradient buffer over the ranks (one collective per buffer)."""
     _, ws = world()
@@ -68,16 +74,23 @@ def allreduce_sum_(flat_buffers, after=None, _force=False):
     _, ws = world()
     if ws == 1 and not _force:
         return
-    if after is not None and flat_buffers and flat_buffers[0].is_cuda:
-        if dist.get_backend() == 'nccl':
-            with torch.cuda.stream(after):
-                works = [dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True) for buf in flat_buffers]
-            for w in works:
-                w.wait()
-            return
-        torch.cuda.current_stream().wait_stream(after)     # gloo rehearsal on GPU tensors: plain stream order
-    for buf in flat_buffers:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    timed = TIMING[0] is not None and bool(flat_buffers) and flat_buffers[0].is_cuda
+    if timed:                                   # bench.py: (start, end) HIP events per step, see the docstring of TIMING
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(after if after is not None else torch.cuda.current_stream())
+    if after is not None and flat_buffers and flat_buffers[0].is_cuda and dist.get_backend() == 'nccl':
+        with torch.cuda.stream(after):
+            works = [dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True) for buf in flat_buffers]
+        for w in works:
+            w.wait()
+    else:
+        if after is not None and flat_buffers and flat_buffers[0].is_cuda:
+            torch.cuda.current_stream().wait_stream(after)     # gloo rehearsal on GPU tensors: plain stream order
+        for buf in flat_buffers:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    if timed:
+        e1.record(torch.cuda.current_stream())
+        TIMING[0].append((e0, e1))
 
 
 def broadcast_(tensors, src=0):

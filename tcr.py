@@ -47,4 +47,8 @@ class TCR(nn.Module):
     def forward(self, img, random, scale=1):
         _, _, h, w = img.shape
         theta = normalized_inverse(pixel_matrix(random, h, w, self.ang, self.trans, scale), h, w)
-        return affine_warp(img, theta.to(img.device))
+        if img.is_cuda:
+            # B x 6 numbers: pinned + non_blocking, so the upload is stream-ordered like everything else in the step (a pageable
+            # copy would make the host wait for the stream, i.e. for the passes queued before the TCR branch)
+            theta = theta.pin_memory().to(img.device, non_blocking=True)
+        return affine_warp(img, theta)

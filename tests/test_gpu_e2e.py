@@ -60,6 +60,49 @@ def test_cli_train_checkpoint_resume_test(tmp_path):
         main.main(['test'] + _cli('-w', wd, '-r', other, '--save_images', frames))
 
 
+def test_baseline_config0_through_the_cli_matches_the_oracle_step(tmp_path):
+    """BASELINE configs[0] exactly as named: the 4-coupling-block SRF network on 8 synthetic 64x64x3 frames through main.py
+    (`--synthetic 8 64 64 --fps 1 --lr_window 1 -c 4`: num_lr 7, ONE supervised frame [2] (data.py:56), lr_dims 12, z_dims 180).  One
+    epoch = one training step on the GPU; the CPU oracle runs the same step from the same seed-0 weights, frame window and latent:
+    logged loss within 1e-4, and the Adam update agrees element by element (an update is lr * sign(g) for all but vanishing
+    gradients: entries that differ by more than a tenth of the step are counted, not bounded)."""
+    import lit_wrapper
+    import main
+    from data import ConcatDataset, VideoAllDataset, VideoTrainDataset, VideoValDataset
+    from oracle import sininn_oracle as O
+    argv = ['train', '--synthetic', '8', '64', '64', '--fps', '1', '--lr_window', '1', '-c', '4', '-b', '8', '-e', '1', '--save_iter', '100',
+            '-p', '100', '-w', str(tmp_path / 'exp'), '--suffix', 'cfg0']
+    z = torch.randn(1, 180, 8, 8, generator=torch.Generator().manual_seed(2))
+    real = lit_wrapper._latent
+    lit_wrapper._latent = lambda b, zd, h, w, device, temp=1.0: z[:b].to(device)
+    try:
+        model = main.main(argv)
+    finally:
+        lit_wrapper._latent = real
+    assert model.opt.lr_dims == 12 and model.opt.z_dims == 180
+    # the same construction sequence main() runs (it consumes the seeded RNG in this order), stopped before training
+    args = main.get_args(argv)
+    sup, unsup = VideoTrainDataset(args), VideoAllDataset(args)
+    train = ConcatDataset(sup, unsup)
+    VideoValDataset(args, len(train) * 4 // 6)
+    assert sup.frames == [2] and len(train) == 1
+    fresh = lit_wrapper.SingleVideoINN(3, 64, 64, args)
+    ref = O.SRFlowOracle(3, 64, 64, scale=4, num_coupling=4)
+    ref.load_state_dict({k[len('inn.'):]: v.detach().clone() for k, v in fresh.state_dict().items()})
+    before = torch.cat([p.detach().reshape(-1) for p in ref.parameters()]).clone()
+    hr, lr = O.gather_window(args.frame_store.lr, args.frame_store.hr, 2, 1)
+    adam = torch.optim.Adam(ref.parameters(), lr=args.learning_rate, betas=tuple(args.adam_betas), weight_decay=args.weight_decay)
+    lam = dict(fwd_rec=1.0, fwd_mmd=0.0, latent_nll=0.0, bwd_rec=1.0, bwd_mmd=0.0)
+    fwd, bwd, _, _, _ = O.training_step(ref, hr[None], lr[None], z, lam, 12)
+    adam.step()
+    assert abs(float(model._logged['train']) / float(fwd + bwd) - 1) < 1e-4
+    want = torch.cat([p.detach().reshape(-1) for p in ref.parameters()]) - before
+    got = torch.cat([p.detach().reshape(-1).cpu() for p in model.inn.parameters()])[:before.numel()] - before
+    assert float(want.abs().max()) > 0.5 * args.learning_rate                 # a step was taken
+    off = (got - want).abs() > 0.1 * args.learning_rate
+    assert float(off.float().mean()) < 2e-3, float(off.float().mean())
+
+
 def _model_and_oracle(size=32, num_coupling=1, lr_window=1, seed=0, **kw):
     import lit_wrapper
     from oracle import sininn_oracle as O

@@ -163,18 +163,26 @@ def test_data_parallel_glue_world2_gloo(tmp_path):
     assert 'rank 0 ok' in out.stdout and 'rank 1 ok' in out.stdout
 
 
-def test_bench_self_launches_its_ranks_cpu_rehearsal():
-    """`python bench.py --gpus 2` with no WORLD_SIZE must spawn its own ranks (torch.distributed.run children, before any
-    GPU call) and relay rank 0's JSON line; --rehearse runs that plumbing on gloo without kernels."""
+@pytest.mark.parametrize('n', [2, 8])
+def test_bench_self_launches_its_ranks_cpu_rehearsal(n):
+    """`python bench.py --gpus N` with no WORLD_SIZE must spawn its own ranks (torch.distributed.run children, before any
+    GPU call) and relay rank 0's JSON line; --rehearse runs that plumbing on gloo without kernels.  The line describes the job it
+    came from: world size, backend, one record per rank, the collective, max-over-ranks step time -- for the
+    day an 8-GPU node runs it (reference parallelism: main.py:112 Trainer(gpus=...))."""
     import json
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
-    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--rehearse', '--steps', '3'],
-                         capture_output=True, text=True, env=env, timeout=300)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--rehearse', '--steps', '3', '--config', '2'],
+                         capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1
     rec = json.loads(lines[0])
-    assert rec['n_gpus'] == 2 and rec['steps'] == 3 and rec['rehearsal'] is True and rec['scaling'] == 'weak'
+    assert rec['n_gpus'] == n and rec['steps'] == 3 and rec['rehearsal'] is True and rec['scaling'] == 'weak'
+    assert rec['config']['global_batch'] == 16 * n and rec['config']['parallelism'] == f'dp{n}'
+    d = rec['distributed']
+    assert d['world_size'] == n and d['backend'] == 'gloo' and len(d['ranks']) == n
+    assert sorted(r['rank'] for r in d['ranks']) == list(range(n)) and len({r['pid'] for r in d['ranks']}) == n
+    assert d['ms_per_step_max_over_ranks'] > 0 and 'all-reduce' in d['collective']
 
 
 def test_checkpoint_holds_tensors_and_primitives_only(tmp_path):
