@@ -383,7 +383,8 @@ int sininn_profile_classes_end(int n, double* ms, double* flops, int* launches);
 
 size_t sininn_glow_saved_floats(int B, int H, int W, int C);
 size_t sininn_glow_saved_floats_dtype(int B, int H, int W, int C, int dtype);   /* dtype 1: bf16 hidden tensors (half the floats) */
-size_t sininn_glow_scratch_bytes(int B, int H, int W, int C, int ksize);
+size_t sininn_glow_scratch_bytes(int B, int H, int W, int C, int ksize);                       /* dtype 0 */
+size_t sininn_glow_scratch_bytes_dtype(int B, int H, int W, int C, int ksize, int dtype);   /* dtype 1 needs no slabs for the fused 1x1 backward */
 int sininn_glow_forward(const sininn_glow_args* args, void* stream);
 int sininn_glow_backward(const sininn_glow_args* args, void* stream, void* wgrad_stream);
 /* Parity tooling (ABI v4): the ReLU gates the forward pass of a block took, gates[m][j] = (hidden[m][j] > 0) as bytes

@@ -142,6 +142,7 @@ _SIGS = {
     'sininn_glow_saved_floats': (C.c_size_t, [C.c_int] * 4),
     'sininn_glow_saved_floats_dtype': (C.c_size_t, [C.c_int] * 5),
     'sininn_glow_scratch_bytes': (C.c_size_t, [C.c_int] * 5),
+    'sininn_glow_scratch_bytes_dtype': (C.c_size_t, [C.c_int] * 6),
     'sininn_glow_forward': (C.c_int, [C.POINTER(GlowArgs), C.c_void_p]),
     'sininn_glow_backward': (C.c_int, [C.POINTER(GlowArgs), C.c_void_p, C.c_void_p]),
     'sininn_glow_hidden_gates': (C.c_int, [C.POINTER(GlowArgs), C.c_int, C.c_void_p, C.c_void_p]),

@@ -132,7 +132,7 @@ int sample_pairs_planar_launch(const uint8_t* clip, const int* idx, int n, int T
 int bayer_demosaic_launch(const uint8_t* hr, uint8_t* rgb, int T, int H, int W, int scale, int reduce_sum, hipStream_t st);
 int bayer_bin_launch(const uint8_t* hr, uint8_t* lr, int T, int H, int W, int scale, int reduce_sum, hipStream_t st);
 size_t glow_saved_floats(int B, int H, int W, int C, int dtype);
-size_t glow_scratch_bytes(int B, int H, int W, int C, int ksize);
+size_t glow_scratch_bytes(int B, int H, int W, int C, int ksize, int dtype);
 int glow_forward(const sininn_glow_args* a, hipStream_t st);
 int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst);
 int glow_hidden_gates(const sininn_glow_args* a, int which, unsigned char* gates, hipStream_t st);
@@ -352,7 +352,8 @@ int sininn_wall_clock_khz(void) {
 int sininn_profile_end(int* count, float* total_ms) { return profile_end(count, total_ms); }
 size_t sininn_glow_saved_floats(int B, int H, int W, int C) { return glow_saved_floats(B, H, W, C, 0); }
 size_t sininn_glow_saved_floats_dtype(int B, int H, int W, int C, int dtype) { return glow_saved_floats(B, H, W, C, dtype); }
-size_t sininn_glow_scratch_bytes(int B, int H, int W, int C, int ksize) { return glow_scratch_bytes(B, H, W, C, ksize); }
+size_t sininn_glow_scratch_bytes(int B, int H, int W, int C, int ksize) { return glow_scratch_bytes(B, H, W, C, ksize, 0); }
+size_t sininn_glow_scratch_bytes_dtype(int B, int H, int W, int C, int ksize, int dtype) { return glow_scratch_bytes(B, H, W, C, ksize, dtype); }
 int sininn_glow_forward(const sininn_glow_args* args, void* stream) { return glow_forward(args, ST(stream)); }
 int sininn_glow_backward(const sininn_glow_args* args, void* stream, void* wgrad_stream) {
   return glow_backward(args, ST(stream), ST(wgrad_stream));

@@ -232,7 +232,7 @@ size_t glow_saved_floats(int B, int H, int W, int C, int dtype) {
 }
 
 struct Scratch { float *dr_b, *dh_b, *dy_first, *dr_a, *dh_a; void* ws; size_t ws_bytes; void* slab[2]; size_t slab_bytes[2]; size_t total_bytes; };
-static Scratch scratch_layout(void* basep, int B, int H, int W, int C, int ksize, int co_a, int co_b) {
+static Scratch scratch_layout(void* basep, int B, int H, int W, int C, int ksize, int co_a, int co_b, int dtype = 0) {
   const size_t M = (size_t)B * H * W;
   float* base = static_cast<float*>(basep);
   Scratch s;
@@ -280,7 +280,7 @@ static Scratch scratch_layout(void* basep, int B, int H, int W, int C, int ksize
   size_t so = (o * sizeof(float) + w + 255) / 256 * 256;
   const int cond_cin[2] = {C - co_a, co_a}, cos[2] = {co_a, co_b};
   for (int i = 0; i < 2; ++i) {
-    s.slab_bytes[i] = ksize == 1 ? conv_sub1_bwd_workspace_bytes(cond_cin[i], cos[i]) : 0;
+    s.slab_bytes[i] = conv_sub1_bwd_shape_supported(ksize, dtype, cond_cin[i], cos[i]) ? conv_sub1_bwd_workspace_bytes(cond_cin[i], cos[i]) : 0;
     s.slab[i] = reinterpret_cast<char*>(base) + so;
     so += (s.slab_bytes[i] + 255) / 256 * 256;
   }
@@ -288,10 +288,10 @@ static Scratch scratch_layout(void* basep, int B, int H, int W, int C, int ksize
   return s;
 }
 
-size_t glow_scratch_bytes(int B, int H, int W, int C, int ksize) {
+size_t glow_scratch_bytes(int B, int H, int W, int C, int ksize, int dtype) {
   const int big = C - C / 2;
   // upper bound over both directions (co_a / co_b are C/2 and C - C/2 in some order)
-  Scratch s = scratch_layout(nullptr, B, H, W, C, ksize, big, big);
+  Scratch s = scratch_layout(nullptr, B, H, W, C, ksize, big, big, dtype);
   return s.total_bytes + 256;
 }
 
@@ -452,7 +452,7 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
   halves_of(a, hv);
   const int co_a = hv[0].co, co_b = hv[1].co, base_a = hv[0].base, base_b = hv[1].base;
   Saved sv = saved_layout(a->saved, M, co_a, co_b, a->dtype == 1);
-  Scratch sc = scratch_layout(a->scratch, B, H, W, C, k, co_a, co_b);
+  Scratch sc = scratch_layout(a->scratch, B, H, W, C, k, co_a, co_b, a->dtype);
   SININN_CHECK(a->scratch_bytes >= sc.total_bytes, "glow_backward: scratch too small (%zu < %zu)", a->scratch_bytes, sc.total_bytes);
   const int inv = a->rev ? 1 : 0;
   const int* map_a = a->dst_map ? a->dst_map + base_a : nullptr;

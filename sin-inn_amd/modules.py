@@ -377,7 +377,7 @@ class _GlowFn(torch.autograd.Function):
         if gld is not None:
             gld = gld.contiguous()
         dx = torch.empty_like(x)
-        nbytes = lib.sininn_glow_scratch_bytes(b, h, w, c, block.ksize)
+        nbytes = lib.sininn_glow_scratch_bytes_dtype(b, h, w, c, block.ksize, 1 if block.precision == 'bf16' else 0)
         scratch = torch.empty((nbytes + 3) // 4, device=dev, dtype=torch.float32)
         s1, keep1 = _subnet_args(block, block.s1, block.split_len2, dev, True, True)
         s2, keep2 = _subnet_args(block, block.s2, block.split_len1, dev, True, True)
