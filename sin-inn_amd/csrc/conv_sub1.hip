@@ -308,12 +308,6 @@ __global__ __launch_bounds__(S1_NTHR) void conv_sub1_bwd_kernel(Sub1Dev q) {
         }
     }
     mark(3);
-    // the next tile (requested one tile ago) -> the other LDS buffer; the tile after it is requested
-    if (tile + (int)gridDim.x < q.ntiles) {
-      store_tile(tile + gridDim.x, buf ^ 1, vx, vd);
-      mark(10);
-      issue_tile(tile + 2 * gridDim.x, vx, vd);
-    }
     // side inputs of this tile's epilogue: requested HERE -- half a tile after the previous tile's epilogue stores and half a tile
     // before they are used.  One counter covers vector loads and stores on this chip and a register that is the data or address
     // of a store in flight may not be overwritten before the store has completed: requested at the top of the tile, these loads
@@ -337,6 +331,14 @@ __global__ __launch_bounds__(S1_NTHR) void conv_sub1_bwd_kernel(Sub1Dev q) {
       const bool cb = e_live && e_cbwd;
       e_u = buf_load4(buf_rsrc((e_cbwd ? pb.v : pb.addend) + e_img * (e_cbwd ? pb.v_stride : 0)), cb ? (e_ip * pb.v_stride + e_col) * 4u : BUF_OOB, 0u);
       e_s = buf_load4(buf_rsrc((e_cbwd ? pb.sbuf : pb.addend) + e_img * (e_cbwd ? pb.Co : 0)), cb ? (e_ip * pb.Co + e_col) * 4u : BUF_OOB, 0u);
+    }
+    __builtin_amdgcn_sched_barrier(0);               // ... and before the next tiles' x / dr: the counter is in order, so waiting for the
+                                                     // side inputs does not wait for those loads
+    // the next tile (requested one tile ago) -> the other LDS buffer; the tile after it is requested
+    if (tile + (int)gridDim.x < q.ntiles) {
+      store_tile(tile + gridDim.x, buf ^ 1, vx, vd);
+      mark(10);
+      issue_tile(tile + 2 * gridDim.x, vx, vd);
     }
     __builtin_amdgcn_sched_barrier(0);               // the requests above stay above: their latency is what stage 3 / W1 hide
     mark(11);
@@ -488,7 +490,9 @@ __global__ __launch_bounds__(S1_NTHR) void conv_sub1_fwd_kernel(Sub1Dev q) {
   float* const w2s = xs0 + 2 * P * XS;              // [N2][HS]
   float* const T0 = w2s + N2 * HS;                  // 2 x [P][TS]: the two K halves of the output tile
   float* const T1 = T0 + P * TS;
-  __shared__ float red[NTHR / 64];
+  __shared__ float ldw[2][NTHR / 64];               // per-wave log-det sums of the last two tiles
+  int ld_b[2] = {0, 0};                             // ... and the image they belong to
+  int ld_pending = -1;                              // buffer whose sums have not been added to logdet yet
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -510,6 +514,27 @@ __global__ __launch_bounds__(S1_NTHR) void conv_sub1_fwd_kernel(Sub1Dev q) {
       const unsigned o1 = (unsigned)(((cw + n * 16 + li) * K1 + 4 * kq) * 4);
 #pragma unroll
       for (int s = 0; s < NS1; ++s) bf1[s][n] = buf_load4(w1_rs, 16 * s + 4 * kq < K1 ? o1 : BUF_OOB, (unsigned)(64 * s));
+    }
+  }
+
+  // ---- the coupling epilogue on one channel quad per thread (pixel tid / NQ, channels 4 (tid % NQ) ..): conv_epilogue_tile's
+  // arithmetic and stores, with the one global side input (v) requested half a tile before it is used (the shared epilogue asks
+  // for it after the barrier and waits out the round trip: 11 of this kernel's 41 us at BASELINE configs[1], level 0)
+  constexpr int CO = N2 / 2, NQ = CO / 4;
+  const int e_pl = tid / NQ, e_cl = 4 * (tid - e_pl * NQ);
+  const bool e_thread = tid < P * NQ;
+  const int e_tcol = (e_cl / HT) * (2 * HT) + (e_cl % HT);
+  const bool e_inv = pb.mode == SININN_CONV_COUPLE_INV;
+  f32x4 e_bs = {0.f, 0.f, 0.f, 0.f}, e_bt = e_bs;
+  int e_omap[4] = {e_cl, e_cl + 1, e_cl + 2, e_cl + 3};
+  if (e_thread) {
+    if (pb.bias) {
+      e_bs = *reinterpret_cast<const f32x4*>(pb.bias + e_tcol);
+      e_bt = *reinterpret_cast<const f32x4*>(pb.bias + e_tcol + HT);
+    }
+    if (pb.out_map) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) e_omap[j] = pb.out_map[e_cl + j];
     }
   }
 
@@ -587,12 +612,27 @@ __global__ __launch_bounds__(S1_NTHR) void conv_sub1_fwd_kernel(Sub1Dev q) {
         }
     }
     // the next tile (requested one tile ago) -> the other buffer; the tile after it is requested
+    // v of this tile's epilogue quad (raw buffer load relative to the image: a quad outside the image reads zeros and is not
+    // stored).  Requested BEFORE the next tiles' x: the counter is in order, so waiting for v then does not wait for those loads
+    const int e_gy = y0 + (e_pl >> 4), e_gx = x0 + (e_pl & 15);
+    const bool e_live = e_thread && e_gy < pb.H && e_gx < pb.W;
+    const size_t e_img = (size_t)b * pb.H * pb.W;
+    const unsigned e_ip = (unsigned)(e_gy * pb.W + e_gx);
+    const f32x4 e_v = buf_load4(buf_rsrc(pb.v + e_img * pb.v_stride), e_live ? (e_ip * pb.v_stride + e_cl) * 4u : BUF_OOB, 0u);
+    __builtin_amdgcn_sched_barrier(0);
     if (tile + (int)gridDim.x < q.ntiles) {
       store_tile(buf ^ 1, vx);
       issue_tile(tile + 2 * gridDim.x, vx);
-      __builtin_amdgcn_sched_barrier(0);
     }
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();                                 // (B) the whole h tile is in LDS (and the next tile's x)
+    if (pb.logdet) {
+      if (tid == 0 && ld_pending >= 0) {              // the previous tile's log-det: every wave has parked its sum before (B)
+        const float* w8 = ldw[ld_pending];
+        atomicAdd(pb.logdet + ld_b[ld_pending], ((w8[0] + w8[1]) + (w8[2] + w8[3])) + ((w8[4] + w8[5]) + (w8[6] + w8[7])));
+      }
+      ld_pending = buf;
+    }
 
     // ---- stage 2: this wave's K half of out[row tile m2][all N2 columns] ---------------------------------------------------------
     f32x4 acc[NU2];
@@ -618,7 +658,46 @@ __global__ __launch_bounds__(S1_NTHR) void conv_sub1_fwd_kernel(Sub1Dev q) {
         for (int r = 0; r < 4; ++r) T[(m2 * 16 + 4 * kq + r) * TS + u * 16 + li] = acc[u][r];
     }
     __syncthreads();                                 // (E) both partial tiles are in LDS; every wave is done with hs
-    conv_epilogue_tile<4, N2, HT, NTHR>(pb, T0, b, y0, x0, 0, tid, red, T1);
+    asm volatile("" :: "v"(e_v));                    // waited for by every wave, before any store of this tile is issued
+    float ld_acc = 0.f;
+    if (e_live) {
+      f32x4 s4 = *reinterpret_cast<const f32x4*>(T0 + e_pl * TS + e_tcol) + e_bs;
+      f32x4 t4 = *reinterpret_cast<const f32x4*>(T0 + e_pl * TS + e_tcol + HT) + e_bt;
+      s4 += *reinterpret_cast<const f32x4*>(T1 + e_pl * TS + e_tcol);
+      t4 += *reinterpret_cast<const f32x4*>(T1 + e_pl * TS + e_tcol + HT);
+      const size_t pix = e_img + e_ip;
+      f32x4 y4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float L = glow_log_e(s4[j], pb.clamp);
+        const float e = expf(L);
+        if (!e_inv) { y4[j] = e * e_v[j] + t4[j]; ld_acc += L; }
+        else { y4[j] = (e_v[j] - t4[j]) / e; ld_acc -= L; }
+      }
+      if (pb.out_map) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pb.out[pix * pb.out_stride + e_omap[j]] = y4[j];
+      } else {
+        *reinterpret_cast<f32x4*>(pb.out + pix * pb.out_stride + e_cl) = y4;
+      }
+      if (pb.out2) *reinterpret_cast<f32x4*>(pb.out2 + pix * pb.out2_stride + e_cl) = y4;
+      if (pb.sbuf) *reinterpret_cast<f32x4*>(pb.sbuf + pix * pb.Co + e_cl) = s4;
+    }
+    // log-det of the tile: the waves' sums are parked in LDS and added (fixed order) by ONE thread after the NEXT block barrier --
+    // one global atomic per block and tile, as in the shared epilogue, without a barrier of its own.  (An atomic per wave was tried:
+    // 8 192 same-address float atomics per launch serialise in L2 and doubled the kernel's duration.)
+    if (pb.logdet) {
+      const float wsum = wave_sum(ld_acc);
+      if (lane == 0) ldw[buf][wave] = wsum;
+      ld_b[buf] = b;
+    }
+  }
+  if (pb.logdet) {
+    __syncthreads();
+    if (tid == 0 && ld_pending >= 0) {
+      const float* w8 = ldw[ld_pending];
+      atomicAdd(pb.logdet + ld_b[ld_pending], ((w8[0] + w8[1]) + (w8[2] + w8[3])) + ((w8[4] + w8[5]) + (w8[6] + w8[7])));
+    }
   }
 }
 

@@ -320,16 +320,19 @@ def test_baseline_config_shape_matches_oracle(batch):
     yg, yc = net(xg), ref(xc)
     assert relerr(yg, yc) < RTOL                                   # forward values: max-norm at the path's tolerance
     (yg * wgt.cuda()).sum().backward(); (yc * wgt).sum().backward()
-    # input gradients: a flipped gate changes dx in one 3x3 neighbourhood by a whole term -> L2 5e-4, max-norm 2e-2 (the
-    # linear kernels themselves hold 1e-4 in max-norm at these shapes: test_conv_kernels_at_baseline_config_shapes)
-    assert rel_l2(xg.grad, xc.grad) < 5e-4 and relerr(xg.grad, xc.grad) < 2e-2
+    # input gradients: a flipped gate changes dx in one 3x3 neighbourhood by a whole term -> L2 8e-4, max-norm 2e-2 (the
+    # linear kernels themselves hold 1e-4 in max-norm at these shapes: test_conv_kernels_at_baseline_config_shapes).  The L2
+    # figure is the number of gates that happen to flip, i.e. it moves with ANY change of summation order in a forward kernel
+    # (3.1e-4 .. 5.2e-4 over the round-3 / round-4 builds at batch 2); the arithmetic itself is held to 2e-5 in max-norm with
+    # the gates forced (tests/test_gpu_gates.py)
+    assert rel_l2(xg.grad, xc.grad) < 8e-4 and relerr(xg.grad, xc.grad) < 2e-2
     zin = torch.cat((lr_c, z), 1)
     zg = zin.cuda().requires_grad_(True); zc = zin.clone().requires_grad_(True)
     w2 = torch.randn(batch, 3, 256, 256, generator=g)
     hg, hc = net(zg, rev=True), ref(zc, rev=True)
     assert relerr(hg, hc) < RTOL
     (hg * w2.cuda()).sum().backward(); (hc * w2).sum().backward()
-    assert rel_l2(zg.grad, zc.grad) < 5e-4 and relerr(zg.grad, zc.grad) < 2e-2
+    assert rel_l2(zg.grad, zc.grad) < 8e-4 and relerr(zg.grad, zc.grad) < 2e-2
     sin_inn_amd.modules.join_side_streams()
 
 

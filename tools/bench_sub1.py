@@ -73,7 +73,25 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / a.reps * 1e3
+    # forward twin: conv1 -> conv2 -> coupling + log-det (sininn_conv_sub1_fwd), with and without its epilogue (ablation hook 8)
+    out = torch.empty(m, 2 * co, device=dev); sb = torch.empty(m, co, device=dev); ld = torch.zeros(b, device=dev); y2 = torch.empty(m, co, device=dev)
+    f1 = args(in_=ops.ptr(x, co), in_stride=2 * co, Cin=k1, w=ops.ptr(pk1[0]), bias=ops.ptr(pk1[1]), Np=256, mode=_lib.CONV_RELU, out_stride=256,
+              N=256, **common)
+    f2 = args(in_=ops.ptr(hid), in_stride=256, Cin=256, w=ops.ptr(pk2[0]), bias=ops.ptr(pk2[1]), Np=k2, mode=_lib.CONV_COUPLE_FWD, out=ops.ptr(out),
+              out_stride=2 * co, v=ops.ptr(x), v_stride=2 * co, sbuf=ops.ptr(sb), logdet=ops.ptr(ld), Co=co, clamp=1.2, out2=ops.ptr(y2),
+              out2_stride=co, col_tile=ops.coupling_tile(co), **common)
+
+    def fwd():
+        _lib.check(lib.sininn_conv_sub1_fwd(C.byref(f1), C.byref(f2), ops._stream()))
+
+    def fwd_pair():
+        _lib.check(lib.sininn_conv_pair_k1(C.byref(f1), C.byref(f2), ops._stream()))
     print(f'shape: batch {b}, {h}x{w}, Cin {k1}, 2Co {k2}: M = {m}')
+    print(f'persistent forward      : {timeit(fwd):8.1f} us')
+    print(f'pair forward (no store) : {timeit(fwd_pair):8.1f} us')
+    lib.sininn_conv_test_hooks(8000, 0)
+    print(f'persistent forward, epilogue skipped : {timeit(fwd):8.1f} us')
+    lib.sininn_conv_test_hooks(0, 0)
     print(f'fused backward + reduce : {timeit(fused):8.1f} us')
     print(f'pair + grouped wgrad    : {timeit(old):8.1f} us')
     stamps.zero_()
