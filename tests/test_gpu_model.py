@@ -340,19 +340,22 @@ def test_full_size_properties():
     """BASELINE config 2 (256x256, bs 16, -c 4), size-independent properties on top of the oracle comparison above:
     HIP forward -> HIP inverse round trip, log-det antisymmetry, permutation/squeeze bijectivity."""
     import archs
-    torch.manual_seed(0)
-    opt = make_opt(num_coupling=4, lr_window=10)
-    net = archs.UncondSRFlow(3, 256, 256, opt).cuda()
-    x = torch.rand(16, 3, 256, 256, device='cuda')
-    with torch.no_grad():
-        y = net(x)
-        ld_f = net.log_jacobian()
-        back = net(y, rev=True)
-        ld_r = net.log_jacobian()
-    assert y.shape == (16, 192, 32, 32)
-    assert relerr(back, x) < RTOL
-    assert relerr(ld_r, -ld_f) < 1e-3
-    assert torch.isfinite(y).all()
+    for c in (4, 8):                                   # both readings of "8-block": -c 4 (8 GLOW blocks) and -c 8 (16)
+        torch.manual_seed(0)
+        opt = make_opt(num_coupling=c, lr_window=10)
+        net = archs.UncondSRFlow(3, 256, 256, opt).cuda()
+        x = torch.rand(16, 3, 256, 256, device='cuda')
+        with torch.no_grad():
+            y = net(x)
+            ld_f = net.log_jacobian()
+            back = net(y, rev=True)
+            ld_r = net.log_jacobian()
+        assert y.shape == (16, 192, 32, 32)
+        assert relerr(back, x) < RTOL
+        assert relerr(ld_r, -ld_f) < 1e-3
+        assert torch.isfinite(y).all()
+        del net, x, y, back
+        torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize('shape,b,c', [((40, 56), 1, 1), ((24, 136), 3, 2), ((72, 80), 2, 1)])
@@ -396,9 +399,10 @@ def test_bigger_configs_properties():
         torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize('shape,num_coupling', [((512, 512), 4), ((720, 1280), 12)])
+@pytest.mark.parametrize('shape,num_coupling', [((512, 512), 4), ((720, 1280), 12), ((256, 256), 8)])
 def test_fp32_forward_parity_at_bigger_config_shapes(shape, num_coupling):
-    """The fp32 path against the oracle at the SHAPES of BASELINE configs[3] / [4] (512x512 -c 4; 1280x720 -c 12), batch 1:
+    """The fp32 path against the oracle at the SHAPES of BASELINE configs[3] / [4] (512x512 -c 4; 1280x720 -c 12) and at the other
+    reading of configs[1]'s "8-block" (256x256, -c 8 = 16 GLOW blocks, SURVEY 8d row 2'; `bench.py --num-coupling 8`), batch 1:
     forward values, log-det and the inverse direction at the path's 1e-4 (their bf16 arithmetic is covered by
     tests/test_gpu_bf16.py::test_bf16_at_baseline_config_shapes)."""
     import archs
