@@ -172,6 +172,22 @@ def cpu_baseline(args, opt, seconds_budget=30.0):
                       f'{torch.get_num_threads()} threads = every core this process may use'}
 
 
+_JSON_FD = [None]
+
+
+def claim_stdout():
+    """fd 1 carries the JSON line and nothing else.  Native libraries print there too (gloo: "[Gloo] Rank 0 is connected to ..."),
+    so from here on everything written to fd 1 lands on stderr and emit() alone writes to the real stdout."""
+    sys.stdout.flush()
+    _JSON_FD[0] = os.dup(1)
+    os.dup2(2, 1)
+
+
+def emit(line):
+    sys.stdout.flush()
+    os.write(1 if _JSON_FD[0] is None else _JSON_FD[0], (line + '\n').encode())   # one write: the ranks share the launcher's pipe
+
+
 def self_launch(n):
     """Run this script under torch.distributed.run with n ranks (one per GPU) and relay rank 0's JSON line."""
     import socket
@@ -184,8 +200,10 @@ def self_launch(n):
            '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     for line in proc.stdout:                 # rank 0 prints exactly one JSON line on stdout; stderr passes through
-        sys.stdout.write(line)
-        sys.stdout.flush()
+        if line.startswith('{'):
+            emit(line.rstrip('\n'))
+        else:
+            sys.stderr.write(line)
     return proc.wait()
 
 
@@ -213,8 +231,7 @@ def rehearse(args, rank, ws):
                           'data': 'synthetic', 'rehearsal': True, 'distributed': distributed_record(ranks, None, float(dt) / args.steps * 1e3),
                           'config': {'workload': 'REHEARSAL of the multi-rank plumbing on CPU (gloo): no kernels run',
                                      'global_batch': ws * args.batch, 'parallelism': f'dp{ws}'}})
-        sys.stdout.write(line + '\n')                     # one write: the ranks share the launcher's stdout pipe
-        sys.stdout.flush()
+        emit(line)
     return 0
 
 
@@ -343,6 +360,7 @@ def main():
                     help='full: forward / reverse pass chains on two streams + weight gradients on a third (default below 2 M level-0 '
                          'pixels per batch); wgrad: one chain + the weight-gradient stream; none == --no-overlap')
     args = ap.parse_args()
+    claim_stdout()
     preset = CONFIGS[args.config]
     if args.size is not None:
         args.height = args.width = args.size
@@ -691,8 +709,7 @@ def main():
         out['cpu_baseline'] = cpu_baseline(args, opt)
     else:
         out['cpu_baseline'] = None
-    sys.stdout.write(json.dumps(out) + '\n')          # one write: under a launcher the ranks share the stdout pipe
-    sys.stdout.flush()
+    emit(json.dumps(out))
 
 
 if __name__ == '__main__':

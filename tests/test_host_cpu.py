@@ -177,8 +177,8 @@ def test_bench_self_launches_its_ranks_cpu_rehearsal(n):
         if out.returncode == 0:
             break
     assert out.returncode == 0, out.stdout + out.stderr
-    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 1
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1, out.stdout      # stdout is the JSON line alone: what gloo / the launcher print goes to stderr (bench.claim_stdout)
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == n and rec['steps'] == 3 and rec['rehearsal'] is True and rec['scaling'] == 'weak'
     assert rec['config']['global_batch'] == 16 * n and rec['config']['parallelism'] == f'dp{n}'
