@@ -28,40 +28,11 @@
 // At the end a block writes its partial gradients as ONE slab; sub1_reduce_kernel sums the slabs in a fixed order into the OIHW
 // gradients (bitwise reproducible, no float atomics) -- on the weight-gradient stream, like every other += into a gradient.
 #include <cstdlib>
-#include "conv_mfma_impl.h"
+#include "conv_sub1_types.h"
 
 namespace sininn {
 
 int conv_prepare(const sininn_conv_args* a, ConvDev& d);
-
-constexpr int S1_HID = 256;            // hidden channels (SININN_HIDDEN)
-constexpr int S1_HS = S1_HID + 4;      // floats per pixel row of the hidden tile in LDS
-constexpr int S1_P = 64;               // pixels per tile (4 x 16)
-constexpr int S1_NTHR = 512;           // 8 waves: wave w owns hidden columns [32 w, 32 w + 32)
-constexpr int S1_MAX_BLOCKS = 256;     // persistent blocks == slabs (one per CU: 122 KB of LDS)
-
-struct Sub1Dev {
-  ConvDev r;        // recompute: in = x (the subnet's input), w = W1 forward pack [256][K1], bias = b1
-  ConvDev a;        // data gradient of conv2: in = dr [.. K2], w = W2 data-gradient pack [256][K2]
-  ConvDev b;        // data gradient of conv1: w = W1 data-gradient pack [pad16(K1)][256] + the epilogue descriptor
-  float* slab;      // [blocks][slab_floats]
-  int ntiles, no_dx;
-};
-
-template <int K1, int K2>
-struct Sub1Shape {
-  static constexpr int K1R = (K1 + 15) / 16 * 16;          // stage R walks K in steps of 16
-  static constexpr int NU1 = (K1 + 16) / 16;               // 16-column tiles of [x | 1] (weight gradient of conv1 + db1)
-  static constexpr int XD = K1R > 16 * NU1 ? K1R : 16 * NU1;
-  static constexpr int XS = XD + 4;                         // floats per pixel row of the x tile
-  static constexpr int DS = K2 + 4;                         // ... of the dr tile
-  static constexpr int NU2 = K2 / 16;
-  static constexpr int NP1 = K1R;                           // columns of the data gradient of conv1 (pad16)
-  static constexpr int NT2 = NP1 / 16;
-  static constexpr int W1S = 16 * NU1;                      // slab row of dW1: [K1 channels | db1 | zero pad]
-  static constexpr int SLAB = K2 * S1_HID + S1_HID * W1S + 64;   // dW2 [K2][256] | dW1^T [W1S][256] (row K1 = db1) | db2 [64]
-  static constexpr size_t LDS = (size_t)(S1_P * S1_HS + 2 * (S1_P * DS + S1_P * XS) + NP1 * S1_HS + S1_P * (NP1 + 4)) * sizeof(float);
-};
 
 template <int K1, int K2, bool STAMP>
 __global__ __launch_bounds__(S1_NTHR) void conv_sub1_bwd_kernel(Sub1Dev q) {
@@ -749,17 +720,27 @@ __global__ __launch_bounds__(256) void sub1_reduce_kernel(const float* __restric
   }
 }
 
+// conv_sub1_bf16.hip: the mixed-precision twins (bf16 weight packs, fp32 tensors)
+bool conv_sub1_bf16_enabled();
+void conv_sub1_bf16_enable(int on);
+int conv_sub1_bf16_bwd_launch(const sininn_conv_args* rc, const sininn_conv_args* d2, const sininn_conv_args* d1, int no_dx, void* ws,
+                              size_t ws_bytes, int* slabs_out, hipStream_t st);
+int conv_sub1_bf16_fwd_supported(const sininn_conv_args* f, const sininn_conv_args* s);
+int conv_sub1_bf16_fwd_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st);
+
 static bool g_sub1_enabled = getenv("SININN_SUB1_BWD") == nullptr || atoi(getenv("SININN_SUB1_BWD")) != 0;   // A/B switch
-void conv_sub1_bwd_enable(int on) { g_sub1_enabled = on != 0; }
+void conv_sub1_bwd_enable(int on) { g_sub1_enabled = on != 0; conv_sub1_bf16_enable(on); }
 bool conv_sub1_bwd_enabled() { return g_sub1_enabled; }
 
-static bool shape_ok(int k1, int k2) { return (k1 == 8 && k2 == 16) || (k1 == 16 && k2 == 32) || (k1 == 24 && k2 == 48); }
+static bool shape_ok(int k1, int k2) { return sub1_shape_ok(k1, k2); }
+
 
 // Shapes the fused backward serves: a fp32 1x1 subnet with K1 = Cin of conv1 and K2 = 2 * Co columns of conv2 in {(8, 16),
 // (16, 32), (24, 48)} -- level 0 of the SRF network (C = 48: 24 | 24) and the small networks of the tests.  Wider subnets (level 1: 96 / 192) would need
 // 300 accumulator registers per lane for the two weight gradients and stay on the data-gradient pair + grouped weight gradients.
 int conv_sub1_bwd_shape_supported(int ksize, int dtype, int cond_cin, int co) {
-  return g_sub1_enabled && ksize == 1 && dtype == 0 && shape_ok(cond_cin, 2 * co);
+  const bool on = dtype == 0 ? g_sub1_enabled : (dtype == 1 && conv_sub1_bf16_enabled());
+  return on && ksize == 1 && shape_ok(cond_cin, 2 * co);
 }
 
 size_t conv_sub1_bwd_workspace_bytes(int cond_cin, int co) {
@@ -798,6 +779,7 @@ static int sub1_reduce(const float* slabs, int S, float* gw2, float* gb2, float*
 int conv_sub1_bwd_launch(const sininn_conv_args* rc, const sininn_conv_args* d2, const sininn_conv_args* d1, int no_dx, void* ws,
                          size_t ws_bytes, int* slabs_out, hipStream_t st) {
   SININN_CHECK(rc && d2 && d1 && ws && slabs_out, "conv_sub1_bwd: null argument");
+  if (rc->w_bf16) return conv_sub1_bf16_bwd_launch(rc, d2, d1, no_dx, ws, ws_bytes, slabs_out, st);
   const int K1 = rc->Cin, K2 = d2->Cin;
   SININN_CHECK(shape_ok(K1, K2), "conv_sub1_bwd: unsupported subnet shape (Cin %d, 2 Co %d)", K1, K2);
   SININN_CHECK(rc->ksize == 1 && d2->ksize == 1 && d1->ksize == 1 && !rc->w_bf16 && !d2->w_bf16 && !d1->w_bf16 && !rc->winograd &&
@@ -874,6 +856,7 @@ static int sub1_fwd_launch(Sub1Dev& q, hipStream_t st) {
 // first: conv1 of the subnet (mode RELU; `out` is ignored: the hidden tensor is never stored), second: conv2 with a coupling
 // epilogue (COUPLE_FWD / COUPLE_INV), described as for sininn_conv_pair_k1.
 int conv_sub1_fwd_supported(const sininn_conv_args* f, const sininn_conv_args* s) {
+  if (f && s && f->w_bf16) return conv_sub1_bf16_fwd_supported(f, s);
   if (!g_sub1_enabled || !f || !s) return 0;
   if (f->ksize != 1 || s->ksize != 1 || f->w_bf16 || s->w_bf16 || f->winograd || s->winograd || f->in_bf16 || s->in_bf16 || f->out_bf16) return 0;
   if (f->in_group_stride > 0 || f->out_group_stride > 0 || s->in_group_stride > 0) return 0;
@@ -885,6 +868,7 @@ int conv_sub1_fwd_supported(const sininn_conv_args* f, const sininn_conv_args* s
 
 int conv_sub1_fwd_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st) {
   SININN_CHECK(conv_sub1_fwd_supported(f, s), "conv_sub1_fwd: unsupported subnet (check sininn_conv_sub1_fwd_supported first)");
+  if (f->w_bf16) return conv_sub1_bf16_fwd_launch(f, s, st);
   SININN_CHECK((unsigned long long)f->H * f->W * f->in_stride * 4ull < (1ull << 31),
                "conv_sub1_fwd: one image of the input exceeds the 2 GB a block addresses (raw buffer staging)");
   Sub1Dev q;

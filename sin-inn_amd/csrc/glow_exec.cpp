@@ -346,12 +346,19 @@ int glow_hidden_gates(const sininn_glow_args* a, int which, unsigned char* gates
       c1.Cin = cond_cin; c1.w = hv[which].net->w1; c1.bias = hv[which].net->b1; c1.Np = SININN_HIDDEN;
       c1.B = a->B; c1.H = a->H; c1.W = a->W; c1.ksize = 1; c1.mode = SININN_CONV_RELU;
       c1.out = h; c1.out_stride = SININN_HIDDEN; c1.N = SININN_HIDDEN;
+      if (a->dtype == 1) {
+        // mixed precision: h = bf16(relu(fp32 sum + b1)), the sum taken over two 16-channel steps of v_mfma_f32_32x32x16_bf16
+        // from zero -- the stand-alone bf16 conv, the pair kernel and the persistent kernels all issue exactly that chain
+        c1.w_bf16 = 1; c1.out_bf16 = 1;
+        if (int rc = conv_launch(&c1, st)) return rc;
+      } else {
       sininn_conv_args c2 = {};
       c2.in = h; c2.in_stride = SININN_HIDDEN; c2.Cin = SININN_HIDDEN; c2.w = hv[which].net->w2; c2.Np = 2 * hv[which].co;
       c2.B = a->B; c2.H = a->H; c2.W = a->W; c2.ksize = 1; c2.mode = SININN_CONV_LINEAR;
       c2.out = which == 0 ? sv.h_b : sv.h_a; c2.out_stride = 2 * hv[which].co; c2.N = 2 * hv[which].co;
       SININN_CHECK(conv_pair_k1_supported(&c1, &c2), "glow_hidden_gates: the 1x1 pair kernel is switched off (needed to reproduce the recomputed h)");
       if (int rc = conv_pair_k1_launch(&c1, &c2, st)) return rc;
+      }
     }
   }
   const int64_t total = (int64_t)M * SININN_HIDDEN;
@@ -535,6 +542,7 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
       sininn_conv_args rc = {};
       rc.in = cond; rc.in_stride = cond_stride; rc.Cin = cond_cin; rc.w = net->w1; rc.bias = net->b1; rc.Np = SININN_HIDDEN;
       rc.B = B; rc.H = H; rc.W = W; rc.ksize = 1; rc.mode = SININN_CONV_RELU;
+      if (bf16) rc.w_bf16 = 1;
       const int which = (&h == &hv[0]) ? 0 : 1;
       int slabs = 0;
       {

@@ -365,3 +365,59 @@ def test_fused_3x3_subnet_through_the_c_abi():
     # a first conv that stores its hidden tensor is not this kernel's case
     f.out = outs[0][0].data_ptr()
     assert lib.sininn_conv_sub3_supported(C.byref(f), C.byref(s)) == 0
+
+
+@pytest.mark.parametrize('rev', [False, True])
+@pytest.mark.parametrize('channels,hw', [(48, (13, 21)), (48, (64, 64)), (16, (9, 33)), (32, (5, 16)), (48, (70, 40))])
+def test_fused_1x1_subnet_bf16_matches_the_pair_path(rev, channels, hw):
+    """Round 4: on the mixed-precision path the level-0 1x1 subnets run as the persistent fused kernels too (conv_sub1_bf16.hip:
+    forward without storing h; the whole backward -- recompute, both data gradients, both weight gradients -- in one launch with h /
+    dh on chip).  Same block, same inputs with the switch off (bf16 pair kernels + grouped bf16 weight gradients, h / dh in HBM
+    as bf16).  From the same fp32 input a subnet's h and dh are bitwise the same in both paths (the same chain of 32x32x16 MFMA steps
+    from zero, one rounding to bf16); the second GEMMs and the weight-gradient sums run in another order, so the fp32 tensors
+    BETWEEN the two subnets of a block (the first half's output / the fused coupling-backward's dr) differ in the last bit, and a
+    value next to a bf16 rounding boundary then lands one bf16 ulp apart in the next subnet (the budget of the fused 3x3 test
+    above: 8e-3 of the max-norm -- a flipped ReLU gate in one unit; 5e-4 in L2).  db2 is summed from the fp32 dr here, from its bf16 rounding in the
+    grouped kernel (1 - 2e-3 apart).  And against the oracle's bf16 emulation at the budget of this file.  Ragged sizes (tiles
+    cut in x and y), the three shapes the kernels serve, both directions, gradients accumulate."""
+    import archs
+    import sin_inn_amd as S
+    from sin_inn_amd import _lib
+    from oracle import sininn_oracle as O
+    torch.manual_seed(channels + hw[0])
+    h, w = hw
+    blk = S.GLOWCouplingBlock([(channels, h, w)], subnet_constructor=archs.subnet_conv_1x1, clamp=1.2)
+    emu = O.GlowBlock(channels, 1, 1.2)
+    emu.load_state_dict({k: v.clone() for k, v in blk.state_dict().items()})
+    emu.emulate_bf16 = True
+    for net in (blk, emu):
+        for p in net.parameters():
+            p.data.mul_(3.0)
+    blk.cuda()
+    blk.precision = 'bf16'
+    x = torch.randn(2, channels, h, w)
+    wgt, ld_w = torch.randn_like(x), torch.randn(2)
+    res = []
+    try:
+        for fused in (1, 0):
+            _lib.lib().sininn_sub1_bwd_test_hook(fused)
+            blk.zero_grad()
+            for _ in range(2):                          # twice: the gradients accumulate
+                xg = x.cuda().requires_grad_(True)
+                y = blk([xg], rev=rev)[0]
+                ((y * wgt.cuda()).sum() + (blk.last_jac * ld_w.cuda()).sum()).backward()
+            S.modules.join_side_streams()
+            res.append([y.detach(), blk.last_jac.detach().clone(), xg.grad] + [p.grad.clone() for p in blk.parameters()])
+    finally:
+        _lib.lib().sininn_sub1_bwd_test_hook(1)
+    names = ['y', 'logdet', 'dx'] + [n for n, _ in blk.named_parameters()]
+    for i, (a, b) in enumerate(zip(*res)):
+        assert relerr(a, b) < 8e-3 and rel_l2(a, b) < (2e-3 if names[i].endswith('2.bias') else 5e-4), (names[i], relerr(a, b), rel_l2(a, b))
+    xe = x.clone().requires_grad_(True)
+    ye = emu(xe, rev=rev)
+    ((ye * wgt).sum() + (emu.last_jac * ld_w).sum()).backward()
+    y_f, ld_f, dx_f = res[0][:3]
+    assert relerr(y_f, ye) < 2e-2 and rel_l2(y_f, ye) < 3e-3 and relerr(ld_f, emu.last_jac) < 2e-2
+    assert rel_l2(dx_f, xe.grad) < 2e-2
+    for (n, pe), g in zip(emu.named_parameters(), res[0][3:]):
+        assert rel_l2(g, 2 * pe.grad) < 5e-2, n       # two accumulated passes on the device
