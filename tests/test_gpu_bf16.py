@@ -421,3 +421,93 @@ def test_fused_1x1_subnet_bf16_matches_the_pair_path(rev, channels, hw):
     assert rel_l2(dx_f, xe.grad) < 2e-2
     for (n, pe), g in zip(emu.named_parameters(), res[0][3:]):
         assert rel_l2(g, 2 * pe.grad) < 5e-2, n       # two accumulated passes on the device
+
+
+@pytest.mark.parametrize('co,b,hw,no_dx', [(24, 2, (13, 21), False), (24, 16, (128, 128), False), (8, 3, (9, 33), False), (16, 1, (2, 16), False),
+                                           (24, 2, (7, 40), True)])
+def test_fused_1x1_subnet_bf16_c_abi(co, b, hw, no_dx):
+    """sininn_conv_sub1_fwd / sininn_conv_sub1_bwd with bf16 weight packs, called directly, against torch arithmetic on the SAME
+    bf16-rounded operands (x, dr, h, dh and the weights rounded to bf16, products exact, sums in float64): what remains is the
+    fp32 accumulation order of the MFMAs, and -- in a handful of the 10^5 .. 10^8 hidden values -- a sum that sits on a bf16 rounding
+    boundary and lands one ulp apart (or, for a pre-activation within rounding distance of 0, on the other side of the gate):
+    2e-5 in L2 and 2e-3 of the max-norm for y / s / dx, 1e-4 of the max-norm for the log-det and the weight gradients (sums over
+    pixels); db2 is summed from the fp32 dr.  Partial tiles, more tiles than persistent blocks (4096 on 256), a single tile, the three shapes, no_dx."""
+    import ctypes as C
+    import sin_inn_amd
+    from sin_inn_amd import _lib, ops
+    lib = _lib.lib()
+    dev = torch.device('cuda')
+    torch.manual_seed(co + b)
+    h, w = hw
+    k1, k2, m = co, 2 * co, b * h * w
+    cx = 2 * co + 8                                               # x lives inside a wider tensor (channel offset 8)
+    bft = torch.bfloat16
+    xfull = torch.randn(m, cx, device=dev)
+    conv1 = torch.nn.Conv2d(k1, 256, 1).to(dev)
+    conv2 = torch.nn.Conv2d(256, k2, 1).to(dev)
+    with torch.no_grad():
+        conv2.weight.mul_(0.3)
+    cmap = ops.coupling_colmap(co, dev)
+    pk1 = ops.pack_conv_bf16(conv1.weight.detach(), conv1.bias.detach(), None, True)
+    pk2 = ops.pack_conv_bf16(conv2.weight.detach(), conv2.bias.detach(), cmap, True)
+    dr = torch.randn(m, k2, device=dev)
+    addend = torch.randn(m, k1, device=dev)
+    vfull = torch.randn(m, cx, device=dev)
+
+    def args(**kw):
+        a = _lib.ConvArgs()
+        for k, v in kw.items():
+            setattr(a, 'inp' if k == 'in_' else k, v)
+        return a
+    pb = lambda t: ops.ptr(t, dtype=bft)
+    common = dict(B=b, H=h, W=w, ksize=1, w_bf16=1)
+    # ---- reference on bf16-rounded operands (float64 sums) --------------------------------------------------------------------
+    x = xfull[:, 8:8 + k1]
+    xb, drb = bf(x).double(), bf(dr).double()
+    w1, w2 = bf(conv1.weight.detach().reshape(256, k1)).double(), bf(conv2.weight.detach().reshape(k2, 256)).double()
+    hid = bf(torch.relu(xb @ w1.t() + conv1.bias.detach().double()).float()).double()          # one rounding of the fp32 sum
+    st = hid @ w2.t() + conv2.bias.detach().double()
+    s_ref, t_ref = st[:, :co], st[:, co:]
+    L = 1.2 * 0.636 * torch.atan(s_ref / 1.2)
+    v = vfull[:, :co].double()
+    y_ref = torch.exp(L) * v + t_ref
+    ld_ref = L.reshape(b, -1).sum(1)
+    dh = bf(((drb @ w2) * (hid > 0)).float()).double()
+    dx_ref = dh @ w1 + addend.double()
+    # ---- forward ----------------------------------------------------------------------------------------------------------------
+    out = torch.full((m, cx), float('nan'), device=dev); sb = torch.empty(m, co, device=dev); ld = torch.zeros(b, device=dev)
+    y2 = torch.empty(m, co, device=dev)
+    f1 = args(in_=ops.ptr(xfull, 8), in_stride=cx, Cin=k1, w=pb(pk1[0]), bias=ops.ptr(pk1[1]), Np=256, mode=_lib.CONV_RELU, out_stride=256,
+              N=256, out_bf16=1, **common)
+    f2 = args(in_stride=256, Cin=256, w=pb(pk2[0]), bias=ops.ptr(pk2[1]), Np=k2, mode=_lib.CONV_COUPLE_FWD, out=ops.ptr(out),
+              out_stride=cx, v=ops.ptr(vfull), v_stride=cx, sbuf=ops.ptr(sb), logdet=ops.ptr(ld), Co=co, clamp=1.2, out2=ops.ptr(y2),
+              out2_stride=co, col_tile=ops.coupling_tile(co), in_bf16=1, **common)
+    assert lib.sininn_conv_sub1_fwd_supported(C.byref(f1), C.byref(f2)) == 1
+    _lib.check(lib.sininn_conv_sub1_fwd(C.byref(f1), C.byref(f2), ops._stream()))
+    torch.cuda.synchronize()
+    close = lambda a_, b_: relerr(a_, b_) < 2e-3 and rel_l2(a_, b_) < 2e-5
+    assert close(out[:, :co], y_ref.float()) and torch.equal(out[:, :co], y2) and bool(torch.isnan(out[:, co:]).all())
+    assert close(sb, s_ref.float()) and relerr(ld, ld_ref.float()) < 1e-4
+    # ---- backward ---------------------------------------------------------------------------------------------------------------
+    g0 = [torch.randn_like(conv2.weight), torch.randn_like(conv2.bias), torch.randn_like(conv1.weight), torch.randn_like(conv1.bias)]
+    gw2, gb2, gw1, gb1 = (g.clone().contiguous() for g in g0)
+    dx = torch.full((m, k1), float('nan'), device=dev)
+    rc = args(in_=ops.ptr(xfull, 8), in_stride=cx, Cin=k1, w=pb(pk1[0]), bias=ops.ptr(pk1[1]), Np=256, **common)
+    d2 = args(in_=ops.ptr(dr), in_stride=k2, Cin=k2, w=pb(pk2[2]), Np=256, mode=_lib.CONV_MASK, out_stride=256, N=256, mask_stride=256,
+              out_bf16=1, mask_bf16=1, **common)
+    d1 = args(in_stride=256, Cin=256, w=pb(pk1[2]), Np=ops.pad16(k1), mode=_lib.CONV_ADD, out=ops.ptr(dx), out_stride=k1, N=k1,
+              addend=ops.ptr(addend), addend_stride=k1, in_bf16=1, **common)
+    nbytes = lib.sininn_conv_sub1_bwd_workspace_bytes(k1, co)
+    ws = torch.empty(nbytes // 4, device=dev)
+    _lib.check(lib.sininn_conv_sub1_bwd(C.byref(rc), C.byref(d2), C.byref(d1), int(no_dx), ops.ptr(gw2), ops.ptr(gb2), ops.ptr(gw1),
+                                        ops.ptr(gb1), ops.ptr(ws), nbytes, ops._stream()))
+    torch.cuda.synchronize()
+    if no_dx:
+        assert bool(torch.isnan(dx).all())                         # untouched
+    else:
+        assert close(dx, dx_ref.float()), (relerr(dx, dx_ref.float()), rel_l2(dx, dx_ref.float()))
+    # dr is in conv2's OIHW channel order (ds | dt); only the FORWARD pack of conv2 is column-interleaved
+    want = [g0[0].double() + (drb.t() @ hid).reshape(k2, 256, 1, 1), g0[1].double() + dr.double().sum(0),
+            g0[2].double() + (dh.t() @ xb).reshape(256, k1, 1, 1), g0[3].double() + dh.sum(0)]
+    for name, got, ref_ in zip(('gw2', 'gb2', 'gw1', 'gb1'), (gw2, gb2, gw1, gb1), want):
+        assert relerr(got, ref_.float()) < 1e-4, (name, relerr(got, ref_.float()))
