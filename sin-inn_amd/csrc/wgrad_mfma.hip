@@ -665,6 +665,7 @@ struct WgradProb {
                            // they are skipped and later channels shift down (IRN DenseBlock feature buffer, cin padded to 8)
   int S, nblk, cblk;
   int wide_c;            // Winograd kernel: this problem's blocks are 32 n x 64 c (N <= 32) instead of 64 n x 32 c
+  int narrow_c;          // bf16 kernel: this problem's blocks are 128 n x 32 c (Cin <= 32) instead of 64 n x 64 c
   int block_begin;       // first block of this problem in the grouped gradient grid
   int red_begin;         // first block of this problem in the grouped reduce grid
 };
@@ -882,26 +883,29 @@ __device__ __forceinline__ unsigned pack_bf16_pair(float lo, float hi) {
 constexpr int WGB_PD = 128 * 2 + 16;                                  // bytes per dout row (channel n): 4-bank step
 constexpr int wgb_pi(int ks) { return (((8 + 2 * (ks / 2)) * 24 * 2 + 255) / 256) * 256 + 16; }   // bytes per in row (channel c)
 
-template <int KS, bool IN_BF16, bool DOUT_BF16>
+// NARROW: the block is 128 n x 32 c (four waves side by side along n) instead of 64 x 64: a conv with Cin <= 32 (the 3x3 conv1 of a
+// level-0 subnet: 24 input channels) then pads its channel axis to 32, not 64 -- half the MFMAs and half the staging of that operand
+template <int KS, bool IN_BF16, bool DOUT_BF16, bool NARROW = false>
 __device__ __forceinline__ void wgrad_bf16_body(const WgradDev& p, const int split, const int n0, const int c0, const int zblock,
                                                 unsigned char* const lds) {
+  constexpr int ND = NARROW ? 128 : 64, NI = NARROW ? 32 : 64;        // staged channels of dout / in
   constexpr int HALO = KS / 2, TAPS = KS * KS, TH = 8;
   constexpr int IROWS = TH + 2 * HALO, IWV = 16 + 2 * HALO;          // staged halo rows, valid pixels per halo row
   constexpr int IROWP = 24;                                           // pixels per halo row in LDS (x = 16 .. 23 readable)
   constexpr int PD = WGB_PD, PI = wgb_pi(KS);
   constexpr int IPAIRS = IROWS * (IWV / 2);                           // pixel pairs of the halo tile
-  constexpr int DG = DOUT_BF16 ? 8 : 16, IG = IN_BF16 ? 8 : 16;       // channel groups of the 64 staged channels (8 bf16 / 4 fp32 per load)
+  constexpr int DG = ND / (DOUT_BF16 ? 8 : 4), IG = NI / (IN_BF16 ? 8 : 4);   // channel groups of the staged channels (8 bf16 / 4 fp32 per load)
   constexpr int D_ITEMS = 64 * DG / 256;                              // (pixel pair, group) items per thread: 2 / 4
   constexpr int I_GRPS = 64 * IG / 256, I_RND = (IPAIRS + 63) / 64;   // groups per thread, rounds of 64 pixel pairs
   constexpr int I_ITEMS = I_GRPS * I_RND;
   constexpr bool PF_I = IN_BF16 || KS == 1, PF_D = (DOUT_BF16 && !(IN_BF16 && KS == 3)) || KS == 1;
   unsigned char* const dT = lds;
-  unsigned char* const iT = lds + 64 * PD;
+  unsigned char* const iT = lds + ND * PD;
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, h = lane >> 5;
-  const int wr = wave & 1, wc = wave >> 1;
+  const int wr = NARROW ? wave : (wave & 1), wc = NARROW ? 0 : (wave >> 1);
 
   f32x16 acc[TAPS];
 #pragma unroll
@@ -1138,13 +1142,20 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradDev& p, const int spl
 
 template <int KS>
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_group_kernel(WgradGroup g) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[64 * WGB_PD + 64 * wgb_pi(KS)];
+  constexpr int LDS_WIDE = 64 * WGB_PD + 64 * wgb_pi(KS), LDS_NARROW = 128 * WGB_PD + 32 * wgb_pi(KS);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_WIDE > LDS_NARROW ? LDS_WIDE : LDS_NARROW];
   const int pi = group_problem(g, blockIdx.x, false);
   const WgradProb& q = g.p[pi];
   const int lb = blockIdx.x - q.block_begin;
   const int split = lb % q.S, nb = (lb / q.S) % q.nblk, cb = lb / (q.S * q.nblk);
   // operand storage types are per problem (block-uniform): conv2's gradient reads a bf16 hidden tensor and the fp32 tail
   // gradient, conv1's the fp32 input and the bf16 hidden gradient
+  if (q.narrow_c) {
+    if (q.d.in_bf16 && !q.d.dout_bf16) wgrad_bf16_body<KS, true, false, true>(q.d, split, nb * 128, cb * 32, cb, lds);
+    else if (!q.d.in_bf16 && q.d.dout_bf16) wgrad_bf16_body<KS, false, true, true>(q.d, split, nb * 128, cb * 32, cb, lds);
+    else wgrad_bf16_body<KS, true, true, true>(q.d, split, nb * 128, cb * 32, cb, lds);
+    return;
+  }
   if (q.d.in_bf16 && !q.d.dout_bf16) wgrad_bf16_body<KS, true, false>(q.d, split, nb * 64, cb * 64, cb, lds);
   else if (!q.d.in_bf16 && q.d.dout_bf16) wgrad_bf16_body<KS, false, true>(q.d, split, nb * 64, cb * 64, cb, lds);
   else wgrad_bf16_body<KS, true, true>(q.d, split, nb * 64, cb * 64, cb, lds);
@@ -1154,6 +1165,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_group_kernel(WgradGroup g) 
 struct WgradGroupPlan { WgradGroup g; int grad_blocks, red_blocks; size_t bytes; bool wino; int th; bool mfma_bf16; };
 
 static bool g_wgrad_wide_c = true;      // test hook bit 7 clears: N <= 32 problems use the 64 x 32 block shape like everything else
+                                        // (and Cin <= 32 problems of the bf16 kernel its 64 x 64 blocks instead of 128 x 32)
 static bool g_wgrad_bf16_mfma = true;   // test hook bit 6 clears: bf16-operand problems accumulate on the f32 pipe (Winograd)
 void wgrad_set_bf16_mfma(int on) { g_wgrad_bf16_mfma = on != 0; }
 void wgrad_set_wide_c(int on) { g_wgrad_wide_c = on != 0; }
@@ -1190,7 +1202,8 @@ static int plan_group(const sininn_wgrad_item* items, int n, int B, int H, int W
     const sininn_wgrad_item& it = items[i];
     SININN_CHECK(it.Cin > 0 && it.Cin % 4 == 0 && it.N > 0 && it.N % 4 == 0, "wgrad_group: Cin=%d and N=%d must be multiples of 4", it.Cin, it.N);
     const bool wide_c = pl.wino && it.N <= 32 && g_wgrad_wide_c;
-    const int bn_i = wide_c ? 32 : bnw, bc_i = wide_c ? 64 : bcw;
+    const bool narrow_c = pl.mfma_bf16 && it.Cin <= 32 && it.N >= 128 && g_wgrad_wide_c;
+    const int bn_i = wide_c ? 32 : (narrow_c ? 128 : bnw), bc_i = wide_c ? 64 : (narrow_c ? 32 : bcw);
     out_tiles += ((it.N + bn_i - 1) / bn_i) * ((it.Cin + bc_i - 1) / bc_i);
   }
   // two blocks per CU; all problems of a group see the same pixels, so one split count serves them all
@@ -1210,7 +1223,8 @@ static int plan_group(const sininn_wgrad_item* items, int n, int B, int H, int W
     const sininn_wgrad_item& it = items[i];
     WgradProb& q = pl.g.p[i];
     q.wide_c = (pl.wino && it.N <= 32 && g_wgrad_wide_c) ? 1 : 0;
-    const int bn_i = q.wide_c ? 32 : bnw, bc_i = q.wide_c ? 64 : bcw;
+    q.narrow_c = (pl.mfma_bf16 && it.Cin <= 32 && it.N >= 128 && g_wgrad_wide_c) ? 1 : 0;
+    const int bn_i = q.wide_c ? 32 : (q.narrow_c ? 128 : bnw), bc_i = q.wide_c ? 64 : (q.narrow_c ? 32 : bcw);
     q.nblk = (it.N + bn_i - 1) / bn_i; q.cblk = (it.Cin + bc_i - 1) / bc_i; q.S = S;
     WgradDev& d = q.d;
     d.in = it.in; d.in_stride = it.in_stride; d.Cin = it.Cin; d.dout = it.dout; d.dout_stride = it.dout_stride; d.N = it.N;

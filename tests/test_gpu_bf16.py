@@ -111,7 +111,8 @@ def test_wgrad_group_with_bf16_operands(ksize, pipe, hw):
     torch.manual_seed(5 + ksize)
     b, (h, w) = 2, hw
     probs, wants = [], []
-    for cin, n, in_b, dout_b in ((256, 48, True, False), (24, 256, False, True), (256, 192, True, False), (96, 256, False, True)):
+    for cin, n, in_b, dout_b in ((256, 48, True, False), (24, 256, False, True), (256, 192, True, False), (96, 256, False, True),
+                                 (16, 128, False, True), (32, 200, True, True)):     # Cin <= 32, N >= 128: the 128 n x 32 c block shape
         conv = torch.nn.Conv2d(cin, n, ksize, padding=ksize // 2)
         x, g = torch.randn(b, cin, h, w), torch.randn(b, n, h, w)
         xv, gv = (bf(x) if (in_b or pipe == 'bf16') else x), (bf(g) if (dout_b or pipe == 'bf16') else g)
