@@ -409,7 +409,11 @@ int conv_bf16_prepare(const sininn_conv_args* a, ConvDevB& q) {
   return 0;
 }
 
+int conv3_smallk_bf16_supported(const sininn_conv_args* a);      // conv3_smallk_bf16.hip: Cin <= 32 -> 256, ReLU, bf16 out
+int conv3_smallk_bf16_launch(const sininn_conv_args* a, hipStream_t st);
+
 int conv_bf16_launch(const sininn_conv_args* a, hipStream_t st) {
+  if (conv3_smallk_bf16_supported(a)) return conv3_smallk_bf16_launch(a, st);
   ConvDevB q;
   if (int rc = conv_bf16_prepare(a, q)) return rc;
   return a->ksize == 3 ? launch_ks<3>(q, st) : launch_ks<1>(q, st);
