@@ -6,11 +6,16 @@
 //   * a block computes ALL 256 output columns of its pixels (8 waves x 32 columns), so a pixel tile is staged once, not four times;
 //   * K = 9 taps x Kp (16 / 32) is small enough for a wave's weight fragments to live in registers for the whole launch
 //     (18 fragments = 72 VGPRs): the MFMA loop reads only the input image from LDS, one 16-byte read per MFMA;
-//   * blocks are persistent over 16 x 16 pixel tiles; the next tile's halo (18 x 18 pixels) is requested a tile ahead and written
-//     into the other half of a double buffer mid-tile: one block barrier per tile;
+//   * blocks are persistent over 16 x 16 pixel tiles; the next tile's halo (18 x 18 pixels) is requested and written into the other
+//     half of a double buffer while this tile computes (two batches, three 32-pixel steps between request and use): one block
+//     barrier per tile;
 //   * the epilogue never touches LDS: a 32 x 32 accumulator tile has its column on the lane and pixels in the registers; bias + ReLU
 //     + rounding to bf16 happen there, two lanes swap halves (DPP + v_perm_b32) and every lane stores 4 bytes = two adjacent
 //     channels of one pixel; a wave's store instruction covers 64-byte runs, the eight waves of a block complete the 512-byte row.
+// MASK = the data gradient of conv2 at the same level (dr: 2 Co <= 48 channels -> dh: 256 channels, masked by [h > 0], bf16 out;
+// 127 us in the general kernel at configs[3]): the same kernel with 27 weight fragments per wave and the mask applied to the
+// packed output word -- the mask word of (pixel, columns c, c + 1) is loaded from h with the address the output word is stored
+// to, two 32-pixel steps ahead of its use.
 #include <cstdlib>
 #include "conv_bf16_types.h"
 
@@ -18,11 +23,12 @@ namespace sininn {
 
 constexpr int C3K_NTHR = 512, C3K_HALO = 18, C3K_HPIX = C3K_HALO * C3K_HALO, C3K_MAX_BLOCKS = 256;
 
-template <int KP>
+template <int CIN, bool MASK>
 __global__ __launch_bounds__(C3K_NTHR) void conv3_smallk_bf16_kernel(ConvDevB q, int ntiles) {
+  constexpr int KP = (CIN + 15) / 16 * 16;
   constexpr int NS = KP / 16, XSB = KP * 2 + 16;                  // bytes per halo pixel: 16 (mod 32) -> conflict-free 16-byte reads
   constexpr int IMG = (C3K_HPIX * XSB + 15) / 16 * 16;
-  constexpr int QMAX = KP / 4, FX = (C3K_HPIX * QMAX + C3K_NTHR - 1) / C3K_NTHR;
+  constexpr int QX = CIN / 4, FX = (C3K_HPIX * QX + C3K_NTHR - 1) / C3K_NTHR;
   const ConvDev& p = q.c;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_c3k[];   // 2 x IMG
 
@@ -41,40 +47,37 @@ __global__ __launch_bounds__(C3K_NTHR) void conv3_smallk_bf16_kernel(ConvDevB q,
     for (int s = 0; s < NS; ++s) wf[t][s] = *reinterpret_cast<const bf16x8*>(q.w + ((size_t)t * p.Np + cw + r) * KP + 16 * s + 8 * hh);
   const float bv = p.bias ? p.bias[cw + r] : 0.f;
 
-  // staging slots of a thread: (halo pixel, channel quad), the same for every tile
-  const int QX = p.Cin / 4;
-  int s_pk[FX];                                                   // halo row << 16 | halo column << 8 | first channel; -1: no slot
-#pragma unroll
-  for (int u = 0; u < FX; ++u) {
-    const int f = tid + C3K_NTHR * u;
-    const int pl = f / QX, c = (f - pl * QX) * 4;
-    const int hy = pl / C3K_HALO, hx = pl - hy * C3K_HALO;
-    s_pk[u] = pl < C3K_HPIX ? (hy << 16) | (hx << 8) | c : -1;
-  }
+  // staging slot u of a thread: halo pixel (tid + 512 u) / QX, channel quad (tid + 512 u) % QX -- the same for every tile
   const int tiles_img = p.tiles_x * p.tiles_y;
   const float* const in = static_cast<const float*>(q.in);
-  auto issue_tile = [&](int tile, f32x4 (&vx)[FX]) {
+  constexpr int FXH = (FX + 1) / 2;                               // the slots are requested / written in two batches per tile (registers)
+  auto issue_half = [&](int tile, int half, f32x4 (&vx)[FXH]) {
     const bool live = tile < ntiles;
     const int b = live ? tile / tiles_img : 0;
     const int trem = tile - b * tiles_img;
     const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
     const __amdgpu_buffer_rsrc_t rs = buf_rsrc(in + (size_t)b * p.H * p.W * p.in_stride);
 #pragma unroll
-    for (int u = 0; u < FX; ++u) {
-      const int gy = ty * 16 - 1 + (s_pk[u] >> 16), gx = tx * 16 - 1 + ((s_pk[u] >> 8) & 255);
-      const bool ok = live && s_pk[u] >= 0 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-      vx[u] = buf_load4(rs, ok ? (unsigned)(((gy * p.W + gx) * p.in_stride + (s_pk[u] & 255)) * 4) : BUF_OOB, 0u);
+    for (int u = 0; u < FXH; ++u) {
+      const int f = tid + C3K_NTHR * (half * FXH + u);
+      const int pl = f / QX, c = (f - pl * QX) * 4;
+      const int hy = pl / C3K_HALO, hx = pl - hy * C3K_HALO;
+      const int gy = ty * 16 - 1 + hy, gx = tx * 16 - 1 + hx;
+      const bool ok = live && pl < C3K_HPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      vx[u] = buf_load4(rs, ok ? (unsigned)(((gy * p.W + gx) * p.in_stride + c) * 4) : BUF_OOB, 0u);
     }
   };
-  auto store_tile = [&](int buf, const f32x4 (&vx)[FX]) {
+  auto store_half = [&](int buf, int half, const f32x4 (&vx)[FXH]) {
     unsigned char* const xs = smem_c3k + buf * IMG;
 #pragma unroll
-    for (int u = 0; u < FX; ++u) {
-      if (s_pk[u] >= 0) {
+    for (int u = 0; u < FXH; ++u) {
+      const int f = tid + C3K_NTHR * (half * FXH + u);
+      const int pl = f / QX, c = (f - pl * QX) * 4;
+      if (pl < C3K_HPIX) {
         bf16x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = (__bf16)vx[u][j];
-        *reinterpret_cast<bf16x4*>(xs + ((s_pk[u] >> 16) * C3K_HALO + ((s_pk[u] >> 8) & 255)) * XSB + (s_pk[u] & 255) * 2) = o;
+        *reinterpret_cast<bf16x4*>(xs + pl * XSB + c * 2) = o;
       }
     }
   };
@@ -82,11 +85,38 @@ __global__ __launch_bounds__(C3K_NTHR) void conv3_smallk_bf16_kernel(ConvDevB q,
   const bool odd = (r & 1) != 0;
   const unsigned sel = odd ? 0x03020706u : 0x05040100u;
   const int G = gridDim.x;
-  f32x4 vx[FX];
-  issue_tile(blockIdx.x, vx);
+  // byte offset of this lane's output word d of fragment s of 32-pixel step m of a tile (relative to the image; `stride` in
+  // elements): even lanes pixel pp, columns (c, c + 1); odd lanes pixel pp + 1, columns (c - 1, c).  BUF_OOB outside the image
+  auto word_off = [&](int y0, int x0, int m, int s, int d, int stride) -> unsigned {
+    const int pp = 16 * s + 8 * (d >> 1) + 2 * (d & 1) + 4 * hh + (odd ? 1 : 0);
+    const int gy = y0 + 2 * m + (pp >> 4), gx = x0 + (pp & 15);
+    return (gy < p.H && gx < p.W) ? (unsigned)(((gy * p.W + gx) * stride + cw + (r & ~1)) * 2) : BUF_OOB;
+  };
+  // ReLU-mask words of a 32-pixel step, requested two steps ahead of their use (a step is 27 MFMAs ~ 0.4 us per wave)
+  unsigned mk[2][8];
+  auto issue_mask = [&](int tile, int m, unsigned (&dst)[8]) {
+    if constexpr (MASK) {
+      const bool live = tile < ntiles;
+      const int b = live ? tile / tiles_img : 0;
+      const int trem = tile - b * tiles_img;
+      const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+      const __amdgpu_buffer_rsrc_t rs = buf_rsrc(q.mask_b + (size_t)b * p.H * p.W * p.mask_stride);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+          dst[4 * s + d] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(live ? word_off(ty * 16, tx * 16, m, s, d, p.mask_stride) : BUF_OOB), 0, 0);
+    }
+  };
+
+  f32x4 vx[FXH];
+  issue_half(blockIdx.x, 0, vx);
   __syncthreads();                                   // zero fill complete
-  store_tile(0, vx);
-  issue_tile(blockIdx.x + G, vx);
+  store_half(0, 0, vx);
+  issue_half(blockIdx.x, 1, vx);
+  store_half(0, 1, vx);
+  issue_mask(blockIdx.x, 0, mk[0]);
+  issue_mask(blockIdx.x, 1, mk[1]);
   __syncthreads();
   int buf = 0;
   for (int tile = blockIdx.x; tile < ntiles; tile += G, buf ^= 1) {
@@ -109,27 +139,33 @@ __global__ __launch_bounds__(C3K_NTHR) void conv3_smallk_bf16_kernel(ConvDevB q,
           const bf16x8 af = *reinterpret_cast<const bf16x8*>(arow + ((t / 3) * C3K_HALO + (t % 3)) * XSB + 32 * s);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wf[t][s], acc, 0, 0, 0);
         }
-      // bias + ReLU + one rounding; element j of fragment s is pixel 16 s + 8 (j >> 2) + 4 hh + (j & 3) of the 32
+      // bias + ReLU (or the mask) + one rounding; element j of fragment s is pixel 16 s + 8 (j >> 2) + 4 hh + (j & 3) of the 32
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         bf16x8 f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = (__bf16)fmaxf(acc[8 * s + j] + bv, 0.f);
+        for (int j = 0; j < 8; ++j) f[j] = MASK ? (__bf16)acc[8 * s + j] : (__bf16)fmaxf(acc[8 * s + j] + bv, 0.f);
         const u32x4 own = __builtin_bit_cast(u32x4, f);
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
           const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)own[d], 0xB1, 0xF, 0xF, true);
-          const unsigned outw = __builtin_amdgcn_perm(nb, own[d], sel);
-          const int pp = 16 * s + 8 * (d >> 1) + 2 * (d & 1) + 4 * hh + (odd ? 1 : 0);      // even lanes: pixel pp (columns c, c + 1)
-          const int gy = y0 + 2 * m + (pp >> 4), gx = x0 + (pp & 15);
-          const unsigned off = (gy < p.H && gx < p.W) ? (unsigned)(((gy * p.W + gx) * p.out_stride + cw + (r & ~1)) * 2) : BUF_OOB;
-          __builtin_amdgcn_raw_buffer_store_b32(outw, out_rs, (int)off, 0, 0);
+          unsigned outw = __builtin_amdgcn_perm(nb, own[d], sel);
+          if constexpr (MASK) {                      // h > 0 of the two bf16 halves: not zero and not negative
+            const unsigned mw = mk[m & 1][4 * s + d];
+            const unsigned keep = (((mw & 0x7fffu) != 0u && (mw & 0x8000u) == 0u) ? 0x0000ffffu : 0u) |
+                                  (((mw & 0x7fff0000u) != 0u && (mw & 0x80000000u) == 0u) ? 0xffff0000u : 0u);
+            outw &= keep;
+          }
+          __builtin_amdgcn_raw_buffer_store_b32(outw, out_rs, (int)word_off(y0, x0, m, s, d, p.out_stride), 0, 0);
         }
       }
-      if (m == 3) {                                  // mid-tile: the next tile (requested a tile ago) -> the other buffer; the one after it is requested
-        if (tile + G < ntiles) store_tile(buf ^ 1, vx);
-        issue_tile(tile + 2 * G, vx);
-      }
+      if (m < 6) issue_mask(tile, m + 2, mk[m & 1]);  // the set just consumed: two steps ahead (the next tile's first two at the end)
+      else issue_mask(tile + G, m - 6, mk[m & 1]);
+      // the next tile's halo image -> the other buffer, in two batches: requested at steps 0 / 4, written at steps 3 / 7 (a
+      // tile beyond the last reads zeros into an image nobody uses)
+      if (m == 0) issue_half(tile + G, 0, vx);
+      if (m == 3) { store_half(buf ^ 1, 0, vx); issue_half(tile + G, 1, vx); }
+      if (m == 7) store_half(buf ^ 1, 1, vx);
     }
     __syncthreads();                                 // every wave is done with this buffer; the next tile's image is complete
   }
@@ -141,20 +177,26 @@ void conv3_smallk_enable(int on) { g_c3k_enabled = on != 0; }
 // conv1 of a 3x3 subnet on the mixed-precision path: fp32 input with at most 32 channels -> ReLU -> 256 bf16 channels
 int conv3_smallk_bf16_supported(const sininn_conv_args* a) {
   if (!g_c3k_enabled || !a) return 0;
-  if (a->ksize != 3 || !a->w_bf16 || a->in_bf16 || !a->out_bf16 || a->winograd || a->mode != SININN_CONV_RELU) return 0;
-  if (a->Np != 256 || a->N != 256 || a->Cin % 8 != 0 || a->Cin > 32 || !a->bias) return 0;
+  if (a->ksize != 3 || !a->w_bf16 || a->in_bf16 || !a->out_bf16 || a->winograd) return 0;
+  if (a->mode == SININN_CONV_RELU) { if (!a->bias) return 0; }
+  else if (a->mode == SININN_CONV_MASK) { if (!a->mask || !a->mask_bf16 || a->mask_stride % 8 != 0 || a->mask_group_stride > 0) return 0; }
+  else return 0;
+  if (a->Np != 256 || a->N != 256) return 0;
+  if (a->mode == SININN_CONV_RELU ? !(a->Cin == 8 || a->Cin == 16 || a->Cin == 24 || a->Cin == 32) : !(a->Cin == 16 || a->Cin == 32 || a->Cin == 48)) return 0;
   if (a->in_group_stride > 0 || a->out_group_stride > 0) return 0;
   if (a->out_stride % 8 != 0 || a->in_stride % 4 != 0) return 0;
   const unsigned long long px = (unsigned long long)a->H * a->W;
   if (px * a->in_stride * 4ull >= (1ull << 31) || px * a->out_stride * 2ull >= (1ull << 31)) return 0;   // raw buffer offsets per image
+  if (a->mode == SININN_CONV_MASK && px * a->mask_stride * 2ull >= (1ull << 31)) return 0;
   return 1;
 }
 
-template <int KP>
+template <int CIN, bool MASK>
 static int c3k_launch(const ConvDevB& q, int ntiles, hipStream_t st) {
+  constexpr int KP = (CIN + 15) / 16 * 16;
   constexpr int IMG = (C3K_HPIX * (KP * 2 + 16) + 15) / 16 * 16;
   constexpr size_t lds = 2 * (size_t)IMG;
-  auto k = conv3_smallk_bf16_kernel<KP>;
+  auto k = conv3_smallk_bf16_kernel<CIN, MASK>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("conv3_smallk_bf16: cannot raise the LDS limit to %zu", lds); return 1; }
@@ -171,7 +213,19 @@ int conv3_smallk_bf16_launch(const sininn_conv_args* a, hipStream_t st) {
   if (int rc = conv_bf16_prepare(a, q)) return rc;
   q.c.tiles_x = (a->W + 15) / 16; q.c.tiles_y = (a->H + 15) / 16;
   const int ntiles = q.c.tiles_x * q.c.tiles_y * a->B;
-  return q.Kp == 16 ? c3k_launch<16>(q, ntiles, st) : c3k_launch<32>(q, ntiles, st);
+  if (a->mode == SININN_CONV_MASK) {
+    switch (a->Cin) {
+      case 16: return c3k_launch<16, true>(q, ntiles, st);
+      case 32: return c3k_launch<32, true>(q, ntiles, st);
+      default: return c3k_launch<48, true>(q, ntiles, st);
+    }
+  }
+  switch (a->Cin) {
+    case 8: return c3k_launch<8, false>(q, ntiles, st);
+    case 16: return c3k_launch<16, false>(q, ntiles, st);
+    case 24: return c3k_launch<24, false>(q, ntiles, st);
+    default: return c3k_launch<32, false>(q, ntiles, st);
+  }
 }
 
 }  // namespace sininn

@@ -48,7 +48,9 @@ def nchw(t):
 @pytest.mark.parametrize('cin,n,hw', [(24, 256, (16, 32)), (256, 48, (13, 21)), (96, 256, (9, 17)), (256, 192, (12, 20)),
                                       (48, 256, (8, 16)), (192, 256, (5, 7)),
                                       # Cin <= 32 -> 256 with ReLU: the persistent small-K kernel (conv3_smallk_bf16.hip); tiles cut in x and y
-                                      (24, 256, (21, 37)), (8, 256, (17, 16)), (32, 256, (5, 40)), (16, 256, (33, 18))])
+                                      (24, 256, (21, 37)), (8, 256, (17, 16)), (32, 256, (5, 40)), (16, 256, (33, 18)),
+                                      # ... and its masked data-gradient twin (2 Co <= 48 channels -> 256, [h > 0] mask): the last section below
+                                      (256, 32, (18, 35)), (256, 16, (7, 9)), (256, 48, (40, 33))])
 def test_conv_bf16_kernel(ksize, cin, n, hw):
     """every operand flavour of the bf16 conv engine against torch on the same bf16-rounded values."""
     import sin_inn_amd
