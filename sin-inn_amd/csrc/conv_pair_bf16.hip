@@ -258,8 +258,13 @@ int conv_pair_bf16_supported(const sininn_conv_args* f, const sininn_conv_args* 
   return s->Np == 16 || s->Np == 32 || s->Np == 48 || s->Np == 64 || s->Np == 96 || s->Np == 192;
 }
 
+// conv_sub1_bf16.hip: the persistent forward for the wide subnets (96 -> 256 -> 192), conv2's pack resident in LDS
+int conv_sub1_bf16_wide_fwd_supported(const sininn_conv_args* f, const sininn_conv_args* s);
+int conv_sub1_bf16_wide_fwd_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st);
+
 int conv_pair_bf16_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st) {
   SININN_CHECK(conv_pair_bf16_supported(f, s), "conv_pair_bf16: unsupported pair");
+  if (conv_sub1_bf16_wide_fwd_supported(f, s)) return conv_sub1_bf16_wide_fwd_launch(f, s, st);
   SININN_CHECK((unsigned long long)f->H * f->W * f->in_stride * 4ull < (1ull << 31),
                "conv_pair_bf16: one image of the input exceeds the 2 GB a block addresses (raw buffer staging)");
   PairDevB q;

@@ -661,6 +661,252 @@ __global__ __launch_bounds__(S1_NTHR) void conv_sub1b_fwd_kernel(Sub1DevB q) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Forward of the WIDE 1x1 subnets (level 1: 96 -> 256 -> 2 x 96), persistent: the structure of conv_sub1b_fwd_kernel on 32-pixel
+// tiles (2 x 16), so that conv2's whole pack (192 x 256 bf16 = 99 KB) stays in LDS for the lifetime of the block beside the h
+// tile, the x double buffer and the output tile (153 KB in all).  The pair kernel it replaces (conv_pair_bf16_kernel, 1024 - 3600
+// blocks of 64 pixels) walks K = 256 of the second GEMM through a chain of L2 round trips for its weight fragments in every
+// block: 76 us at BASELINE configs[3] for 4 us of matrix work.  Stage 1 = one 32 x 32 accumulator tile per wave over K1 / 16
+// steps (bitwise the pair kernel's h); h goes to LDS as bf16 and -- training passes: the backward of a wide subnet is not fused,
+// it reads h -- to HBM straight from the registers (4-byte stores, 64-byte runs); stage 2: 2 x N2 / 16 tiles of 16 x 16 on
+// v_mfma_f32_16x16x32_bf16, three per wave, K = 256 in one piece; the coupling epilogue takes up to two channel quads per thread.
+template <int K1, int N2, int HT>
+__global__ __launch_bounds__(S1_NTHR) void conv_sub1b_wide_fwd_kernel(Sub1DevB q, __bf16* hout, int hout_stride) {
+  constexpr int P = 32, NTHR = S1_NTHR;
+  constexpr int K1R = (K1 + 15) / 16 * 16, NS1 = K1R / 16, XSB = K1R * 2 + 16, HSB = S1_HID * 2 + 16, NU2 = N2 / 16, TS = N2 + 4;
+  constexpr int NT2 = 2 * NU2, TPW = (NT2 + 7) / 8;               // 16 x 16 output tiles of a pixel tile; per wave
+  static_assert(K1 % 16 == 0 && K1 <= 96 && N2 % 32 == 0 && N2 <= 192, "conv_sub1b_wide_fwd: shape");
+  const ConvDev& pr = q.r;
+  const ConvDev& pb = q.b;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_s1bw[];
+  unsigned char* const xs0 = smem_s1bw;                           // 2 x [P][XSB]
+  unsigned char* const hs = xs0 + 2 * P * XSB;                    // [P][HSB]
+  unsigned char* const w2s = hs + P * HSB;                        // [N2][HSB]
+  float* const T = reinterpret_cast<float*>(w2s + N2 * HSB);      // [P][TS]
+  __shared__ float ldw[2][NTHR / 64];
+  int ld_b[2] = {0, 0};
+  int ld_pending = -1;
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, hh = lane >> 5;
+  const int cw = wave * 32;
+  const bool odd = (r & 1) != 0;
+
+  for (int f = tid; f < N2 * (S1_HID / 8); f += NTHR) {
+    const int n = f / (S1_HID / 8), c8 = f - n * (S1_HID / 8);
+    *reinterpret_cast<u32x4*>(w2s + n * HSB + c8 * 16) = *reinterpret_cast<const u32x4*>(q.w2 + (size_t)n * S1_HID + c8 * 8);
+  }
+  const float b1v = pr.bias ? pr.bias[cw + r] : 0.f;
+  bf16x8 w1f[NS1];
+#pragma unroll
+  for (int s = 0; s < NS1; ++s) w1f[s] = *reinterpret_cast<const bf16x8*>(q.w1f + (size_t)(cw + r) * K1R + 16 * s + 8 * hh);
+
+  // coupling epilogue: channel quads (pixel, 4 channels) dealt to the threads, NQE per thread
+  constexpr int CO = N2 / 2, NQ = CO / 4, NQE = (P * NQ + NTHR - 1) / NTHR;
+  const bool e_inv = pb.mode == SININN_CONV_COUPLE_INV;
+  const int tiles_img = pr.tiles_x * pr.tiles_y;
+  auto tile_origin = [&](int tile, int& b, int& y0, int& x0) {
+    b = tile / tiles_img;
+    const int trem = tile - b * tiles_img;
+    const int ty = trem / pr.tiles_x;
+    y0 = ty * 2; x0 = (trem - ty * pr.tiles_x) * 16;
+  };
+
+  constexpr int QX = K1 / 4, FX = (P * QX + NTHR - 1) / NTHR;
+  auto issue_tile = [&](int tile, f32x4 (&vx)[FX]) {
+    const bool live = tile < q.ntiles;
+    int b, y0, x0; tile_origin(live ? tile : 0, b, y0, x0);
+    const __amdgpu_buffer_rsrc_t x_rs = buf_rsrc(pr.in + (size_t)b * pr.H * pr.W * pr.in_stride);
+#pragma unroll
+    for (int u = 0; u < FX; ++u) {
+      const int f = tid + NTHR * u;
+      const int pl = f / QX, c = (f - pl * QX) * 4;
+      const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+      const unsigned off = (live && f < P * QX && gy < pr.H && gx < pr.W) ? (unsigned)(((gy * pr.W + gx) * pr.in_stride + c) * 4) : BUF_OOB;
+      vx[u] = buf_load4(x_rs, off, 0u);
+    }
+  };
+  auto store_tile = [&](int buf, const f32x4 (&vx)[FX]) {
+    unsigned char* const xs = xs0 + buf * (P * XSB);
+#pragma unroll
+    for (int u = 0; u < FX; ++u) {
+      const int f = tid + NTHR * u;
+      const int pl = f / QX, c = (f - pl * QX) * 4;
+      if (f < P * QX) {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (__bf16)vx[u][j];
+        *reinterpret_cast<bf16x4*>(xs + pl * XSB + c * 2) = o;
+      }
+    }
+  };
+  // v of a tile's epilogue quads (raw buffer loads relative to the image: a quad outside the image / a tile beyond the last reads zeros)
+  auto load_v = [&](int tile, f32x4 (&ev)[NQE]) {
+    const bool live = tile < q.ntiles;
+    int b, y0, x0; tile_origin(live ? tile : 0, b, y0, x0);
+    const __amdgpu_buffer_rsrc_t rs = buf_rsrc(pb.v + (size_t)b * pb.H * pb.W * pb.v_stride);
+#pragma unroll
+    for (int i = 0; i < NQE; ++i) {
+      const int e = tid + NTHR * i;
+      const int pl = e / NQ, cl = 4 * (e - pl * NQ);
+      const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+      const bool ok = live && e < P * NQ && gy < pb.H && gx < pb.W;
+      ev[i] = buf_load4(rs, ok ? ((unsigned)(gy * pb.W + gx) * pb.v_stride + cl) * 4u : BUF_OOB, 0u);
+    }
+  };
+  const int G = gridDim.x;
+  const int row = lane & 15, kg = lane >> 4;
+  const unsigned sel = odd ? 0x03020706u : 0x05040100u;
+  // per-thread constants of the epilogue quads (the same for every tile): packed bias of s / t, output channel map
+  f32x4 e_bs[NQE], e_bt[NQE];
+  int e_om[NQE][4];
+#pragma unroll
+  for (int i = 0; i < NQE; ++i) {
+    const int e = tid + NTHR * i;
+    const int pl = e / NQ, cl = 4 * (e - pl * NQ);
+    const int tcol = (cl / HT) * (2 * HT) + (cl % HT);
+    e_bs[i] = e_bt[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e_om[i][j] = cl + j;
+    if (e < P * NQ) {
+      if (pb.bias) {
+        e_bs[i] = *reinterpret_cast<const f32x4*>(pb.bias + tcol);
+        e_bt[i] = *reinterpret_cast<const f32x4*>(pb.bias + tcol + HT);
+      }
+      if (pb.out_map) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e_om[i][j] = pb.out_map[cl + j];
+      }
+    }
+  }
+
+  auto body = [&](int tile, int buf, f32x4 (&vxn)[FX], f32x4 (&ev)[NQE]) {
+    int b, y0, x0; tile_origin(tile, b, y0, x0);
+    const unsigned char* const xs = xs0 + buf * (P * XSB);
+    // ---- stage 1: h[32][32 of this wave] -> LDS (and HBM) ---------------------------------------------------------------------
+    {
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int s = 0; s < NS1; ++s) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(xs + r * XSB + (16 * s + 8 * hh) * 2);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, w1f[s], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = fmaxf(acc[e] + b1v, 0.f);
+      bf16x8 hf[2];
+      acc_to_frags(acc, hf);
+      const __amdgpu_buffer_rsrc_t h_rs = buf_rsrc(hout + (size_t)b * pr.H * pr.W * hout_stride);
+      unsigned char* const base = hs + (4 * hh + (odd ? 1 : 0)) * HSB + (cw + (r & ~1)) * 2;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const u32x4 own = __builtin_bit_cast(u32x4, hf[s]);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)own[d], 0xB1, 0xF, 0xF, true);
+          const unsigned word = __builtin_amdgcn_perm(nb, own[d], sel);
+          const int p = 16 * s + 8 * (d >> 1) + 2 * (d & 1);     // + 4 hh + odd: this lane's pixel of the tile
+          *reinterpret_cast<unsigned*>(base + p * HSB) = word;
+          if (hout) {
+            const int pp = p + 4 * hh + (odd ? 1 : 0);
+            const int gy = y0 + (pp >> 4), gx = x0 + (pp & 15);
+            const unsigned off = (gy < pr.H && gx < pr.W) ? (unsigned)(((gy * pr.W + gx) * hout_stride + cw + (r & ~1)) * 2) : BUF_OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(word, h_rs, (int)off, 0, 0);
+          }
+        }
+      }
+    }
+    if (tile + G < q.ntiles) store_tile(buf ^ 1, vxn);
+    issue_tile(tile + 3 * G, vxn);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                                 // (B) the whole h tile is in LDS (and the next tile's x)
+    if (pb.logdet) {
+      if (tid == 0 && ld_pending >= 0) {
+        const float* w8 = ldw[ld_pending];
+        atomicAdd(pb.logdet + ld_b[ld_pending], ((w8[0] + w8[1]) + (w8[2] + w8[3])) + ((w8[4] + w8[5]) + (w8[6] + w8[7])));
+      }
+      ld_pending = buf;
+    }
+    // ---- stage 2: 16 x 16 tiles (pixel tile t & 1, column tile t >> 1), t = wave, wave + 8, ... ------------------------------------
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+      const int t = wave + 8 * i;
+      if (t < NT2) {
+        const int pt = t & 1, nt = t >> 1;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < S1_HID / 32; ++s) {
+          const bf16x8 af = *reinterpret_cast<const bf16x8*>(hs + (16 * pt + row) * HSB + (32 * s + 8 * kg) * 2);
+          const bf16x8 bf = *reinterpret_cast<const bf16x8*>(w2s + (16 * nt + row) * HSB + (32 * s + 8 * kg) * 2);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) T[(16 * pt + 4 * kg + e) * TS + 16 * nt + row] = acc[e];
+      }
+    }
+    __syncthreads();                                 // (E) the output tile is in LDS; every wave is done with hs
+    asm volatile("" :: "v"(ev[0]));
+    float ld_acc = 0.f;
+    const size_t e_img = (size_t)b * pb.H * pb.W;
+#pragma unroll
+    for (int i = 0; i < NQE; ++i) {
+      const int e = tid + NTHR * i;
+      const int pl = e / NQ, cl = 4 * (e - pl * NQ);
+      const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+      if (e < P * NQ && gy < pb.H && gx < pb.W) {
+        const int tcol = (cl / HT) * (2 * HT) + (cl % HT);
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(T + pl * TS + tcol) + e_bs[i];
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(T + pl * TS + tcol + HT) + e_bt[i];
+        const size_t pix = e_img + (unsigned)(gy * pb.W + gx);
+        f32x4 y4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float L = glow_log_e(s4[j], pb.clamp);
+          const float ex = expf(L);
+          if (!e_inv) { y4[j] = ex * ev[i][j] + t4[j]; ld_acc += L; }
+          else { y4[j] = (ev[i][j] - t4[j]) / ex; ld_acc -= L; }
+        }
+        if (pb.out_map) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pb.out[pix * pb.out_stride + e_om[i][j]] = y4[j];
+        } else {
+          *reinterpret_cast<f32x4*>(pb.out + pix * pb.out_stride + cl) = y4;
+        }
+        if (pb.out2) *reinterpret_cast<f32x4*>(pb.out2 + pix * pb.out2_stride + cl) = y4;
+        if (pb.sbuf) *reinterpret_cast<f32x4*>(pb.sbuf + pix * pb.Co + cl) = s4;
+      }
+    }
+    load_v(tile + 2 * G, ev);
+    if (pb.logdet) {
+      const float wsum = wave_sum(ld_acc);
+      if (lane == 0) ldw[buf][wave] = wsum;
+      ld_b[buf] = b;
+    }
+  };
+
+  f32x4 vxa[FX], vxb[FX], eva[NQE], evb[NQE];
+  issue_tile(blockIdx.x, vxa);
+  store_tile(0, vxa);
+  issue_tile(blockIdx.x + G, vxa);
+  issue_tile(blockIdx.x + 2 * G, vxb);
+  load_v(blockIdx.x, eva);
+  load_v(blockIdx.x + G, evb);
+  __syncthreads();
+  for (int tile = blockIdx.x; tile < q.ntiles; tile += 2 * G) {
+    body(tile, 0, vxa, eva);
+    if (tile + G < q.ntiles) body(tile + G, 1, vxb, evb);
+  }
+  if (pb.logdet) {
+    __syncthreads();
+    if (tid == 0 && ld_pending >= 0) {
+      const float* w8 = ldw[ld_pending];
+      atomicAdd(pb.logdet + ld_b[ld_pending], ((w8[0] + w8[1]) + (w8[2] + w8[3])) + ((w8[4] + w8[5]) + (w8[6] + w8[7])));
+    }
+  }
+}
+
 // ---- host -----------------------------------------------------------------------------------------------------------------------
 size_t conv_sub1_bwd_workspace_bytes(int cond_cin, int co);      // conv_sub1.hip: the slab layout is shared
 static bool g_sub1b_enabled = getenv("SININN_SUB1_BF16") == nullptr || atoi(getenv("SININN_SUB1_BF16")) != 0;   // A/B switch
@@ -791,6 +1037,58 @@ int conv_sub1_bf16_fwd_launch(const sininn_conv_args* f, const sininn_conv_args*
   if (f->Cin == 8) return ht16 ? sub1b_fwd_launch<8, 16, 16>(q, st) : sub1b_fwd_launch<8, 16, 8>(q, st);
   if (f->Cin == 16) return ht16 ? sub1b_fwd_launch<16, 32, 16>(q, st) : sub1b_fwd_launch<16, 32, 8>(q, st);
   return ht16 ? sub1b_fwd_launch<24, 48, 16>(q, st) : sub1b_fwd_launch<24, 48, 8>(q, st);
+}
+
+// ---- wide subnets (level 1): forward only ------------------------------------------------------------------------------------------
+static bool g_sub1b_wide = getenv("SININN_SUB1_BF16_WIDE") == nullptr || atoi(getenv("SININN_SUB1_BF16_WIDE")) != 0;   // A/B switch
+
+template <int K1, int N2, int HT>
+static int sub1b_wide_launch(Sub1DevB& q, __bf16* hout, int hout_stride, hipStream_t st) {
+  constexpr int K1R = (K1 + 15) / 16 * 16;
+  constexpr size_t lds = (size_t)2 * 32 * (K1R * 2 + 16) + (size_t)(32 + N2) * (S1_HID * 2 + 16) + (size_t)32 * (N2 + 4) * 4;
+  static_assert(lds + 64 <= 160 * 1024, "conv_sub1b_wide_fwd: LDS");
+  auto k = conv_sub1b_wide_fwd_kernel<K1, N2, HT>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) { set_error("conv_sub1_bf16_wide_fwd: cannot raise the LDS limit to %zu", lds); return 1; }
+  const int blocks = q.ntiles < S1_MAX_BLOCKS ? q.ntiles : S1_MAX_BLOCKS;
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(S1_NTHR), lds, st, q, hout, hout_stride);
+  SININN_LAUNCH_CHECK("conv_sub1_bf16_wide_fwd");
+  return 0;
+}
+
+// first / second as conv_pair_bf16_launch takes them; first->out (bf16 [pixel][256]) may be NULL: h is then not stored
+int conv_sub1_bf16_wide_fwd_supported(const sininn_conv_args* f, const sininn_conv_args* s) {
+  if (!g_sub1b_enabled || !g_sub1b_wide || !f || !s) return 0;
+  if (f->ksize != 1 || s->ksize != 1 || !f->w_bf16 || !s->w_bf16 || f->winograd || s->winograd || f->in_bf16 || !s->in_bf16 || s->out_bf16) return 0;
+  if (f->in_group_stride > 0 || f->out_group_stride > 0 || s->in_group_stride > 0) return 0;
+  if (f->mode != SININN_CONV_RELU || !(s->mode == SININN_CONV_COUPLE_FWD || s->mode == SININN_CONV_COUPLE_INV)) return 0;
+  if (f->Np != S1_HID || f->N != S1_HID || s->Cin != S1_HID) return 0;
+  if (f->B != s->B || f->H != s->H || f->W != s->W) return 0;
+  if (f->out && (!f->out_bf16 || f->out_stride % 8 != 0 || (unsigned long long)f->H * f->W * f->out_stride * 2ull >= (1ull << 31))) return 0;
+  if ((unsigned long long)f->H * f->W * f->in_stride * 4ull >= (1ull << 31) || (unsigned long long)s->H * s->W * s->v_stride * 4ull >= (1ull << 31)) return 0;
+  if (s->col_tile != 32 || s->Co % 16 != 0) return 0;
+  return (f->Cin == 96 && s->Np == 192) ? 1 : 0;
+}
+
+int conv_sub1_bf16_wide_fwd_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st) {
+  SININN_CHECK(conv_sub1_bf16_wide_fwd_supported(f, s), "conv_sub1_bf16_wide_fwd: unsupported subnet");
+  Sub1DevB q = {};
+  alignas(16) static float dummy[8] = {};
+  ConvDevB t;
+  sininn_conv_args fa = *f;
+  fa.out = dummy; fa.out_stride = S1_HID; fa.out_bf16 = 1;
+  if (int e = conv_bf16_prepare(&fa, t)) return e;
+  q.r = t.c; q.r.in = f->in; q.w1f = t.w;
+  sininn_conv_args sa = *s;
+  sa.in = dummy; sa.in_stride = S1_HID;
+  if (int e = conv_bf16_prepare(&sa, t)) return e;
+  q.b = t.c; q.a = t.c; q.w2 = t.w; q.w1d = nullptr;
+  q.r.tiles_x = q.a.tiles_x = q.b.tiles_x = (f->W + 15) / 16;
+  q.r.tiles_y = q.a.tiles_y = q.b.tiles_y = (f->H + 1) / 2;
+  q.ntiles = q.r.tiles_x * q.r.tiles_y * f->B;
+  q.r.stamp = q.a.stamp = q.b.stamp = nullptr;
+  q.no_dx = 0; q.slab = nullptr;
+  return sub1b_wide_launch<96, 192, 16>(q, reinterpret_cast<__bf16*>(f->out), f->out ? f->out_stride : 0, st);
 }
 
 }  // namespace sininn
