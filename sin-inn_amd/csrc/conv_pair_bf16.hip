@@ -261,10 +261,13 @@ int conv_pair_bf16_supported(const sininn_conv_args* f, const sininn_conv_args* 
 // conv_sub1_bf16.hip: the persistent forward for the wide subnets (96 -> 256 -> 192), conv2's pack resident in LDS
 int conv_sub1_bf16_wide_fwd_supported(const sininn_conv_args* f, const sininn_conv_args* s);
 int conv_sub1_bf16_wide_fwd_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st);
+int conv_sub1_bf16_wide_bwd_supported(const sininn_conv_args* d2, const sininn_conv_args* d1);
+int conv_sub1_bf16_wide_bwd_launch(const sininn_conv_args* d2, const sininn_conv_args* d1, hipStream_t st);
 
 int conv_pair_bf16_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st) {
   SININN_CHECK(conv_pair_bf16_supported(f, s), "conv_pair_bf16: unsupported pair");
   if (conv_sub1_bf16_wide_fwd_supported(f, s)) return conv_sub1_bf16_wide_fwd_launch(f, s, st);
+  if (conv_sub1_bf16_wide_bwd_supported(f, s)) return conv_sub1_bf16_wide_bwd_launch(f, s, st);
   SININN_CHECK((unsigned long long)f->H * f->W * f->in_stride * 4ull < (1ull << 31),
                "conv_pair_bf16: one image of the input exceeds the 2 GB a block addresses (raw buffer staging)");
   PairDevB q;

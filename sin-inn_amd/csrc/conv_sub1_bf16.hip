@@ -907,6 +907,369 @@ __global__ __launch_bounds__(S1_NTHR) void conv_sub1b_wide_fwd_kernel(Sub1DevB q
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Data gradients of the WIDE 1x1 subnets (level 1: dr[192] -> dh[256] . [h > 0] -> dx[96]), persistent, 32-pixel tiles: the twin of
+// conv_sub1b_wide_fwd_kernel for the backward pair (conv_pair_bf16_kernel<96, .>: 90 us at BASELINE configs[3]).  The wave's
+// fragments of conv2's data-gradient pack (K = 192: 12 fragments) live in registers, conv1's data-gradient pack (96 x 256) in LDS.
+//   stage 2  dh[32][32 of this wave] = dr W2 on v_mfma_f32_32x32x16_bf16, rounded to bf16; the ReLU mask is applied to the packed
+//            word (pixel, columns c, c + 1) after the lane swap, with the word of h loaded from the same address one tile ahead;
+//            the word goes to the LDS image for stage 3 and to HBM (conv1's weight gradient reads dh)
+//   stage 3  dx[32][96] = dh W1: 2 x 6 tiles of 16 x 16, K = 256 split in two halves over the waves (three half-tiles each), the
+//            epilogue (ADD / ADD_CBWD_*, up to two channel quads per thread, side inputs requested a tile ahead) sums the halves
+//   WG1      (training): dW1^T[k][c] += sum_p x[p][k] dh[p][c] and db1 += sum_p dh ride along -- the masked dh tile in its accumulator
+//            layout is the B operand (as in conv_sub1b_bwd_kernel), x^T comes from a [channel][pixel] image; one slab per block,
+//            wide_reduce_kernel sums them.  dh then never reaches HBM and conv1's problem leaves the grouped weight-gradient launch
+template <int K1, int K2, bool WG1>
+__global__ __launch_bounds__(S1_NTHR) void conv_sub1b_wide_bwd_kernel(Sub1DevB q, const __bf16* hmask, int hmask_stride, __bf16* dhout, int dhout_stride,
+                                                                      const float* xin, int xin_stride) {
+  constexpr int P = 32, NTHR = S1_NTHR;
+  constexpr int XTB = P * 2 + 8, NM1 = K1 / 32;                  // bytes per channel row of the transposed x image; 32-row tiles of dW1^T
+  constexpr int NS2 = K2 / 16, DSB = K2 * 2 + 16, HSB = S1_HID * 2 + 16, NP1 = K1, NU1 = NP1 / 16, TS = NP1 + 4;
+  constexpr int NHT = 2 * NU1 * 2, TPW = (NHT + 7) / 8;          // (pixel tile, column tile, K half) pieces of stage 3; per wave
+  static_assert(K1 % 16 == 0 && K1 <= 96 && K2 % 16 == 0 && K2 <= 192, "conv_sub1b_wide_bwd: shape");
+  const ConvDev& pa = q.a;
+  const ConvDev& pb = q.b;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_s1bwb[];
+  unsigned char* const ds0 = smem_s1bwb;                          // 2 x [P][DSB]: dr as bf16
+  unsigned char* const dhs = ds0 + 2 * P * DSB;                   // [P][HSB]: dh as bf16
+  unsigned char* const wd = dhs + P * HSB;                        // [NP1][HSB]: W1 data-gradient pack
+  float* const T0 = reinterpret_cast<float*>(wd + NP1 * HSB);     // 2 x [P][TS]: the two K halves of the dx tile
+  float* const T1 = T0 + P * TS;
+  unsigned char* const xt0 = reinterpret_cast<unsigned char*>(T1 + P * TS);   // WG1: 2 x [K1][XTB]: x^T as bf16
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, hh = lane >> 5;
+  const int cw = wave * 32;
+  const bool odd = (r & 1) != 0;
+  const unsigned sel = odd ? 0x03020706u : 0x05040100u;
+
+  f32x16 accW1[WG1 ? NM1 : 1];
+  float accb1 = 0.f;
+#pragma unroll
+  for (int t = 0; t < (WG1 ? NM1 : 1); ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accW1[t][e] = 0.f;
+
+  for (int f = tid; f < NP1 * (S1_HID / 8); f += NTHR) {
+    const int n = f / (S1_HID / 8), c8 = f - n * (S1_HID / 8);
+    *reinterpret_cast<u32x4*>(wd + n * HSB + c8 * 16) = *reinterpret_cast<const u32x4*>(q.w1d + (size_t)n * S1_HID + c8 * 8);
+  }
+  bf16x8 w2f[NS2];
+#pragma unroll
+  for (int s = 0; s < NS2; ++s) w2f[s] = *reinterpret_cast<const bf16x8*>(q.w2 + (size_t)(cw + r) * K2 + 16 * s + 8 * hh);
+
+  const int tiles_img = pa.tiles_x * pa.tiles_y;
+  auto tile_origin = [&](int tile, int& b, int& y0, int& x0) {
+    b = tile / tiles_img;
+    const int trem = tile - b * tiles_img;
+    const int ty = trem / pa.tiles_x;
+    y0 = ty * 2; x0 = (trem - ty * pa.tiles_x) * 16;
+  };
+  constexpr int QD = K2 / 4, FD = (P * QD + NTHR - 1) / NTHR;
+  auto issue_tile = [&](int tile, f32x4 (&vd)[FD]) {
+    const bool live = tile < q.ntiles;
+    int b, y0, x0; tile_origin(live ? tile : 0, b, y0, x0);
+    const __amdgpu_buffer_rsrc_t d_rs = buf_rsrc(pa.in + (size_t)b * pa.H * pa.W * pa.in_stride);
+#pragma unroll
+    for (int u = 0; u < FD; ++u) {
+      const int f = tid + NTHR * u;
+      const int pl = f / QD, c = (f - pl * QD) * 4;
+      const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+      const unsigned off = (live && f < P * QD && gy < pa.H && gx < pa.W) ? (unsigned)(((gy * pa.W + gx) * pa.in_stride + c) * 4) : BUF_OOB;
+      vd[u] = buf_load4(d_rs, off, 0u);
+    }
+  };
+  auto store_tile = [&](int buf, const f32x4 (&vd)[FD]) {
+    unsigned char* const ds = ds0 + buf * (P * DSB);
+#pragma unroll
+    for (int u = 0; u < FD; ++u) {
+      const int f = tid + NTHR * u;
+      const int pl = f / QD, c = (f - pl * QD) * 4;
+      if (f < P * QD) {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (__bf16)vd[u][j];
+        *reinterpret_cast<bf16x4*>(ds + pl * DSB + c * 2) = o;
+      }
+    }
+  };
+  constexpr int QXW = K1 / 4, FXW = (P * QXW + NTHR - 1) / NTHR;
+  auto issue_x = [&](int tile, f32x4 (&vx)[FXW]) {
+    const bool live = tile < q.ntiles;
+    int b, y0, x0; tile_origin(live ? tile : 0, b, y0, x0);
+    const __amdgpu_buffer_rsrc_t x_rs = buf_rsrc(xin + (size_t)b * pa.H * pa.W * xin_stride);
+#pragma unroll
+    for (int u = 0; u < FXW; ++u) {
+      const int f = tid + NTHR * u;
+      const int pl = f / QXW, c = (f - pl * QXW) * 4;
+      const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+      const unsigned off = (live && f < P * QXW && gy < pa.H && gx < pa.W) ? (unsigned)(((gy * pa.W + gx) * xin_stride + c) * 4) : BUF_OOB;
+      vx[u] = buf_load4(x_rs, off, 0u);
+    }
+  };
+  auto store_x = [&](int buf, const f32x4 (&vx)[FXW]) {
+    unsigned char* const xt = xt0 + buf * (K1 * XTB);
+#pragma unroll
+    for (int u = 0; u < FXW; ++u) {
+      const int f = tid + NTHR * u;
+      const int pl = f / QXW, c = (f - pl * QXW) * 4;
+      if (f < P * QXW) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<__bf16*>(xt + (c + j) * XTB + pl * 2) = (__bf16)vx[u][j];
+      }
+    }
+  };
+  // byte offset (relative to the image, row stride in elements) of this lane's packed word d of fragment s: even lanes pixel pp,
+  // columns (c, c + 1); odd lanes pixel pp + 1, columns (c - 1, c)
+  auto word_off = [&](int y0, int x0, int s, int d, int stride) -> unsigned {
+    const int pp = 16 * s + 8 * (d >> 1) + 2 * (d & 1) + 4 * hh + (odd ? 1 : 0);
+    const int gy = y0 + (pp >> 4), gx = x0 + (pp & 15);
+    return (gy < pa.H && gx < pa.W) ? (unsigned)(((gy * pa.W + gx) * stride + cw + (r & ~1)) * 2) : BUF_OOB;
+  };
+  auto issue_mask = [&](int tile, unsigned (&mk)[8]) {
+    const bool live = tile < q.ntiles;
+    int b, y0, x0; tile_origin(live ? tile : 0, b, y0, x0);
+    const __amdgpu_buffer_rsrc_t rs = buf_rsrc(hmask + (size_t)b * pa.H * pa.W * hmask_stride);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+        mk[4 * s + d] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(live ? word_off(y0, x0, s, d, hmask_stride) : BUF_OOB), 0, 0);
+  };
+
+  // epilogue quads (pixel, 4 columns of dx) dealt to the threads; per-thread constants
+  constexpr int NQ = NP1 / 4, NQE = (P * NQ + NTHR - 1) / NTHR;
+  const int emode = pb.mode;
+  const bool e_cbwd = emode == SININN_CONV_ADD_CBWD_FWD || emode == SININN_CONV_ADD_CBWD_INV;
+  const bool e_fast = !q.no_dx;
+  int amap[NQE][4];
+  f32x4 e_bq[NQE];
+#pragma unroll
+  for (int i = 0; i < NQE; ++i) {
+    const int e = tid + NTHR * i;
+    const int pl = e / NQ, col = 4 * (e - pl * NQ);
+    e_bq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) amap[i][j] = col + j;
+    if (e_fast && e < P * NQ && col < pb.N) {
+      if (pb.addend_map) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) amap[i][j] = pb.addend_map[col + j];
+      }
+      if (pb.bias) e_bq[i] = *reinterpret_cast<const f32x4*>(pb.bias + col);
+    }
+  }
+  struct Side { f32x4 ad, u, s; };
+  auto load_side = [&](int tile, Side (&sd)[NQE]) {
+    const bool live = tile < q.ntiles;
+    int b, y0, x0; tile_origin(live ? tile : 0, b, y0, x0);
+    const size_t img = (size_t)b * pb.H * pb.W;
+    const __amdgpu_buffer_rsrc_t ad_rs = buf_rsrc(pb.addend + img * pb.addend_stride);
+    const __amdgpu_buffer_rsrc_t u_rs = buf_rsrc((e_cbwd ? pb.v : pb.addend) + img * (e_cbwd ? pb.v_stride : 0));
+    const __amdgpu_buffer_rsrc_t s_rs = buf_rsrc((e_cbwd ? pb.sbuf : pb.addend) + img * (e_cbwd ? pb.Co : 0));
+#pragma unroll
+    for (int i = 0; i < NQE; ++i) {
+      const int e = tid + NTHR * i;
+      const int pl = e / NQ, col = 4 * (e - pl * NQ);
+      const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+      const bool ok = live && e_fast && e < P * NQ && col < pb.N && gy < pb.H && gx < pb.W;
+      const unsigned ip = (unsigned)(gy * pb.W + gx);
+      if (pb.addend_map) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          sd[i].ad[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ad_rs, (int)(ok ? (ip * pb.addend_stride + amap[i][j]) * 4u : BUF_OOB), 0, 0));
+      } else {
+        sd[i].ad = buf_load4(ad_rs, ok ? (ip * pb.addend_stride + col) * 4u : BUF_OOB, 0u);
+      }
+      const bool cb = ok && e_cbwd;
+      sd[i].u = buf_load4(u_rs, cb ? (ip * pb.v_stride + col) * 4u : BUF_OOB, 0u);
+      sd[i].s = buf_load4(s_rs, cb ? (ip * pb.Co + col) * 4u : BUF_OOB, 0u);
+    }
+  };
+
+  const int G = gridDim.x;
+  const int row = lane & 15, kg = lane >> 4;
+  f32x4 vd[FD], vxw[FXW];
+  unsigned mk[8];
+  Side sd[NQE];
+  issue_tile(blockIdx.x, vd);
+  if constexpr (WG1) issue_x(blockIdx.x, vxw);
+  store_tile(0, vd);
+  if constexpr (WG1) store_x(0, vxw);
+  issue_tile(blockIdx.x + G, vd);
+  if constexpr (WG1) issue_x(blockIdx.x + G, vxw);
+  issue_mask(blockIdx.x, mk);
+  load_side(blockIdx.x, sd);
+  __syncthreads();
+  int buf = 0;
+  for (int tile = blockIdx.x; tile < q.ntiles; tile += G, buf ^= 1) {
+    int b, y0, x0; tile_origin(tile, b, y0, x0);
+    const unsigned char* const ds = ds0 + buf * (P * DSB);
+    // ---- stage 2: dh = (dr W2) . [h > 0] -> LDS + HBM ---------------------------------------------------------------------------------
+    {
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int s = 0; s < NS2; ++s) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(ds + r * DSB + (16 * s + 8 * hh) * 2);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, w2f[s], acc, 0, 0, 0);
+      }
+      bf16x8 hf[2];
+      acc_to_frags(acc, hf);
+      const __amdgpu_buffer_rsrc_t o_rs = buf_rsrc(dhout + (size_t)b * pa.H * pa.W * dhout_stride);
+      unsigned char* const base = dhs + (4 * hh + (odd ? 1 : 0)) * HSB + (cw + (r & ~1)) * 2;
+      auto keep_of = [](unsigned mw) -> unsigned {   // h > 0 of the two bf16 halves: not zero and not negative
+        return (((mw & 0x7fffu) != 0u && (mw & 0x8000u) == 0u) ? 0x0000ffffu : 0u) |
+               (((mw & 0x7fff0000u) != 0u && (mw & 0x80000000u) == 0u) ? 0xffff0000u : 0u);
+      };
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        u32x4 own = __builtin_bit_cast(u32x4, hf[s]);
+        if constexpr (WG1) {
+          // the mask words arrive in the swapped layout (pixel, columns c, c + 1): swapped back (the swap is an involution) they
+          // mask this lane's own (pixel, pixel + 1) pairs, and the masked fragment is the B operand of the weight-gradient MFMAs
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const unsigned mw = mk[4 * s + d];
+            const unsigned mnb = (unsigned)__builtin_amdgcn_mov_dpp((int)mw, 0xB1, 0xF, 0xF, true);
+            own[d] &= keep_of(__builtin_amdgcn_perm(mnb, mw, sel));
+          }
+          hf[s] = __builtin_bit_cast(bf16x8, own);
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)own[d], 0xB1, 0xF, 0xF, true);
+          unsigned word = __builtin_amdgcn_perm(nb, own[d], sel);
+          if constexpr (!WG1) word &= keep_of(mk[4 * s + d]);
+          *reinterpret_cast<unsigned*>(base + (16 * s + 8 * (d >> 1) + 2 * (d & 1)) * HSB) = word;
+          if (dhout) __builtin_amdgcn_raw_buffer_store_b32(word, o_rs, (int)word_off(y0, x0, s, d, dhout_stride), 0, 0);
+        }
+      }
+      if constexpr (WG1) {
+        const unsigned char* const xt = xt0 + buf * (K1 * XTB);
+#pragma unroll
+        for (int t = 0; t < NM1; ++t)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const bf16x8 af = read_tr_frag(xt + (32 * t + r) * XTB + (16 * s + 4 * hh) * 2);
+            accW1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, hf[s], accW1[t], 0, 0, 0);
+          }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) accb1 += (float)hf[s][j];
+      }
+    }
+    issue_mask(tile + G, mk);                        // the next tile's mask words: a tile ahead of their use
+    if (tile + G < q.ntiles) {
+      store_tile(buf ^ 1, vd);
+      if constexpr (WG1) store_x(buf ^ 1, vxw);
+    }
+    issue_tile(tile + 2 * G, vd);
+    if constexpr (WG1) issue_x(tile + 2 * G, vxw);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                                 // (C) the whole dh tile is in LDS (and the next tile's dr / x^T)
+
+    // ---- stage 3: dx[32][NP1] = dh W1, K halves: piece t = wave + 8 i -> (K half t & 1, pixel tile (t >> 1) & 1, column tile t >> 2) ----
+    if (!q.no_dx) {
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) {
+        const int t = wave + 8 * i;
+        if (t < NHT) {
+          const int g2 = t & 1, pt = (t >> 1) & 1, nt = t >> 2;
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < S1_HID / 64; ++s) {
+            const int k0 = 128 * g2 + 32 * s + 8 * kg;
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(dhs + (16 * pt + row) * HSB + k0 * 2);
+            const bf16x8 bf = *reinterpret_cast<const bf16x8*>(wd + (16 * nt + row) * HSB + k0 * 2);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc, 0, 0, 0);
+          }
+          float* const T = g2 ? T1 : T0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) T[(16 * pt + 4 * kg + e) * TS + 16 * nt + row] = acc[e];
+        }
+      }
+    }
+    __syncthreads();                                 // (E) both halves of the dx tile are in LDS; every wave is done with dhs
+    asm volatile("" :: "v"(sd[0].ad), "v"(sd[0].u), "v"(sd[0].s));
+    if (!q.no_dx) {
+#pragma unroll
+      for (int i = 0; i < NQE; ++i) {
+        const int e = tid + NTHR * i;
+        const int pl = e / NQ, col = 4 * (e - pl * NQ);
+        const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+        if (e < P * NQ && col < pb.N && gy < pb.H && gx < pb.W) {
+          const size_t pix = (size_t)b * pb.H * pb.W + (unsigned)(gy * pb.W + gx);
+          f32x4 val = *reinterpret_cast<const f32x4*>(T0 + pl * TS + col) + *reinterpret_cast<const f32x4*>(T1 + pl * TS + col);
+          val += e_bq[i];
+          val += sd[i].ad;
+          if (!e_cbwd) {
+            *reinterpret_cast<f32x4*>(pb.out + pix * pb.out_stride + col) = val;
+          } else {
+            const float gl = pb.logdet ? pb.logdet[b] : 0.f;
+            f32x4 o_a, o_b, o_c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float g = val[j], u = sd[i].u[j], sv = sd[i].s[j];
+              const float L = glow_log_e(sv, pb.clamp), dL = glow_dlog_e(sv, pb.clamp);
+              const float ex = expf(L);
+              if (emode == SININN_CONV_ADD_CBWD_FWD) { o_c[j] = g * ex; o_b[j] = g; o_a[j] = (g * u * ex + gl) * dL; }
+              else { o_c[j] = g / ex; o_b[j] = -o_c[j]; o_a[j] = -(g * u + gl) * dL; }
+            }
+            *reinterpret_cast<f32x4*>(pb.out + pix * pb.out_stride + col) = o_a;
+            *reinterpret_cast<f32x4*>(pb.out + pix * pb.out_stride + pb.Co + col) = o_b;
+            *reinterpret_cast<f32x4*>(pb.out2 + pix * pb.out2_stride + col) = o_c;
+          }
+        }
+      }
+    }
+    load_side(tile + G, sd);                         // the next tile's side inputs: a tile ahead of their use
+  }
+  if constexpr (WG1) {                               // slab of this block: dW1^T [K1][256] | db1 [256]
+    float* const slab = q.slab + (size_t)blockIdx.x * ((K1 + 1) * S1_HID);
+#pragma unroll
+    for (int t = 0; t < NM1; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) slab[(32 * t + (e & 3) + 8 * (e >> 2) + 4 * hh) * S1_HID + cw + r] = accW1[t][e];
+    const float bsum = accb1 + __shfl_xor(accb1, 32);
+    if (hh == 0) slab[K1 * S1_HID + cw + r] = bsum;
+  }
+}
+
+// gw1[n][k] += sum over the slabs of dW1^T[k][n], gb1[n] += sum of db1[n]: eight interleaved groups of slabs, each summed in
+// ascending order by one thread, the eight partial sums added as a balanced tree (the association of sub1_reduce_kernel)
+template <int K1>
+__global__ __launch_bounds__(256) void wide_reduce_kernel(const float* __restrict__ slabs, int S, float* __restrict__ gw1, float* __restrict__ gb1) {
+  constexpr int ET = (K1 + 1) * S1_HID / 4;
+  constexpr size_t slab4 = (size_t)(K1 + 1) * S1_HID / 4;
+  __shared__ f32x4 part[8][32];
+  const int tid = threadIdx.x, g = tid >> 5, el = tid & 31;
+  const int e = blockIdx.x * 32 + el;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+  if (e < ET) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(slabs) + e;
+    int s = g;
+#pragma unroll 4
+    for (; s + 8 < S; s += 16) { a0 += src[(size_t)s * slab4]; a1 += src[(size_t)(s + 8) * slab4]; }
+    if (s < S) a0 += src[(size_t)s * slab4];
+    a0 += a1;
+  }
+  part[g][el] = a0;
+  __syncthreads();
+  if (tid < 32 && e < ET) {
+    const f32x4 tot = ((part[0][el] + part[1][el]) + (part[2][el] + part[3][el])) + ((part[4][el] + part[5][el]) + (part[6][el] + part[7][el]));
+    const int idx = e * 4, k = idx / S1_HID, n = idx - k * S1_HID;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (k < K1) { if (gw1) gw1[(n + j) * K1 + k] += tot[j]; }
+      else if (gb1) gb1[n + j] += tot[j];
+    }
+  }
+}
+
 // ---- host -----------------------------------------------------------------------------------------------------------------------
 size_t conv_sub1_bwd_workspace_bytes(int cond_cin, int co);      // conv_sub1.hip: the slab layout is shared
 static bool g_sub1b_enabled = getenv("SININN_SUB1_BF16") == nullptr || atoi(getenv("SININN_SUB1_BF16")) != 0;   // A/B switch
@@ -1089,6 +1452,101 @@ int conv_sub1_bf16_wide_fwd_launch(const sininn_conv_args* f, const sininn_conv_
   q.r.stamp = q.a.stamp = q.b.stamp = nullptr;
   q.no_dx = 0; q.slab = nullptr;
   return sub1b_wide_launch<96, 192, 16>(q, reinterpret_cast<__bf16*>(f->out), f->out ? f->out_stride : 0, st);
+}
+
+// the backward pair of a wide subnet (d2: dr fp32 -> dh bf16 with a bf16 ReLU mask; d1: dh -> dx, ADD / ADD_CBWD epilogue)
+int conv_sub1_bf16_wide_bwd_supported(const sininn_conv_args* d2, const sininn_conv_args* d1) {
+  if (!g_sub1b_enabled || !g_sub1b_wide || !d2 || !d1) return 0;
+  if (d2->ksize != 1 || d1->ksize != 1 || !d2->w_bf16 || !d1->w_bf16 || d2->winograd || d1->winograd) return 0;
+  if (d2->in_bf16 || !d2->out_bf16 || !d1->in_bf16 || d1->out_bf16) return 0;
+  if (d2->mode != SININN_CONV_MASK || !d2->mask || !d2->mask_bf16 || d2->mask_stride % 8 != 0) return 0;
+  if (d2->in_group_stride > 0 || d2->out_group_stride > 0 || d2->mask_group_stride > 0 || d1->in_group_stride > 0) return 0;
+  if (d2->Np != S1_HID || d2->N != S1_HID || d1->Cin != S1_HID) return 0;
+  if (d2->out && d2->out_stride % 8 != 0) return 0;
+  if (d2->B != d1->B || d2->H != d1->H || d2->W != d1->W) return 0;
+  const bool cbwd = d1->mode == SININN_CONV_ADD_CBWD_FWD || d1->mode == SININN_CONV_ADD_CBWD_INV;
+  if (!(cbwd || d1->mode == SININN_CONV_ADD)) return 0;
+  if (d1->mask || d1->out_map || !d1->out || !d1->addend || d1->out_stride % 4 != 0 || !aligned16(d1->out)) return 0;
+  if (!d1->addend_map && (d1->addend_stride % 4 != 0 || !aligned16(d1->addend))) return 0;
+  if (d1->bias && !aligned16(d1->bias)) return 0;
+  if (cbwd && !(d1->Co % 4 == 0 && d1->v_stride % 4 == 0 && d1->out2_stride % 4 == 0 && d1->v && d1->sbuf && d1->out2 && aligned16(d1->v) &&
+                aligned16(d1->sbuf) && aligned16(d1->out2))) return 0;
+  const unsigned long long px = (unsigned long long)d2->H * d2->W;
+  if (px * d2->in_stride * 4ull >= (1ull << 31) || px * d2->mask_stride * 2ull >= (1ull << 31) || px * (d2->out ? d2->out_stride : 0) * 2ull >= (1ull << 31)) return 0;
+  if (px * (unsigned long long)(d1->addend_stride > d1->out_stride ? d1->addend_stride : d1->out_stride) * 4ull >= (1ull << 31)) return 0;
+  return (d2->Cin == 192 && d1->N == 96 && d1->Np == 96) ? 1 : 0;
+}
+
+// x / x_stride / ws: non-null -> the weight gradient of conv1 rides along (slabs into ws, summed by conv_sub1_bf16_wide_reduce) and
+// d2->out may be NULL (dh is then not stored)
+size_t conv_sub1_bf16_wide_ws_bytes(int ksize, int dtype, int cond_cin, int co) {
+  if (!g_sub1b_enabled || !g_sub1b_wide || ksize != 1 || dtype != 1 || cond_cin != 96 || co != 96) return 0;
+  return (size_t)S1_MAX_BLOCKS * (96 + 1) * S1_HID * sizeof(float);
+}
+
+static int wide_bwd_launch(const sininn_conv_args* d2, const sininn_conv_args* d1, const float* x, int x_stride, void* ws, size_t ws_bytes,
+                           int* slabs_out, hipStream_t st) {
+  SININN_CHECK(conv_sub1_bf16_wide_bwd_supported(d2, d1), "conv_sub1_bf16_wide_bwd: unsupported pair");
+  const bool wg1 = x != nullptr;
+  if (wg1) {
+    SININN_CHECK(ws && aligned16(ws) && ws_bytes >= conv_sub1_bf16_wide_ws_bytes(1, 1, 96, 96) && slabs_out, "conv_sub1_bf16_wide_bwd: workspace too small");
+    SININN_CHECK(aligned16(x) && x_stride % 4 == 0 && (unsigned long long)d2->H * d2->W * x_stride * 4ull < (1ull << 31), "conv_sub1_bf16_wide_bwd: bad x");
+  }
+  Sub1DevB q = {};
+  alignas(16) static float dummy[8] = {};
+  ConvDevB t;
+  sininn_conv_args da = *d2;
+  da.mode = SININN_CONV_LINEAR; da.mask = nullptr; da.mask_bf16 = 0; da.out = dummy; da.out_stride = S1_HID; da.N = S1_HID; da.out_bf16 = 1;
+  if (int e = conv_bf16_prepare(&da, t)) return e;
+  q.a = t.c; q.a.in = static_cast<const float*>(d2->in); q.w2 = t.w;
+  sininn_conv_args db = *d1;
+  db.in = dummy; db.in_stride = S1_HID; db.in_bf16 = 1;
+  if (int e = conv_bf16_prepare(&db, t)) return e;
+  q.b = t.c; q.r = t.c; q.w1d = t.w; q.w1f = nullptr;
+  q.r.tiles_x = q.a.tiles_x = q.b.tiles_x = (d2->W + 15) / 16;
+  q.r.tiles_y = q.a.tiles_y = q.b.tiles_y = (d2->H + 1) / 2;
+  q.ntiles = q.a.tiles_x * q.a.tiles_y * d2->B;
+  q.r.stamp = q.a.stamp = q.b.stamp = nullptr;
+  q.no_dx = 0; q.slab = static_cast<float*>(ws);
+  constexpr size_t lds0 = (size_t)2 * 32 * (192 * 2 + 16) + (size_t)(32 + 96) * (S1_HID * 2 + 16) + (size_t)2 * 32 * (96 + 4) * 4;
+  constexpr size_t lds1 = lds0 + (size_t)2 * 96 * (32 * 2 + 8);
+  static_assert(lds1 <= 160 * 1024, "conv_sub1b_wide_bwd: LDS");
+  const int blocks = q.ntiles < S1_MAX_BLOCKS ? q.ntiles : S1_MAX_BLOCKS;
+  const __bf16* hm = reinterpret_cast<const __bf16*>(d2->mask);
+  __bf16* dho = reinterpret_cast<__bf16*>(d2->out);
+  const int dhs_ = d2->out ? d2->out_stride : 0;
+  if (wg1) {
+    auto k = conv_sub1b_wide_bwd_kernel<96, 192, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    if (e != hipSuccess) { set_error("conv_sub1_bf16_wide_bwd: cannot raise the LDS limit to %zu", lds1); return 1; }
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(S1_NTHR), lds1, st, q, hm, d2->mask_stride, dho, dhs_, x, x_stride);
+    *slabs_out = blocks;
+  } else {
+    auto k = conv_sub1b_wide_bwd_kernel<96, 192, false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0);
+    if (e != hipSuccess) { set_error("conv_sub1_bf16_wide_bwd: cannot raise the LDS limit to %zu", lds0); return 1; }
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(S1_NTHR), lds0, st, q, hm, d2->mask_stride, dho, dhs_, static_cast<const float*>(nullptr), 0);
+  }
+  SININN_LAUNCH_CHECK("conv_sub1_bf16_wide_bwd");
+  return 0;
+}
+
+int conv_sub1_bf16_wide_bwd_launch(const sininn_conv_args* d2, const sininn_conv_args* d1, hipStream_t st) {
+  return wide_bwd_launch(d2, d1, nullptr, 0, nullptr, 0, nullptr, st);
+}
+
+int conv_sub1_bf16_wide_bwd_wg1_launch(const sininn_conv_args* d2, const sininn_conv_args* d1, const float* x, int x_stride, void* ws, size_t ws_bytes,
+                                       int* slabs_out, hipStream_t st) {
+  SININN_CHECK(x != nullptr, "conv_sub1_bf16_wide_bwd_wg1: x is NULL");
+  return wide_bwd_launch(d2, d1, x, x_stride, ws, ws_bytes, slabs_out, st);
+}
+
+int conv_sub1_bf16_wide_reduce(const void* ws, int slabs, float* gw1, float* gb1, hipStream_t st) {
+  SININN_CHECK(ws && slabs > 0 && slabs <= S1_MAX_BLOCKS, "conv_sub1_bf16_wide_reduce: bad arguments");
+  constexpr int ET = (96 + 1) * S1_HID / 4;
+  hipLaunchKernelGGL((wide_reduce_kernel<96>), dim3((ET + 31) / 32), dim3(256), 0, st, static_cast<const float*>(ws), slabs, gw1, gb1);
+  SININN_LAUNCH_CHECK("conv_sub1_bf16_wide_reduce");
+  return 0;
 }
 
 }  // namespace sininn

@@ -49,6 +49,12 @@ int conv_sub1_bwd_launch(const sininn_conv_args* rc, const sininn_conv_args* d2,
 int conv_sub1_bwd_reduce(int cond_cin, int co, const void* ws, int slabs, float* gw2, float* gb2, float* gw1, float* gb1, hipStream_t st);
 int conv_sub1_fwd_supported(const sininn_conv_args* f, const sininn_conv_args* s);
 int conv_sub1_fwd_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st);
+// conv_sub1_bf16.hip: data gradients of a wide (level-1) 1x1 subnet + the weight gradient of its conv1 in one persistent launch
+size_t conv_sub1_bf16_wide_ws_bytes(int ksize, int dtype, int cond_cin, int co);
+int conv_sub1_bf16_wide_bwd_supported(const sininn_conv_args* d2, const sininn_conv_args* d1);
+int conv_sub1_bf16_wide_bwd_wg1_launch(const sininn_conv_args* d2, const sininn_conv_args* d1, const float* x, int x_stride, void* ws, size_t ws_bytes,
+                                       int* slabs_out, hipStream_t st);
+int conv_sub1_bf16_wide_reduce(const void* ws, int slabs, float* gw1, float* gb1, hipStream_t st);
 
 int order_after(hipStream_t waiter, hipStream_t producer) {
   if (waiter == producer) return 0;
@@ -281,6 +287,8 @@ static Scratch scratch_layout(void* basep, int B, int H, int W, int C, int ksize
   const int cond_cin[2] = {C - co_a, co_a}, cos[2] = {co_a, co_b};
   for (int i = 0; i < 2; ++i) {
     s.slab_bytes[i] = conv_sub1_bwd_shape_supported(ksize, dtype, cond_cin[i], cos[i]) ? conv_sub1_bwd_workspace_bytes(cond_cin[i], cos[i]) : 0;
+    const size_t wide = conv_sub1_bf16_wide_ws_bytes(ksize, dtype, cond_cin[i], cos[i]);
+    if (wide > s.slab_bytes[i]) s.slab_bytes[i] = wide;
     s.slab[i] = reinterpret_cast<char*>(base) + so;
     so += (s.slab_bytes[i] + 255) / 256 * 256;
   }
@@ -555,6 +563,25 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
         if (int rc_ = conv_sub1_bwd_reduce(cond_cin, h.co, sc.slab[which], slabs, net->gw2, net->gb2, net->gw1, net->gb1, wst)) return rc_;
       }
       return 0;
+    }
+    {
+      // wide 1x1 subnet on the mixed-precision path (level 1): both data gradients AND conv1's weight gradient in one persistent
+      // launch -- dh never reaches HBM, conv1's problem leaves the grouped weight-gradient launch (conv2's stays: it was added above)
+      const int which = (&h == &hv[0]) ? 0 : 1;
+      const size_t wide_ws = conv_sub1_bf16_wide_ws_bytes(k, a->dtype, cond_cin, h.co);
+      sininn_conv_args d2w = d2;
+      d2w.out = nullptr;
+      if (bf16 && !skip_d1 && net->gw1 && wide_ws > 0 && sc.slab_bytes[which] >= wide_ws && conv_pair_k1_supported(&d2, &d1) &&
+          conv_sub1_bf16_wide_bwd_supported(&d2w, &d1)) {
+        int slabs = 0;
+        {
+          ClassScope scp(PC_DGRAD2, k, conv_flops(M, k, 2 * h.co, SININN_HIDDEN) + 2.0 * conv_flops(M, k, SININN_HIDDEN, cond_cin), st);
+          if (int rc_ = conv_sub1_bf16_wide_bwd_wg1_launch(&d2w, &d1, cond, cond_stride, sc.slab[which], sc.slab_bytes[which], &slabs, st)) return rc_;
+        }
+        if (int rc_ = order_after(wst, st)) return rc_;
+        ClassScope scp(PC_WGRAD, k, 0.0, wst);
+        return conv_sub1_bf16_wide_reduce(sc.slab[which], slabs, net->gw1, net->gb1, wst);
+      }
     }
     const bool pair = !skip_d1 && conv_pair_k1_supported(&d2, &d1);
     if (pair) {

@@ -81,7 +81,7 @@ def test_glow_block(ksize, rev, channels, hw):
 
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
 @pytest.mark.parametrize('rev', [False, True])
-@pytest.mark.parametrize('channels,hw', [(48, (13, 21)), (192, (6, 18)), (16, (9, 33)), (96, (4, 16))])
+@pytest.mark.parametrize('channels,hw', [(48, (13, 21)), (192, (6, 18)), (16, (9, 33)), (96, (4, 16)), (192, (19, 40))])
 def test_fused_1x1_pair_matches_the_two_launch_path(rev, channels, hw, precision):
     """1x1 subnets run conv1 -> conv2 (and dgrad2 -> dgrad1) as ONE launch with the hidden tile in LDS (conv_pair_k1.hip);
     same block, same inputs through the two-launch path: equal up to fp32 summation order, forward and every gradient,
