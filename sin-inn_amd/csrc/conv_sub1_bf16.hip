@@ -1270,6 +1270,182 @@ __global__ __launch_bounds__(256) void wide_reduce_kernel(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// conv2's weight gradient of a WIDE 1x1 subnet (level 1: dW2[n][c] += sum_p dr[p][n] h[p][c], db2 += sum_p dr), persistent, 32-pixel
+// tiles: the third kernel of the level-1 backward.  h is read from HBM (bf16 [pixel][256]) with 4-byte loads in the lane-swapped
+// layout the forward kernel stored it in; swapped back it is the B operand as it stands (column on the lane, pixel pairs in the
+// registers) -- no LDS for the 256-channel operand at all; dr^T comes from a [channel][pixel] image (fp32 dr rounded while staged).
+// Six 32 x 32 accumulators per wave for the lifetime of the block, one slab per block (wide_reduce2_kernel).
+template <int K2>
+__global__ __launch_bounds__(S1_NTHR) void conv_sub1b_wide_wg2_kernel(const float* dr, int dr_stride, const __bf16* hin, int h_stride, int B, int H, int W,
+                                                                      int tiles_x, int tiles_y, int ntiles, float* slabs) {
+  constexpr int P = 32, NTHR = S1_NTHR, NM2 = K2 / 32, DTB = P * 2 + 8;
+  static_assert(K2 % 32 == 0 && K2 <= 192, "conv_sub1b_wide_wg2: shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_s1bw2[];    // 2 x [K2][DTB]: dr^T as bf16
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, hh = lane >> 5;
+  const int cw = wave * 32;
+  const bool odd = (r & 1) != 0;
+  const unsigned sel = odd ? 0x03020706u : 0x05040100u;
+  (void)B;
+
+  f32x16 acc[NM2];
+#pragma unroll
+  for (int t = 0; t < NM2; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  const int tiles_img = tiles_x * tiles_y;
+  auto tile_origin = [&](int tile, int& b, int& y0, int& x0) {
+    b = tile / tiles_img;
+    const int trem = tile - b * tiles_img;
+    const int ty = trem / tiles_x;
+    y0 = ty * 2; x0 = (trem - ty * tiles_x) * 16;
+  };
+  constexpr int QD = K2 / 4, FD = (P * QD + NTHR - 1) / NTHR;
+  f32x4 accb2[FD];                                  // db2 in fp32: a staging slot is the same (pixel, channel quad) of every tile
+#pragma unroll
+  for (int u = 0; u < FD; ++u) accb2[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto issue_tile = [&](int tile, f32x4 (&vd)[FD]) {
+    const bool live = tile < ntiles;
+    int b, y0, x0; tile_origin(live ? tile : 0, b, y0, x0);
+    const __amdgpu_buffer_rsrc_t d_rs = buf_rsrc(dr + (size_t)b * H * W * dr_stride);
+#pragma unroll
+    for (int u = 0; u < FD; ++u) {
+      const int f = tid + NTHR * u;
+      const int pl = f / QD, c = (f - pl * QD) * 4;
+      const int gy = y0 + (pl >> 4), gx = x0 + (pl & 15);
+      const unsigned off = (live && f < P * QD && gy < H && gx < W) ? (unsigned)(((gy * W + gx) * dr_stride + c) * 4) : BUF_OOB;
+      vd[u] = buf_load4(d_rs, off, 0u);
+    }
+  };
+  auto store_tile = [&](int buf, const f32x4 (&vd)[FD]) {
+    unsigned char* const dt = smem_s1bw2 + buf * (K2 * DTB);
+#pragma unroll
+    for (int u = 0; u < FD; ++u) {
+      const int f = tid + NTHR * u;
+      const int pl = f / QD, c = (f - pl * QD) * 4;
+      if (f < P * QD) {
+        accb2[u] += vd[u];                            // pixels outside the image were loaded as zeros
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<__bf16*>(dt + (c + j) * DTB + pl * 2) = (__bf16)vd[u][j];
+      }
+    }
+  };
+  auto issue_h = [&](int tile, unsigned (&hw)[8]) {
+    const bool live = tile < ntiles;
+    int b, y0, x0; tile_origin(live ? tile : 0, b, y0, x0);
+    const __amdgpu_buffer_rsrc_t rs = buf_rsrc(hin + (size_t)b * H * W * h_stride);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int pp = 16 * s + 8 * (d >> 1) + 2 * (d & 1) + 4 * hh + (odd ? 1 : 0);
+        const int gy = y0 + (pp >> 4), gx = x0 + (pp & 15);
+        const unsigned off = (live && gy < H && gx < W) ? (unsigned)(((gy * W + gx) * h_stride + cw + (r & ~1)) * 2) : BUF_OOB;
+        hw[4 * s + d] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0);
+      }
+  };
+
+  const int G = gridDim.x;
+  f32x4 vd[FD];
+  unsigned hw[8];
+  issue_tile(blockIdx.x, vd);
+  store_tile(0, vd);
+  issue_tile(blockIdx.x + G, vd);
+  issue_h(blockIdx.x, hw);
+  __syncthreads();
+  int buf = 0;
+  for (int tile = blockIdx.x; tile < ntiles; tile += G, buf ^= 1) {
+    const unsigned char* const dt = smem_s1bw2 + buf * (K2 * DTB);
+    bf16x8 hf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u32x4 own;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const unsigned w_ = hw[4 * s + d];
+        const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)w_, 0xB1, 0xF, 0xF, true);
+        own[d] = __builtin_amdgcn_perm(nb, w_, sel);                 // back to (pixel, pixel + 1) of this lane's column
+      }
+      hf[s] = __builtin_bit_cast(bf16x8, own);
+    }
+    issue_h(tile + G, hw);
+#pragma unroll
+    for (int t = 0; t < NM2; ++t)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 af = read_tr_frag(dt + (32 * t + r) * DTB + (16 * s + 4 * hh) * 2);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, hf[s], acc[t], 0, 0, 0);
+      }
+    if (tile + G < ntiles) store_tile(buf ^ 1, vd);
+    issue_tile(tile + 2 * G, vd);
+    __syncthreads();
+  }
+  // slab: dW2 [K2][256] | db2 [256: first K2 used]
+  float* const slab = slabs + (size_t)blockIdx.x * ((K2 + 1) * S1_HID);
+#pragma unroll
+  for (int t = 0; t < NM2; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) slab[(32 * t + (e & 3) + 8 * (e >> 2) + 4 * hh) * S1_HID + cw + r] = acc[t][e];
+  __syncthreads();
+  float* const red = reinterpret_cast<float*>(smem_s1bw2);         // [P * QD] float4 = 24 KB of the 27 KB
+#pragma unroll
+  for (int u = 0; u < FD; ++u) {
+    const int f = tid + NTHR * u;
+    if (f < P * QD) *reinterpret_cast<f32x4*>(red + 4 * f) = accb2[u];
+  }
+  __syncthreads();
+  if (tid < S1_HID) {
+    float v = 0.f;
+    if (tid < K2) {
+      float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int pl = 0; pl < P; pl += 4)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part[i] += red[(pl + i) * K2 + tid];
+      v = (part[0] + part[1]) + (part[2] + part[3]);
+    }
+    slab[K2 * S1_HID + tid] = v;
+  }
+}
+
+// gw2[n][c] += sum over the slabs of dW2[n][c] (the slab row IS the OIHW row of a 1x1 conv), gb2[n] += sum of db2[n]
+template <int K2>
+__global__ __launch_bounds__(256) void wide_reduce2_kernel(const float* __restrict__ slabs, int S, float* __restrict__ gw2, float* __restrict__ gb2) {
+  constexpr int ET = (K2 + 1) * S1_HID / 4;
+  constexpr size_t slab4 = (size_t)(K2 + 1) * S1_HID / 4;
+  __shared__ f32x4 part[8][32];
+  const int tid = threadIdx.x, g = tid >> 5, el = tid & 31;
+  const int e = blockIdx.x * 32 + el;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+  if (e < ET) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(slabs) + e;
+    int s = g;
+#pragma unroll 4
+    for (; s + 8 < S; s += 16) { a0 += src[(size_t)s * slab4]; a1 += src[(size_t)(s + 8) * slab4]; }
+    if (s < S) a0 += src[(size_t)s * slab4];
+    a0 += a1;
+  }
+  part[g][el] = a0;
+  __syncthreads();
+  if (tid < 32 && e < ET) {
+    const f32x4 tot = ((part[0][el] + part[1][el]) + (part[2][el] + part[3][el])) + ((part[4][el] + part[5][el]) + (part[6][el] + part[7][el]));
+    const int idx = e * 4;
+    if (idx < K2 * S1_HID) {
+      if (gw2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gw2[idx + j] += tot[j];
+      }
+    } else if (gb2) {
+      const int n = idx - K2 * S1_HID;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (n + j < K2) gb2[n + j] += tot[j];
+    }
+  }
+}
+
 // ---- host -----------------------------------------------------------------------------------------------------------------------
 size_t conv_sub1_bwd_workspace_bytes(int cond_cin, int co);      // conv_sub1.hip: the slab layout is shared
 static bool g_sub1b_enabled = getenv("SININN_SUB1_BF16") == nullptr || atoi(getenv("SININN_SUB1_BF16")) != 0;   // A/B switch
@@ -1546,6 +1722,32 @@ int conv_sub1_bf16_wide_reduce(const void* ws, int slabs, float* gw1, float* gb1
   constexpr int ET = (96 + 1) * S1_HID / 4;
   hipLaunchKernelGGL((wide_reduce_kernel<96>), dim3((ET + 31) / 32), dim3(256), 0, st, static_cast<const float*>(ws), slabs, gw1, gb1);
   SININN_LAUNCH_CHECK("conv_sub1_bf16_wide_reduce");
+  return 0;
+}
+
+// conv2's weight gradient of a wide subnet: dr fp32 [pixel][192], h bf16 [pixel][256] -> slabs in ws; then the reduce
+size_t conv_sub1_bf16_wide_wg2_ws_bytes(int ksize, int dtype, int cond_cin, int co) {
+  if (!g_sub1b_enabled || !g_sub1b_wide || ksize != 1 || dtype != 1 || cond_cin != 96 || co != 96) return 0;
+  return (size_t)S1_MAX_BLOCKS * (192 + 1) * S1_HID * sizeof(float);
+}
+
+int conv_sub1_bf16_wide_wg2_launch(const float* dr, int dr_stride, const void* h, int h_stride, int B, int H, int W, void* ws, size_t ws_bytes,
+                                   float* gw2, float* gb2, hipStream_t st) {
+  SININN_CHECK(dr && h && ws && aligned16(dr) && aligned16(h) && aligned16(ws) && dr_stride % 4 == 0 && h_stride % 8 == 0 && B > 0 && H > 0 && W > 0,
+               "conv_sub1_bf16_wide_wg2: bad arguments");
+  SININN_CHECK(ws_bytes >= (size_t)S1_MAX_BLOCKS * (192 + 1) * S1_HID * sizeof(float), "conv_sub1_bf16_wide_wg2: workspace too small");
+  SININN_CHECK((unsigned long long)H * W * dr_stride * 4ull < (1ull << 31) && (unsigned long long)H * W * h_stride * 2ull < (1ull << 31),
+               "conv_sub1_bf16_wide_wg2: one image of an operand exceeds the 2 GB a block addresses");
+  const int tiles_x = (W + 15) / 16, tiles_y = (H + 1) / 2, ntiles = tiles_x * tiles_y * B;
+  const int blocks = ntiles < S1_MAX_BLOCKS ? ntiles : S1_MAX_BLOCKS;
+  constexpr size_t lds = (size_t)2 * 192 * (32 * 2 + 8);
+  auto k = conv_sub1b_wide_wg2_kernel<192>;
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(S1_NTHR), lds, st, dr, dr_stride, reinterpret_cast<const __bf16*>(h), h_stride, B, H, W, tiles_x, tiles_y,
+                     ntiles, static_cast<float*>(ws));
+  SININN_LAUNCH_CHECK("conv_sub1_bf16_wide_wg2");
+  constexpr int ET = (192 + 1) * S1_HID / 4;
+  hipLaunchKernelGGL((wide_reduce2_kernel<192>), dim3((ET + 31) / 32), dim3(256), 0, st, static_cast<const float*>(ws), blocks, gw2, gb2);
+  SININN_LAUNCH_CHECK("conv_sub1_bf16_wide_reduce2");
   return 0;
 }
 

@@ -55,6 +55,9 @@ int conv_sub1_bf16_wide_bwd_supported(const sininn_conv_args* d2, const sininn_c
 int conv_sub1_bf16_wide_bwd_wg1_launch(const sininn_conv_args* d2, const sininn_conv_args* d1, const float* x, int x_stride, void* ws, size_t ws_bytes,
                                        int* slabs_out, hipStream_t st);
 int conv_sub1_bf16_wide_reduce(const void* ws, int slabs, float* gw1, float* gb1, hipStream_t st);
+size_t conv_sub1_bf16_wide_wg2_ws_bytes(int ksize, int dtype, int cond_cin, int co);
+int conv_sub1_bf16_wide_wg2_launch(const float* dr, int dr_stride, const void* h, int h_stride, int B, int H, int W, void* ws, size_t ws_bytes,
+                                   float* gw2, float* gb2, hipStream_t st);
 
 int order_after(hipStream_t waiter, hipStream_t producer) {
   if (waiter == producer) return 0;
@@ -237,7 +240,7 @@ size_t glow_saved_floats(int B, int H, int W, int C, int dtype) {
   return 2 * align64(hid) + 3 * align64(M * big) + 64;
 }
 
-struct Scratch { float *dr_b, *dh_b, *dy_first, *dr_a, *dh_a; void* ws; size_t ws_bytes; void* slab[2]; size_t slab_bytes[2]; size_t total_bytes; };
+struct Scratch { float *dr_b, *dh_b, *dy_first, *dr_a, *dh_a; void* ws; size_t ws_bytes; void* slab[2]; size_t slab_bytes[2]; void* slab2[2]; size_t slab2_bytes[2]; size_t total_bytes; };
 static Scratch scratch_layout(void* basep, int B, int H, int W, int C, int ksize, int co_a, int co_b, int dtype = 0) {
   const size_t M = (size_t)B * H * W;
   float* base = static_cast<float*>(basep);
@@ -291,6 +294,10 @@ static Scratch scratch_layout(void* basep, int B, int H, int W, int C, int ksize
     if (wide > s.slab_bytes[i]) s.slab_bytes[i] = wide;
     s.slab[i] = reinterpret_cast<char*>(base) + so;
     so += (s.slab_bytes[i] + 255) / 256 * 256;
+    // ... and of conv2's weight gradient of a wide 1x1 subnet on the mixed-precision path (its own kernel, weight-gradient stream)
+    s.slab2_bytes[i] = conv_sub1_bf16_wide_wg2_ws_bytes(ksize, dtype, cond_cin[i], cos[i]);
+    s.slab2[i] = reinterpret_cast<char*>(base) + so;
+    so += (s.slab2_bytes[i] + 255) / 256 * 256;
   }
   s.total_bytes = so;
   return s;
@@ -510,7 +517,15 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
     const bool gm = group_major_hidden(a, net);
     const int gs = gm ? (int)(M * 8) : 0;
     const bool fused = fused_sub1(a, cond_cin, h.co);       // conv_sub1.hip: its weight gradients come out of the same launch
-    if (net->gw2 && !fused) {
+    const int which_half = (&h == &hv[0]) ? 0 : 1;
+    const bool wide_wg2 = bf16 && k == 1 && sc.slab2_bytes[which_half] > 0;
+    if (net->gw2 && !fused && wide_wg2) {
+      // wide 1x1 subnet, mixed precision: dW2 += dr^T h as its own persistent kernel (h read straight into MFMA operand registers)
+      if (int rc = order_after(wst, st)) return rc;
+      ClassScope scp(PC_WGRAD, k, conv_flops(M, k, SININN_HIDDEN, 2 * h.co), wst);
+      if (int rc = conv_sub1_bf16_wide_wg2_launch(dr, 2 * h.co, hbuf, SININN_HIDDEN, B, H, W, sc.slab2[which_half], sc.slab2_bytes[which_half],
+                                                  net->gw2, net->gb2, wst)) return rc;
+    } else if (net->gw2 && !fused) {
       if (grouped) add_item(hbuf, SININN_HIDDEN, SININN_HIDDEN, dr, 2 * h.co, 2 * h.co, net->gw2, net->gb2, bf16 ? 1 : 0, 0, gs, 0);
       else {
         if (int rc = order_after(wst, st)) return rc;

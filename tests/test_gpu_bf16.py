@@ -373,7 +373,8 @@ def test_fused_3x3_subnet_through_the_c_abi():
 
 
 @pytest.mark.parametrize('rev', [False, True])
-@pytest.mark.parametrize('channels,hw', [(48, (13, 21)), (48, (64, 64)), (16, (9, 33)), (32, (5, 16)), (48, (70, 40))])
+@pytest.mark.parametrize('channels,hw', [(48, (13, 21)), (48, (64, 64)), (16, (9, 33)), (32, (5, 16)), (48, (70, 40)),
+                                         (192, (6, 18)), (192, (19, 40)), (192, (45, 80))])    # 192: the level-1 kernels (wide forward / backward + dW1 / dW2)
 def test_fused_1x1_subnet_bf16_matches_the_pair_path(rev, channels, hw):
     """Round 4: on the mixed-precision path the level-0 1x1 subnets run as the persistent fused kernels too (conv_sub1_bf16.hip:
     forward without storing h; the whole backward -- recompute, both data gradients, both weight gradients -- in one launch with h /
