@@ -25,6 +25,7 @@ int conv_sub1_bwd_launch(const sininn_conv_args* rc, const sininn_conv_args* d2,
                          size_t ws_bytes, int* slabs_out, hipStream_t st);
 int conv_sub1_bwd_reduce(int cond_cin, int co, const void* ws, int slabs, float* gw2, float* gb2, float* gw1, float* gb1, hipStream_t st);
 void conv_sub1_bwd_enable(int on);
+void conv3_smallk_enable(int on);
 int conv_sub1_fwd_supported(const sininn_conv_args* f, const sininn_conv_args* s);
 int conv_sub1_fwd_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st);
 int conv_pair_k1_launch(const sininn_conv_args* f, const sininn_conv_args* s, hipStream_t st);
@@ -311,7 +312,7 @@ int sininn_conv_sub1_bwd(const sininn_conv_args* recompute, const sininn_conv_ar
   return conv_sub1_bwd_reduce(recompute->Cin, d2->Cin / 2, workspace, slabs, gw2, gb2, gw1, gb1, ST(stream));
 }
 // test hook: the block executor's fused 1x1 subnet backward on / off (A/B against the pair + grouped weight-gradient path)
-void sininn_sub1_bwd_test_hook(int on) { conv_sub1_bwd_enable(on); }
+void sininn_sub1_bwd_test_hook(int on) { conv_sub1_bwd_enable(on); conv3_smallk_enable(on); }   // every round-4 persistent kernel on / off
 
 /* test hook (not part of the documented surface): force tile configuration / channel chunk */
 void sininn_conv_test_hooks(int force_cfg, int force_ck) { conv_set_test_hooks(force_cfg, force_ck); }

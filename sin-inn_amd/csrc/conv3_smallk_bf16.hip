@@ -16,15 +16,22 @@
 // 127 us in the general kernel at configs[3]): the same kernel with 27 weight fragments per wave and the mask applied to the
 // packed output word -- the mask word of (pixel, columns c, c + 1) is loaded from h with the address the output word is stored
 // to, two 32-pixel steps ahead of its use.
+// `bits` (block executor only): the ReLU gates as a bit mask, one 32-bit word per (32-pixel step of a tile, hidden column): bit p =
+// gate of pixel p of the step.  A lane of conv1 holds 16 of a column's 32 pixels in its accumulator registers: it packs their
+// gates, ORs with the lane 32 apart (the other 16 pixels) and the wave stores 128 contiguous bytes per step; the masked data
+// gradient loads the words of its two columns once per step (8 bytes per lane) instead of eight words of h: 32 B per pixel
+// instead of 512 B (134 MB -> 8 MB at BASELINE configs[3], level 0).  The layout is private to these two kernels.
 #include <cstdlib>
 #include "conv_bf16_types.h"
 
 namespace sininn {
 
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int C3K_NTHR = 512, C3K_HALO = 18, C3K_HPIX = C3K_HALO * C3K_HALO, C3K_MAX_BLOCKS = 256;
 
-template <int CIN, bool MASK>
-__global__ __launch_bounds__(C3K_NTHR) void conv3_smallk_bf16_kernel(ConvDevB q, int ntiles) {
+template <int CIN, bool MASK, bool BITS>
+__global__ __launch_bounds__(C3K_NTHR) void conv3_smallk_bf16_kernel(ConvDevB q, int ntiles, unsigned* bits) {
   constexpr int KP = (CIN + 15) / 16 * 16;
   constexpr int NS = KP / 16, XSB = KP * 2 + 16;                  // bytes per halo pixel: 16 (mod 32) -> conflict-free 16-byte reads
   constexpr int IMG = (C3K_HPIX * XSB + 15) / 16 * 16;
@@ -93,19 +100,25 @@ __global__ __launch_bounds__(C3K_NTHR) void conv3_smallk_bf16_kernel(ConvDevB q,
     return (gy < p.H && gx < p.W) ? (unsigned)(((gy * p.W + gx) * stride + cw + (r & ~1)) * 2) : BUF_OOB;
   };
   // ReLU-mask words of a 32-pixel step, requested two steps ahead of their use (a step is 27 MFMAs ~ 0.4 us per wave)
-  unsigned mk[2][8];
-  auto issue_mask = [&](int tile, int m, unsigned (&dst)[8]) {
+  unsigned mk[2][BITS ? 2 : 8];
+  auto issue_mask = [&](int tile, int m, unsigned (&dst)[BITS ? 2 : 8]) {
     if constexpr (MASK) {
       const bool live = tile < ntiles;
       const int b = live ? tile / tiles_img : 0;
       const int trem = tile - b * tiles_img;
       const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
-      const __amdgpu_buffer_rsrc_t rs = buf_rsrc(q.mask_b + (size_t)b * p.H * p.W * p.mask_stride);
+      if constexpr (BITS) {                          // gate words of this lane's two columns for step m of the tile
+        const unsigned step = (unsigned)(((b * p.tiles_y + ty) * p.tiles_x + tx) * 8 + m);
+        const u32x2 g2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(buf_rsrc(bits), (int)(live ? (step * 256u + cw + (r & ~1)) * 4u : BUF_OOB), 0, 0));
+        dst[0] = g2[0]; dst[1] = g2[1];
+      } else {
+        const __amdgpu_buffer_rsrc_t rs = buf_rsrc(q.mask_b + (size_t)b * p.H * p.W * p.mask_stride);
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
-          dst[4 * s + d] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(live ? word_off(ty * 16, tx * 16, m, s, d, p.mask_stride) : BUF_OOB), 0, 0);
+          for (int d = 0; d < 4; ++d)
+            dst[4 * s + d] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(live ? word_off(ty * 16, tx * 16, m, s, d, p.mask_stride) : BUF_OOB), 0, 0);
+      }
     }
   };
 
@@ -130,6 +143,7 @@ __global__ __launch_bounds__(C3K_NTHR) void conv3_smallk_bf16_kernel(ConvDevB q,
     for (int m = 0; m < 8; ++m) {                   // 32 pixels per step: tile rows 2 m, 2 m + 1
       const unsigned char* const arow = xs + ((2 * m + (r >> 4)) * C3K_HALO + (r & 15)) * XSB + 16 * hh;
       f32x16 acc;
+      unsigned gate_word = 0u;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
@@ -146,18 +160,41 @@ __global__ __launch_bounds__(C3K_NTHR) void conv3_smallk_bf16_kernel(ConvDevB q,
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[j] = MASK ? (__bf16)acc[8 * s + j] : (__bf16)fmaxf(acc[8 * s + j] + bv, 0.f);
         const u32x4 own = __builtin_bit_cast(u32x4, f);
+        if constexpr (!MASK) {
+          if constexpr (BITS) {                      // gates of this lane's 8 pixels of fragment s: pixel 16 s + 8 (j >> 2) + (j & 3) (+ 4 hh below)
+#pragma unroll
+            for (int dq = 0; dq < 4; ++dq) {
+              const unsigned t = own[dq] & 0x7fff7fffu;          // after the ReLU a value is +0, -0 or positive
+              const int p0 = 16 * s + 8 * (dq >> 1) + 2 * (dq & 1);
+              gate_word |= ((t & 0xffffu) ? 1u : 0u) << p0;
+              gate_word |= ((t >> 16) ? 1u : 0u) << (p0 + 1);
+            }
+          }
+        }
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
           const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)own[d], 0xB1, 0xF, 0xF, true);
           unsigned outw = __builtin_amdgcn_perm(nb, own[d], sel);
           if constexpr (MASK) {                      // h > 0 of the two bf16 halves: not zero and not negative
-            const unsigned mw = mk[m & 1][4 * s + d];
-            const unsigned keep = (((mw & 0x7fffu) != 0u && (mw & 0x8000u) == 0u) ? 0x0000ffffu : 0u) |
-                                  (((mw & 0x7fff0000u) != 0u && (mw & 0x80000000u) == 0u) ? 0xffff0000u : 0u);
+            const unsigned mw = BITS ? 0u : mk[m & 1][(BITS ? 0 : 4 * s + d)];
+            unsigned keep;
+            if constexpr (BITS) {                    // bit pp of the gate words of columns c, c + 1 (pp = this word's pixel of the step)
+              const int pp = 16 * s + 8 * (d >> 1) + 2 * (d & 1) + 4 * hh + (odd ? 1 : 0);
+              keep = (((mk[m & 1][0] >> pp) & 1u) ? 0x0000ffffu : 0u) | (((mk[m & 1][1] >> pp) & 1u) ? 0xffff0000u : 0u);
+            } else {
+              keep = (((mw & 0x7fffu) != 0u && (mw & 0x8000u) == 0u) ? 0x0000ffffu : 0u) |
+                     (((mw & 0x7fff0000u) != 0u && (mw & 0x80000000u) == 0u) ? 0xffff0000u : 0u);
+            }
             outw &= keep;
           }
           __builtin_amdgcn_raw_buffer_store_b32(outw, out_rs, (int)word_off(y0, x0, m, s, d, p.out_stride), 0, 0);
         }
+      }
+      if constexpr (!MASK && BITS) {                 // this lane's 16 pixels | the other 16 (lane 32 apart); lanes 0 .. 31 store 128 bytes
+        unsigned g = gate_word << (4 * hh);
+        g |= (unsigned)__shfl_xor((int)g, 32);
+        const size_t step = ((size_t)(b * p.tiles_y + ty) * p.tiles_x + tx) * 8 + m;
+        if (hh == 0) bits[step * 256 + cw + r] = g;
       }
       if (m < 6) issue_mask(tile, m + 2, mk[m & 1]);  // the set just consumed: two steps ahead (the next tile's first two at the end)
       else issue_mask(tile + G, m - 6, mk[m & 1]);
@@ -191,41 +228,51 @@ int conv3_smallk_bf16_supported(const sininn_conv_args* a) {
   return 1;
 }
 
-template <int CIN, bool MASK>
-static int c3k_launch(const ConvDevB& q, int ntiles, hipStream_t st) {
+template <int CIN, bool MASK, bool BITS>
+static int c3k_launch_b(const ConvDevB& q, int ntiles, unsigned* bits, hipStream_t st) {
   constexpr int KP = (CIN + 15) / 16 * 16;
   constexpr int IMG = (C3K_HPIX * (KP * 2 + 16) + 15) / 16 * 16;
   constexpr size_t lds = 2 * (size_t)IMG;
-  auto k = conv3_smallk_bf16_kernel<CIN, MASK>;
+  auto k = conv3_smallk_bf16_kernel<CIN, MASK, BITS>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("conv3_smallk_bf16: cannot raise the LDS limit to %zu", lds); return 1; }
   }
   const int blocks = ntiles < C3K_MAX_BLOCKS ? ntiles : C3K_MAX_BLOCKS;
-  hipLaunchKernelGGL(k, dim3(blocks), dim3(C3K_NTHR), lds, st, q, ntiles);
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(C3K_NTHR), lds, st, q, ntiles, bits);
   SININN_LAUNCH_CHECK("conv3_smallk_bf16");
   return 0;
 }
 
-int conv3_smallk_bf16_launch(const sininn_conv_args* a, hipStream_t st) {
+template <int CIN, bool MASK>
+static int c3k_launch(const ConvDevB& q, int ntiles, unsigned* bits, hipStream_t st) {
+  return bits ? c3k_launch_b<CIN, MASK, true>(q, ntiles, bits, st) : c3k_launch_b<CIN, MASK, false>(q, ntiles, bits, st);
+}
+
+// bits: NULL, or the gate bit mask [B*H*W][8] words that conv1 (mode RELU) writes and the masked data gradient (mode MASK) reads
+// instead of a->mask (block executor: the region lives in `saved`)
+int conv3_smallk_bf16_launch_bits(const sininn_conv_args* a, unsigned* bits, hipStream_t st) {
   SININN_CHECK(conv3_smallk_bf16_supported(a), "conv3_smallk_bf16: unsupported conv");
   ConvDevB q;
   if (int rc = conv_bf16_prepare(a, q)) return rc;
   q.c.tiles_x = (a->W + 15) / 16; q.c.tiles_y = (a->H + 15) / 16;
   const int ntiles = q.c.tiles_x * q.c.tiles_y * a->B;
+  SININN_CHECK(!bits || (unsigned long long)ntiles * 8ull * 256ull * 4ull < (1ull << 31), "conv3_smallk_bf16: gate bit mask exceeds 2 GB");
   if (a->mode == SININN_CONV_MASK) {
     switch (a->Cin) {
-      case 16: return c3k_launch<16, true>(q, ntiles, st);
-      case 32: return c3k_launch<32, true>(q, ntiles, st);
-      default: return c3k_launch<48, true>(q, ntiles, st);
+      case 16: return c3k_launch<16, true>(q, ntiles, bits, st);
+      case 32: return c3k_launch<32, true>(q, ntiles, bits, st);
+      default: return c3k_launch<48, true>(q, ntiles, bits, st);
     }
   }
   switch (a->Cin) {
-    case 8: return c3k_launch<8, false>(q, ntiles, st);
-    case 16: return c3k_launch<16, false>(q, ntiles, st);
-    case 24: return c3k_launch<24, false>(q, ntiles, st);
-    default: return c3k_launch<32, false>(q, ntiles, st);
+    case 8: return c3k_launch<8, false>(q, ntiles, bits, st);
+    case 16: return c3k_launch<16, false>(q, ntiles, bits, st);
+    case 24: return c3k_launch<24, false>(q, ntiles, bits, st);
+    default: return c3k_launch<32, false>(q, ntiles, bits, st);
   }
 }
+
+int conv3_smallk_bf16_launch(const sininn_conv_args* a, hipStream_t st) { return conv3_smallk_bf16_launch_bits(a, nullptr, st); }
 
 }  // namespace sininn

@@ -55,6 +55,9 @@ int conv_sub1_bf16_wide_bwd_supported(const sininn_conv_args* d2, const sininn_c
 int conv_sub1_bf16_wide_bwd_wg1_launch(const sininn_conv_args* d2, const sininn_conv_args* d1, const float* x, int x_stride, void* ws, size_t ws_bytes,
                                        int* slabs_out, hipStream_t st);
 int conv_sub1_bf16_wide_reduce(const void* ws, int slabs, float* gw1, float* gb1, hipStream_t st);
+// conv3_smallk_bf16.hip: the small-K 3x3 convs of a level-0 subnet; `bits` = the ReLU gates as a bit mask [pixel][8] words
+int conv3_smallk_bf16_supported(const sininn_conv_args* a);
+int conv3_smallk_bf16_launch_bits(const sininn_conv_args* a, unsigned* bits, hipStream_t st);
 size_t conv_sub1_bf16_wide_wg2_ws_bytes(int ksize, int dtype, int cond_cin, int co);
 int conv_sub1_bf16_wide_wg2_launch(const float* dr, int dr_stride, const void* h, int h_stride, int B, int H, int W, void* ws, size_t ws_bytes,
                                    float* gw2, float* gb2, hipStream_t st);
@@ -219,8 +222,10 @@ static void halves_of(const sininn_glow_args* a, Half h[2]) {
   else { h[0] = Half{&a->s1, 0, l1, l2}; h[1] = Half{&a->s2, -1, 0, l1}; }
 }
 
-struct Saved { float *h_a, *h_b, *s_a, *s_b, *ybuf; size_t total; };
-static Saved saved_layout(float* base, size_t M, int co_a, int co_b, bool bf16 = false) {
+struct Saved { float *h_a, *h_b, *s_a, *s_b, *ybuf; unsigned *bits_a, *bits_b; size_t total; };
+static inline size_t padded_pixels(int B, int H, int W) { return (size_t)B * ((H + 15) / 16 * 16) * ((W + 15) / 16 * 16); }
+// Mpad: pixels of the image padded to whole 16 x 16 tiles (the gate bit masks are indexed by tile step)
+static Saved saved_layout(float* base, size_t M, int co_a, int co_b, bool bf16 = false, size_t Mpad = 0) {
   Saved s;
   size_t o = 0;
   const size_t hid = bf16 ? M * SININN_HIDDEN / 2 : M * SININN_HIDDEN;      // bf16 hidden tensors take half the floats
@@ -229,6 +234,12 @@ static Saved saved_layout(float* base, size_t M, int co_a, int co_b, bool bf16 =
   s.s_a = base + o; o += align64(M * co_a);
   s.s_b = base + o; o += align64(M * co_b);
   s.ybuf = base + o; o += align64(M * co_a);
+  // mixed precision: the ReLU gates of the two hidden tensors as bit masks, [pixel][256 / 32] words (the small-K 3x3 kernels)
+  s.bits_a = s.bits_b = nullptr;
+  if (bf16) {
+    s.bits_a = reinterpret_cast<unsigned*>(base + o); o += align64(Mpad * (SININN_HIDDEN / 32));
+    s.bits_b = reinterpret_cast<unsigned*>(base + o); o += align64(Mpad * (SININN_HIDDEN / 32));
+  }
   s.total = o;
   return s;
 }
@@ -237,7 +248,7 @@ size_t glow_saved_floats(int B, int H, int W, int C, int dtype) {
   const size_t M = (size_t)B * H * W;
   const int big = C - C / 2;
   const size_t hid = dtype == 1 ? M * SININN_HIDDEN / 2 : M * SININN_HIDDEN;
-  return 2 * align64(hid) + 3 * align64(M * big) + 64;
+  return 2 * align64(hid) + 3 * align64(M * big) + (dtype == 1 ? 2 * align64(padded_pixels(B, H, W) * (SININN_HIDDEN / 32)) : 0) + 64;
 }
 
 struct Scratch { float *dr_b, *dh_b, *dy_first, *dr_a, *dh_a; void* ws; size_t ws_bytes; void* slab[2]; size_t slab_bytes[2]; void* slab2[2]; size_t slab2_bytes[2]; size_t total_bytes; };
@@ -344,7 +355,7 @@ int glow_hidden_gates(const sininn_glow_args* a, int which, unsigned char* gates
   const size_t M = (size_t)a->B * a->H * a->W;
   Half hv[2];
   halves_of(a, hv);
-  Saved sv = saved_layout(a->saved, M, hv[0].co, hv[1].co, a->dtype == 1);
+  Saved sv = saved_layout(a->saved, M, hv[0].co, hv[1].co, a->dtype == 1, padded_pixels(a->B, a->H, a->W));
   float* h = which == 0 ? sv.h_a : sv.h_b;
   const int gm = group_major_hidden(a, hv[which].net) ? 1 : 0;
   {
@@ -389,7 +400,7 @@ int glow_forward(const sininn_glow_args* a, hipStream_t st) {
   const int C = a->C;
   Half hv[2];
   halves_of(a, hv);
-  Saved sv = saved_layout(a->saved, M, hv[0].co, hv[1].co, a->dtype == 1);
+  Saved sv = saved_layout(a->saved, M, hv[0].co, hv[1].co, a->dtype == 1, padded_pixels(a->B, a->H, a->W));
   const int mode = a->rev ? SININN_CONV_COUPLE_INV : SININN_CONV_COUPLE_FWD;
   const bool bf16 = a->dtype == 1;
   for (int i = 0; i < 2; ++i) {
@@ -447,7 +458,10 @@ int glow_forward(const sininn_glow_args* a, hipStream_t st) {
     }
     {
       ClassScope sc(PC_CONV1, a->ksize, conv_flops(M, a->ksize, c1.Cin, SININN_HIDDEN), st);
-      if (int rc = conv_launch(&c1, st)) return rc;
+      if (bf16 && a->ksize == 3 && !a->no_save && conv3_smallk_bf16_supported(&c1)) {
+        // small-K conv1 of a training pass: the gates go out as a bit mask too (the backward's masked data gradient reads it)
+        if (int rc = conv3_smallk_bf16_launch_bits(&c1, i == 0 ? sv.bits_a : sv.bits_b, st)) return rc;
+      } else if (int rc = conv_launch(&c1, st)) return rc;
     }
     hipEvent_t e0, e1;
     unsigned long long* stamp = nullptr;
@@ -473,7 +487,7 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
   Half hv[2];
   halves_of(a, hv);
   const int co_a = hv[0].co, co_b = hv[1].co, base_a = hv[0].base, base_b = hv[1].base;
-  Saved sv = saved_layout(a->saved, M, co_a, co_b, a->dtype == 1);
+  Saved sv = saved_layout(a->saved, M, co_a, co_b, a->dtype == 1, padded_pixels(a->B, a->H, a->W));
   Scratch sc = scratch_layout(a->scratch, B, H, W, C, k, co_a, co_b, a->dtype);
   SININN_CHECK(a->scratch_bytes >= sc.total_bytes, "glow_backward: scratch too small (%zu < %zu)", a->scratch_bytes, sc.total_bytes);
   const int inv = a->rev ? 1 : 0;
@@ -604,7 +618,14 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
       if (int rc = conv_pair_k1_launch(&d2, &d1, st)) return rc;
     } else {
       ClassScope scp(PC_DGRAD2, k, conv_flops(M, k, 2 * h.co, SININN_HIDDEN), st);
-      if (int rc = conv_launch(&d2, st)) return rc;
+      // the forward pass wrote the gate bit mask iff its conv1 ran on the small-K kernel: the same predicate on the same descriptor
+      sininn_conv_args f1 = {};
+      f1.in = cond; f1.in_stride = cond_stride; f1.Cin = cond_cin; f1.w = net->w1; f1.bias = net->b1; f1.Np = SININN_HIDDEN;
+      f1.B = B; f1.H = H; f1.W = W; f1.ksize = k; f1.mode = SININN_CONV_RELU;
+      f1.out = const_cast<float*>(hbuf); f1.out_stride = SININN_HIDDEN; f1.N = SININN_HIDDEN; f1.w_bf16 = 1; f1.out_bf16 = 1;
+      if (bf16 && k == 3 && conv3_smallk_bf16_supported(&f1) && conv3_smallk_bf16_supported(&d2)) {
+        if (int rc = conv3_smallk_bf16_launch_bits(&d2, which_half == 0 ? sv.bits_a : sv.bits_b, st)) return rc;
+      } else if (int rc = conv_launch(&d2, st)) return rc;
     }
     if (net->gw1) {
       if (grouped) add_item(cond, cond_stride, cond_cin, dh, SININN_HIDDEN, SININN_HIDDEN, net->gw1, net->gb1, 0, bf16 ? 1 : 0, 0, gs);

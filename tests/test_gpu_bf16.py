@@ -517,3 +517,41 @@ def test_fused_1x1_subnet_bf16_c_abi(co, b, hw, no_dx):
             g0[2].double() + (dh.t() @ xb).reshape(256, k1, 1, 1), g0[3].double() + dh.sum(0)]
     for name, got, ref_ in zip(('gw2', 'gb2', 'gw1', 'gb1'), (gw2, gb2, gw1, gb1), want):
         assert relerr(got, ref_.float()) < 1e-4, (name, relerr(got, ref_.float()))
+
+
+@pytest.mark.parametrize('rev', [False, True])
+@pytest.mark.parametrize('channels,hw', [(48, (13, 21)), (48, (40, 33)), (16, (9, 33)), (32, (18, 16))])
+def test_small_k_3x3_kernels_match_the_general_conv(rev, channels, hw):
+    """Round 4: on the mixed-precision path the two "fat output" 3x3 convs of a level-0 subnet -- conv1 (Cin <= 32 -> 256, ReLU) and
+    the masked data gradient of conv2 (2 Co <= 48 -> 256) -- run on a persistent kernel with register-resident weights
+    (conv3_smallk_bf16.hip); in a training pass conv1 also writes the ReLU gates as a bit mask (a wave ballot per accumulator
+    register) that the data gradient reads instead of the 256-channel hidden tensor.  Same block, same inputs with the switch off
+    (general bf16 conv, mask read from h): every tensor within the one-bf16-ulp budget of the other A/B tests of this file, ragged
+    sizes (16 x 16 tiles cut in x and y), the shapes the kernel serves, both directions; a wrong gate bit would be an O(1) error in dx."""
+    import archs
+    import sin_inn_amd as S
+    from sin_inn_amd import _lib
+    torch.manual_seed(channels + hw[1])
+    h, w = hw
+    blk = S.GLOWCouplingBlock([(channels, h, w)], subnet_constructor=archs.subnet_conv, clamp=1.2)
+    for p in blk.parameters():
+        p.data.mul_(3.0)
+    blk.cuda()
+    blk.precision = 'bf16'
+    x = torch.randn(2, channels, h, w)
+    wgt, ld_w = torch.randn_like(x), torch.randn(2)
+    res = []
+    try:
+        for on in (1, 0):
+            _lib.lib().sininn_sub1_bwd_test_hook(on)
+            blk.zero_grad()
+            xg = x.cuda().requires_grad_(True)
+            y = blk([xg], rev=rev)[0]
+            ((y * wgt.cuda()).sum() + (blk.last_jac * ld_w.cuda()).sum()).backward()
+            S.modules.join_side_streams()
+            res.append([y.detach(), blk.last_jac.detach().clone(), xg.grad] + [p.grad.clone() for p in blk.parameters()])
+    finally:
+        _lib.lib().sininn_sub1_bwd_test_hook(1)
+    names = ['y', 'logdet', 'dx'] + [n for n, _ in blk.named_parameters()]
+    for n, a, b in zip(names, *res):
+        assert relerr(a, b) < 8e-3 and rel_l2(a, b) < 5e-4, (n, relerr(a, b), rel_l2(a, b))
