@@ -188,7 +188,9 @@ int sininn_conv_pair_k1(const sininn_conv_args* first, const sininn_conv_args* s
  * (Cin of conv1, 2 Co) in {(8, 16), (16, 32), (24, 48)} -- level 0 of the SRF network.  A block per CU keeps conv2's pack in LDS and
  * its conv1 fragments in registers over all of its 64-pixel tiles; the hidden tensor is never stored (first->out is ignored: the
  * matching backward, sininn_conv_sub1_bwd, recomputes it).  first: mode RELU; second: mode COUPLE_FWD / COUPLE_INV, described as
- * for sininn_conv_pair_k1.  Same values as the pair up to fp32 summation order (K = 256 is summed in two halves). */
+ * for sininn_conv_pair_k1.  Same values as the pair up to fp32 summation order (K = 256 is summed in two halves).
+ * Mixed precision (both convs w_bf16, described as for the mixed-precision pair): the same entry points run the bf16 twins
+ * (csrc/conv_sub1_bf16.hip: bf16 operands, fp32 accumulation / epilogue; h is rounded to bf16 once, bitwise as in the pair). */
 int sininn_conv_sub1_fwd_supported(const sininn_conv_args* first, const sininn_conv_args* second);
 int sininn_conv_sub1_fwd(const sininn_conv_args* first, const sininn_conv_args* second, void* stream);
 
@@ -202,7 +204,8 @@ int sininn_conv_sub1_fwd(const sininn_conv_args* first, const sininn_conv_args* 
  * w = data-gradient pack of conv1, Np = pad16(Cin of conv1), the epilogue fields); d2->mask / d2->out / d1->in are ignored.
  * Shapes served: (Cin of conv1, 2 Co) in {(8, 16), (16, 32), (24, 48)} -- sininn_conv_sub1_bwd_workspace_bytes returns 0 for any
  * other.  dx / the fused coupling backward are bitwise what sininn_conv_pair_k1(d2, d1) produces from the stored h; the weight
- * gradients agree with sininn_wgrad up to fp32 summation order.  no_dx != 0: the data gradient of conv1 is not needed. */
+ * gradients agree with sininn_wgrad up to fp32 summation order.  no_dx != 0: the data gradient of conv1 is not needed.
+ * Mixed precision: recompute / d2 / d1 with w_bf16 = 1 (bf16 packs; x, dr, dx and the gradients stay fp32) select the bf16 twin. */
 size_t sininn_conv_sub1_bwd_workspace_bytes(int cin, int co);
 int sininn_conv_sub1_bwd(const sininn_conv_args* recompute, const sininn_conv_args* d2, const sininn_conv_args* d1, int no_dx,
                          float* gw2, float* gb2, float* gw1, float* gb1, void* workspace, size_t workspace_bytes, void* stream);
