@@ -300,6 +300,8 @@ def class_roofline(precision, arch='SRF'):
     n = 12
     ms, fl, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_int * n)()
     _lib.check(_lib.lib().sininn_profile_classes_end(n, ms, fl, cnt))
+    by = (C.c_double * n)()
+    _lib.check(_lib.lib().sininn_profile_classes_bytes(n, by))
     out = []
     for i in range(n):
         if cnt[i] == 0:
@@ -319,6 +321,10 @@ def class_roofline(precision, arch='SRF'):
                 rec['note'] = 'Winograd: frac counts the EXECUTED MFMA FLOPs (2.25x fewer than the algorithmic direct-conv count)'
         else:
             rec['bound'] = 'hbm'
+        if by[i] > 0:      # the fused 1x1 launches report their algorithmic HBM bytes: the second roof of a class that sits at the ridge
+            gbs = by[i] / (ms[i] * 1e-3) / 1e9
+            rec['hbm'] = {'alg_bytes': by[i], 'achieved_gbs': gbs, 'peak_gbs': PEAK_HBM_GBS, 'frac': gbs / PEAK_HBM_GBS,
+                          'note': 'algorithmic bytes (x / dr / side inputs / outputs / stored hidden tensor / slabs) over the class time'}
         out.append(rec)
     return out
 
@@ -537,6 +543,8 @@ def main():
         classes = class_roofline(args.precision, args.arch)
         for c in classes:
             c['ms_per_step'] = c.pop('ms') / n_iso
+            if 'hbm' in c:
+                c['hbm']['alg_bytes_per_step'] = c['hbm'].pop('alg_bytes') / n_iso
             c['launches_per_step'] = c.pop('launches') // n_iso
         if flow_ev:
             # HBM rows of the warp (north_star's second fused kernel).  Algorithmic bytes per pixel (e = bytes of an image

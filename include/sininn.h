@@ -383,6 +383,9 @@ int sininn_wall_clock_khz(void);   /* tick rate of the stamps */
 #define SININN_PROFILE_CLASSES 12
 void sininn_profile_classes_begin(void);
 int sininn_profile_classes_end(int n, double* ms, double* flops, int* launches);
+/* algorithmic HBM bytes per class, summed over the launches of the last sininn_profile_classes_end (the fused 1x1 launches report
+ * them: x / dr / side inputs / outputs / slabs; 0 for a class whose launches do not) */
+int sininn_profile_classes_bytes(int n, double* bytes);
 
 size_t sininn_glow_saved_floats(int B, int H, int W, int C);
 size_t sininn_glow_saved_floats_dtype(int B, int H, int W, int C, int dtype);   /* dtype 1: bf16 hidden tensors (half the floats) */

@@ -139,6 +139,7 @@ _SIGS = {
     'sininn_profile_end': (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     'sininn_profile_classes_begin': (None, []),
     'sininn_profile_classes_end': (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    'sininn_profile_classes_bytes': (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     'sininn_glow_saved_floats': (C.c_size_t, [C.c_int] * 4),
     'sininn_glow_saved_floats_dtype': (C.c_size_t, [C.c_int] * 5),
     'sininn_glow_scratch_bytes': (C.c_size_t, [C.c_int] * 5),

@@ -99,6 +99,7 @@ int dense_forward(const sininn_dense_args* a, hipStream_t st);
 int dense_backward(const sininn_dense_args* a, hipStream_t st, hipStream_t wst);
 void profile_classes_begin();
 int profile_classes_end(int n, double* ms, double* flops, int* launches);
+int profile_classes_bytes(int n, double* bytes);
 void profile_begin(int h, unsigned long long* stamps, int max_launches);
 int profile_end(int* count, float* total_ms);
 int softsplat_fwd_launch(const float* in, const float* flow, int B, int C, int H, int W, float* out, hipStream_t st);
@@ -475,6 +476,7 @@ int sininn_pack_conv_weights_bf16(const float* w_oihw, const float* bias, int N,
 
 void sininn_profile_classes_begin(void) { profile_classes_begin(); }
 int sininn_profile_classes_end(int n, double* ms, double* flops, int* launches) { return profile_classes_end(n, ms, flops, launches); }
+int sininn_profile_classes_bytes(int n, double* bytes) { return profile_classes_bytes(n, bytes); }
 
 int sininn_glow_group_major_fits(int B, int H, int W) { return group_major_fits((size_t)B * H * W, W) ? 1 : 0; }
 int sininn_glow_hidden_gates(const sininn_glow_args* args, int which, uint8_t* gates, void* stream) {

@@ -137,7 +137,8 @@ static bool prof_pair(hipEvent_t* a, hipEvent_t* b, unsigned long long** stamp) 
 // with its class and its ALGORITHMIC FLOPs (direct-convolution count 2 M k^2 Cin N).  Meaningful on ONE stream only (the
 // bracket then is the kernel's own duration); bench.py runs a few single-stream steps after the timed region for it. ----
 enum { PC_CONV1 = 0, PC_COUPLE = 1, PC_DGRAD2 = 2, PC_DGRAD1 = 3, PC_WGRAD = 4, PC_CBWD = 5, PC_PER_K = 6, PC_N = 12 };
-struct ClassRec { hipEvent_t a, b; int cls; double flops; };
+struct ClassRec { hipEvent_t a, b; int cls; double flops; double bytes; };
+static double g_pc_bytes[PC_N] = {};        // algorithmic HBM bytes per class of the last profile_classes_end (1x1 launches report them)
 static bool g_pc_on = false;
 static std::vector<ClassRec> g_pc_recs;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pc_pool;
@@ -153,6 +154,7 @@ int profile_classes_end(int n, double* ms, double* flops, int* launches) {
   std::lock_guard<std::mutex> lock(g_ev_mutex);
   g_pc_on = false;
   for (int i = 0; i < n; ++i) { ms[i] = 0.0; flops[i] = 0.0; launches[i] = 0; }
+  for (int i = 0; i < PC_N; ++i) g_pc_bytes[i] = 0.0;
   for (auto& r : g_pc_recs) {
     float t = 0.f;
     if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) {
@@ -160,29 +162,38 @@ int profile_classes_end(int n, double* ms, double* flops, int* launches) {
       return 1;
     }
     if (r.cls < n) { ms[r.cls] += t; flops[r.cls] += r.flops; launches[r.cls] += 1; }
+    if (r.cls < PC_N) g_pc_bytes[r.cls] += r.bytes;
     g_pc_pool.push_back({r.a, r.b});
   }
   g_pc_recs.clear();
   return 0;
 }
 
+// algorithmic HBM bytes per class summed over the launches of the last profile_classes_end (0 where a launch did not report them)
+int profile_classes_bytes(int n, double* bytes) {
+  std::lock_guard<std::mutex> lock(g_ev_mutex);
+  for (int i = 0; i < n; ++i) bytes[i] = i < PC_N ? g_pc_bytes[i] : 0.0;
+  return 0;
+}
+
 // start bracket of one launch (nullptr when class profiling is off); class_scope_close records the end event
-hipEvent_t class_scope_open(int cls, int ksize, double flops, hipStream_t st) {
+hipEvent_t class_scope_open_b(int cls, int ksize, double flops, hipStream_t st, double bytes) {
   if (!g_pc_on) return nullptr;
   std::lock_guard<std::mutex> lock(g_ev_mutex);
   if (g_pc_recs.size() >= 60000) return nullptr;
   std::pair<hipEvent_t, hipEvent_t> p;
   if (!g_pc_pool.empty()) { p = g_pc_pool.back(); g_pc_pool.pop_back(); }
   else if (hipEventCreate(&p.first) != hipSuccess || hipEventCreate(&p.second) != hipSuccess) return nullptr;
-  g_pc_recs.push_back(ClassRec{p.first, p.second, cls + (ksize == 1 ? PC_PER_K : 0), flops});
+  g_pc_recs.push_back(ClassRec{p.first, p.second, cls + (ksize == 1 ? PC_PER_K : 0), flops, bytes});
   (void)hipEventRecord(p.first, st);
   return p.second;
 }
+hipEvent_t class_scope_open(int cls, int ksize, double flops, hipStream_t st) { return class_scope_open_b(cls, ksize, flops, st, 0.0); }   // dense_exec.cpp
 void class_scope_close(hipEvent_t end, hipStream_t st) { if (end) (void)hipEventRecord(end, st); }
 
 struct ClassScope {           // RAII bracket: records the start event now and the end event when it goes out of scope
   hipStream_t st; hipEvent_t b;
-  ClassScope(int cls, int ksize, double flops, hipStream_t s) : st(s), b(class_scope_open(cls, ksize, flops, s)) {}
+  ClassScope(int cls, int ksize, double flops, hipStream_t s, double bytes = 0.0) : st(s), b(class_scope_open_b(cls, ksize, flops, s, bytes)) {}
   ~ClassScope() { class_scope_close(b, st); }
 };
 static inline double conv_flops(size_t M, int k, int cin, int n) { return 2.0 * (double)M * k * k * cin * n; }
@@ -444,15 +455,18 @@ int glow_forward(const sininn_glow_args* a, hipStream_t st) {
     }
     // 1x1 subnets (fp32): both convs in one launch, the hidden tile stays in LDS between them (conv_pair_k1.hip)
     const bool recompute = fused_sub1(a, c1.Cin, h.co);      // the backward recomputes h from this half's input
+    // algorithmic HBM bytes of a fused 1x1 forward: x, v in; y (+ its compact copy for the first half), s out; + the hidden tensor when stored
+    const double fwd_bytes = 4.0 * (double)M * (c1.Cin + 2 * h.co + (a->no_save ? 0 : h.co) + (i == 0 ? h.co : 0)) +
+                             ((a->no_save || recompute) ? 0.0 : (double)M * SININN_HIDDEN * (bf16 ? 2 : 4));
     if (recompute && conv_sub1_fwd_supported(&c1, &c2)) {
       // ... and the forward is the persistent twin of that kernel: conv1 -> conv2 -> coupling + log-det, weights resident on chip
-      ClassScope sc(PC_COUPLE, a->ksize, conv_flops(M, a->ksize, c1.Cin, SININN_HIDDEN) + conv_flops(M, a->ksize, SININN_HIDDEN, 2 * h.co), st);
+      ClassScope sc(PC_COUPLE, a->ksize, conv_flops(M, a->ksize, c1.Cin, SININN_HIDDEN) + conv_flops(M, a->ksize, SININN_HIDDEN, 2 * h.co), st, fwd_bytes);
       if (int rc = conv_sub1_fwd_launch(&c1, &c2, st)) return rc;
       continue;
     }
     if (conv_pair_k1_supported(&c1, &c2) && (a->no_save || recompute || conv_pair_k1_preferred(&c1))) {
       if (a->no_save || recompute) c1.out = nullptr; // ... and then the hidden tensor never reaches HBM
-      ClassScope sc(PC_COUPLE, a->ksize, conv_flops(M, a->ksize, c1.Cin, SININN_HIDDEN) + conv_flops(M, a->ksize, SININN_HIDDEN, 2 * h.co), st);
+      ClassScope sc(PC_COUPLE, a->ksize, conv_flops(M, a->ksize, c1.Cin, SININN_HIDDEN) + conv_flops(M, a->ksize, SININN_HIDDEN, 2 * h.co), st, fwd_bytes);
       if (int rc = conv_pair_k1_launch(&c1, &c2, st)) return rc;
       continue;
     }
@@ -536,7 +550,8 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
     if (net->gw2 && !fused && wide_wg2) {
       // wide 1x1 subnet, mixed precision: dW2 += dr^T h as its own persistent kernel (h read straight into MFMA operand registers)
       if (int rc = order_after(wst, st)) return rc;
-      ClassScope scp(PC_WGRAD, k, conv_flops(M, k, SININN_HIDDEN, 2 * h.co), wst);
+      ClassScope scp(PC_WGRAD, k, conv_flops(M, k, SININN_HIDDEN, 2 * h.co), wst,
+                     4.0 * (double)M * 2 * h.co + 2.0 * (double)M * SININN_HIDDEN + 2.0 * 256.0 * (2 * h.co + 1) * SININN_HIDDEN * 4.0);   // dr, bf16 h, slabs written + read
       if (int rc = conv_sub1_bf16_wide_wg2_launch(dr, 2 * h.co, hbuf, SININN_HIDDEN, B, H, W, sc.slab2[which_half], sc.slab2_bytes[which_half],
                                                   net->gw2, net->gb2, wst)) return rc;
     } else if (net->gw2 && !fused) {
@@ -583,12 +598,15 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
       const int which = (&h == &hv[0]) ? 0 : 1;
       int slabs = 0;
       {
-        ClassScope scp(PC_DGRAD2, k, 2.0 * (conv_flops(M, k, 2 * h.co, SININN_HIDDEN) + conv_flops(M, k, SININN_HIDDEN, cond_cin)), st);
+        // algorithmic bytes: dr, x in; the epilogue's side inputs and outputs (ADD: addend -> out; fused coupling backward: addend, v, s -> 3 outputs)
+        const double epi = (fuse ? 6.0 : 2.0) * cond_cin;
+        ClassScope scp(PC_DGRAD2, k, 2.0 * (conv_flops(M, k, 2 * h.co, SININN_HIDDEN) + conv_flops(M, k, SININN_HIDDEN, cond_cin)), st,
+                       4.0 * (double)M * (2 * h.co + cond_cin + (skip_d1 ? 0.0 : epi)));
         if (int rc_ = conv_sub1_bwd_launch(&rc, &d2, &d1, skip_d1 ? 1 : 0, sc.slab[which], sc.slab_bytes[which], &slabs, st)) return rc_;
       }
       if (net->gw1 || net->gw2) {
         if (int rc_ = order_after(wst, st)) return rc_;
-        ClassScope scp(PC_WGRAD, k, 0.0, wst);
+        ClassScope scp(PC_WGRAD, k, 0.0, wst, (double)slabs * ((double)2 * h.co * SININN_HIDDEN + (double)SININN_HIDDEN * (cond_cin + 8)) * 4.0);   // the slabs, read once
         if (int rc_ = conv_sub1_bwd_reduce(cond_cin, h.co, sc.slab[which], slabs, net->gw2, net->gb2, net->gw1, net->gb1, wst)) return rc_;
       }
       return 0;
@@ -604,11 +622,13 @@ int glow_backward(const sininn_glow_args* a, hipStream_t st, hipStream_t wst) {
           conv_sub1_bf16_wide_bwd_supported(&d2w, &d1)) {
         int slabs = 0;
         {
-          ClassScope scp(PC_DGRAD2, k, conv_flops(M, k, 2 * h.co, SININN_HIDDEN) + 2.0 * conv_flops(M, k, SININN_HIDDEN, cond_cin), st);
+          const double epi = (fuse ? 6.0 : 2.0) * cond_cin;
+          ClassScope scp(PC_DGRAD2, k, conv_flops(M, k, 2 * h.co, SININN_HIDDEN) + 2.0 * conv_flops(M, k, SININN_HIDDEN, cond_cin), st,
+                         4.0 * (double)M * (2 * h.co + cond_cin + epi) + 2.0 * (double)M * SININN_HIDDEN);      // dr, x, side inputs / outputs + the bf16 h (mask)
           if (int rc_ = conv_sub1_bf16_wide_bwd_wg1_launch(&d2w, &d1, cond, cond_stride, sc.slab[which], sc.slab_bytes[which], &slabs, st)) return rc_;
         }
         if (int rc_ = order_after(wst, st)) return rc_;
-        ClassScope scp(PC_WGRAD, k, 0.0, wst);
+        ClassScope scp(PC_WGRAD, k, 0.0, wst, (double)slabs * (cond_cin + 1) * SININN_HIDDEN * 4.0);
         return conv_sub1_bf16_wide_reduce(sc.slab[which], slabs, net->gw1, net->gb1, wst);
       }
     }
