@@ -20,6 +20,13 @@
 //            v_mfma_f32_16x16x32_bf16 with W1's data-gradient pack resident in LDS
 //   epilogue the quad epilogue of conv_sub1_bwd_kernel (ADD / ADD_CBWD_*, side inputs requested mid-tile)
 // One slab of partial gradients per block in the layout of conv_sub1.hip: sub1_reduce_kernel sums them.
+//
+// Kernels of this file (all persistent, 512 threads, one block per CU):
+//   conv_sub1b_fwd_kernel / conv_sub1b_bwd_kernel      level-0 shapes ((Cin, 2 Co) in {(8, 16), (16, 32), (24, 48)}), 64-pixel tiles:
+//                                                      forward without storing h; the whole backward (above)
+//   conv_sub1b_wide_fwd_kernel                         level 1 (96 -> 256 -> 192), 32-pixel tiles, conv2's pack resident in LDS
+//   conv_sub1b_wide_bwd_kernel (+ wide_reduce_kernel)  level 1: both data gradients (+ conv1's weight gradient, WG1)
+//   conv_sub1b_wide_wg2_kernel (+ wide_reduce2_kernel) level 1: conv2's weight gradient, h read from HBM into operand registers
 #include <cstdlib>
 #include "conv_bf16_types.h"
 #include "conv_sub1_types.h"
@@ -55,11 +62,6 @@ struct Sub1BShape {
   static constexpr size_t LDS = T_OFF + T_BYTES;
   static_assert(STAGE_BYTES % 16 == 0 && XT_BYTES % 16 == 0 && DT_BYTES % 16 == 0, "conv_sub1_bf16: image alignment");
 };
-
-__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
-  const bf16x2 p = {(__bf16)lo, (__bf16)hi};
-  return __builtin_bit_cast(unsigned, p);
-}
 
 // accumulator tile (32 x 32, column on the lane) -> the two 16-row operand fragments of a following MFMA that sums over the
 // tile's rows: element j of lane half h of fragment s is row 16 s + 8 (j >> 2) + 4 h + (j & 3)
