@@ -880,6 +880,24 @@ __device__ __forceinline__ unsigned pack_bf16_pair(float lo, float hi) {
 // holds 144 accumulator registers, so only its bf16 operand (the 256-channel hidden tensor / hidden gradient: the HBM
 // stream) is prefetched across the MFMA loop (16-32 VGPRs); the fp32 operand's loads (32-64 VGPRs) are issued after the
 // loop, not live across it -- prefetching both spilled 98 VGPRs.  1x1 problems (16 accumulators) prefetch both.
+// Diagnostic build variants of the bf16 weight gradient (tools/build_variant.sh ... "-DWGB_ABL=n"; timing only, results are wrong):
+// 1 no MFMA loop, 2 no transposing LDS stores, 4 no global loads, 8 no operand shifts / bias sums in the loop, 16 no barriers
+#ifndef WGB_ABL
+#define WGB_ABL 0
+#endif
+// staging item f of a thread -> (pixel-pair slot, channel group).  WGB_COALESCE: four consecutive lanes take four consecutive channel
+// groups of ONE pixel pair -- 64 contiguous bytes per pixel, whole sectors per wave instruction -- instead of 64 lanes taking one
+// 16-byte group of 64 different pixels (a quarter of every sector used; the ablation builds put 40 % of the kernel on its loads)
+#ifndef WGB_COALESCE
+#define WGB_COALESCE 1
+#endif
+#if WGB_COALESCE
+#define WGB_SLOT(f) (((f) >> 2) & 63)
+#define WGB_GROUP(f) ((((f) >> 8) << 2) | ((f) & 3))
+#else
+#define WGB_SLOT(f) ((f) & 63)
+#define WGB_GROUP(f) ((f) >> 6)
+#endif
 constexpr int WGB_PD = 128 * 2 + 16;                                  // bytes per dout row (channel n): 4-bank step
 constexpr int wgb_pi(int ks) { return (((8 + 2 * (ks / 2)) * 24 * 2 + 255) / 256) * 256 + 16; }   // bytes per in row (channel c)
 
@@ -926,6 +944,9 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradDev& p, const int spl
     b = tt / p.tiles_y; y0 = ty * TH; x0 = tx * 16;
   };
   auto load16 = [&](const float* base, size_t elem, bool is_bf16) -> wgb_u32x4 {
+#if (WGB_ABL & 4)
+    return (wgb_u32x4){(unsigned)elem, 0u, 0u, 0u};
+#endif
     return is_bf16 ? *reinterpret_cast<const wgb_u32x4*>(reinterpret_cast<const __bf16*>(base) + elem)
                    : *reinterpret_cast<const wgb_u32x4*>(base + elem);
   };
@@ -934,7 +955,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradDev& p, const int spl
 #pragma unroll
     for (int i = 0; i < D_ITEMS; ++i) {
       const int f = tid + 256 * i;
-      const int pp = f & 63, g = f >> 6;
+      const int pp = WGB_SLOT(f), g = WGB_GROUP(f);
       const int gy = y0 + (pp >> 3), gx = x0 + (pp & 7) * 2;
       const int n = n0 + g * (DOUT_BF16 ? 8 : 4);
       const bool rowok = gy < p.H && n < p.N;                        // N % 8 (bf16) / % 4 (fp32) == 0: host check
@@ -948,7 +969,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradDev& p, const int spl
 #pragma unroll
     for (int gi = 0; gi < I_GRPS; ++gi) {
       const int f = tid + 256 * gi;
-      const int g = f >> 6, l = f & 63;
+      const int g = WGB_GROUP(f), l = WGB_SLOT(f);
       const int c = c0 + g * (IN_BF16 ? 8 : 4);
 #pragma unroll
       for (int rnd = 0; rnd < I_RND; ++rnd) {
@@ -964,6 +985,10 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradDev& p, const int spl
   };
   // (pixel, pixel + 1) pairs of channel j of a group -> one dword; rows of the transposed tile are `pitch` bytes apart
   auto store_pairs = [&](unsigned char* dst, int pitch, const wgb_u32x4& v0, const wgb_u32x4& v1, bool is_bf16) {
+#if (WGB_ABL & 2)
+    asm volatile("" :: "v"(v0), "v"(v1), "v"(dst));
+    return;
+#endif
     if (is_bf16) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -980,7 +1005,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradDev& p, const int spl
 #pragma unroll
     for (int i = 0; i < D_ITEMS; ++i) {
       const int f = tid + 256 * i;
-      const int pp = f & 63, g = f >> 6;
+      const int pp = WGB_SLOT(f), g = WGB_GROUP(f);
       store_pairs(dT + (g * (DOUT_BF16 ? 8 : 4)) * PD + pp * 4, PD, d_reg[i][0], d_reg[i][1], DOUT_BF16);
     }
   };
@@ -988,7 +1013,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradDev& p, const int spl
 #pragma unroll
     for (int gi = 0; gi < I_GRPS; ++gi) {
       const int f = tid + 256 * gi;
-      const int g = f >> 6, l = f & 63;
+      const int g = WGB_GROUP(f), l = WGB_SLOT(f);
 #pragma unroll
       for (int rnd = 0; rnd < I_RND; ++rnd) {
         const int q = l + 64 * rnd;
@@ -1016,7 +1041,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradDev& p, const int spl
         v0[u] = zero4; v1[u] = zero4;
         if (i < D_ITEMS) {
           const int f = tid + 256 * i;
-          const int pp = f & 63, g = f >> 6;
+          const int pp = WGB_SLOT(f), g = WGB_GROUP(f);
           const int gy = y0 + (pp >> 3), gx = x0 + (pp & 7) * 2;
           const int n = n0 + g * (DOUT_BF16 ? 8 : 4);
           const bool rowok = gy < p.H && n < p.N;
@@ -1030,7 +1055,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradDev& p, const int spl
         const int i = i0 + u;
         if (i < D_ITEMS) {
           const int f = tid + 256 * i;
-          const int pp = f & 63, g = f >> 6;
+          const int pp = WGB_SLOT(f), g = WGB_GROUP(f);
           store_pairs(dT + (g * (DOUT_BF16 ? 8 : 4)) * PD + pp * 4, PD, v0[u], v1[u], DOUT_BF16);
         }
       }
@@ -1048,7 +1073,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradDev& p, const int spl
         if (it < I_ITEMS) {
           const int gi = it / I_RND, rnd = it - gi * I_RND;
           const int f = tid + 256 * gi;
-          const int g = f >> 6, q = (f & 63) + 64 * rnd;
+          const int g = WGB_GROUP(f), q = WGB_SLOT(f) + 64 * rnd;
           const int c = c0 + g * (IN_BF16 ? 8 : 4);
           if (q < IPAIRS) {
             const int row = q / (IWV / 2), pr = q - row * (IWV / 2);
@@ -1066,7 +1091,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradDev& p, const int spl
         if (it < I_ITEMS) {
           const int gi = it / I_RND, rnd = it - gi * I_RND;
           const int f = tid + 256 * gi;
-          const int g = f >> 6, q = (f & 63) + 64 * rnd;
+          const int g = WGB_GROUP(f), q = WGB_SLOT(f) + 64 * rnd;
           if (q < IPAIRS) {
             const int row = q / (IWV / 2), pr = q - row * (IWV / 2);
             store_pairs(iT + (g * (IN_BF16 ? 8 : 4)) * PI + row * (IROWP * 2) + pr * 4, PI, v0[u], v1[u], IN_BF16);
@@ -1081,10 +1106,14 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradDev& p, const int spl
     if constexpr (PF_I) load_i(t_begin);
   }
   for (int tile = t_begin; tile < t_end; ++tile) {
+#if !(WGB_ABL & 16)
     __syncthreads();                              // the previous tile's fragment reads are done
+#endif
     if constexpr (PF_D) store_d(); else stage_d_direct(tile);
     if constexpr (PF_I) store_i(); else stage_i_direct(tile);
+#if !(WGB_ABL & 16)
     __syncthreads();
+#endif
     if (tile + 1 < t_end) {                       // in flight under the MFMAs below
       if constexpr (PF_D) load_d(tile + 1);
       if constexpr (PF_I) load_i(tile + 1);
@@ -1093,8 +1122,9 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradDev& p, const int spl
     const unsigned char* arow = dT + (wr * 32 + r) * PD + h * 16;
     const unsigned char* brow = iT + (wc * 32 + r) * PI + h * 16;
 #pragma unroll 2
-    for (int y = 0; y < TH; ++y) {
+    for (int y = 0; y < ((WGB_ABL & 1) ? 0 : TH); ++y) {
       const wgb_bf16x8 af = *reinterpret_cast<const wgb_bf16x8*>(arow + y * 32);
+#if !(WGB_ABL & 8)
       {
         const __bf16* av = reinterpret_cast<const __bf16*>(&af);
         float sacc = 0.f;
@@ -1102,6 +1132,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradDev& p, const int spl
         for (int j = 0; j < 8; ++j) sacc += (float)av[j];
         bsum += sacc;
       }
+#endif
 #pragma unroll
       for (int dy = 0; dy < KS; ++dy) {
         const wgb_u32x4 lo = *reinterpret_cast<const wgb_u32x4*>(brow + (y + dy) * (IROWP * 2));
@@ -1110,11 +1141,15 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradDev& p, const int spl
         } else {
           const wgb_u32x4 hi = *reinterpret_cast<const wgb_u32x4*>(brow + (y + dy) * (IROWP * 2) + 16);
           wgb_u32x4 s1, s2;
+#if (WGB_ABL & 8)
+          s1 = lo; s2 = hi;
+#else
           s1[0] = __builtin_amdgcn_alignbyte(lo[1], lo[0], 2);
           s1[1] = __builtin_amdgcn_alignbyte(lo[2], lo[1], 2);
           s1[2] = __builtin_amdgcn_alignbyte(lo[3], lo[2], 2);
           s1[3] = __builtin_amdgcn_alignbyte(hi[0], lo[3], 2);
           s2[0] = lo[1]; s2[1] = lo[2]; s2[2] = lo[3]; s2[3] = hi[0];
+#endif
           acc[dy * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, *reinterpret_cast<const wgb_bf16x8*>(&lo), acc[dy * 3 + 0], 0, 0, 0);
           acc[dy * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, *reinterpret_cast<const wgb_bf16x8*>(&s1), acc[dy * 3 + 1], 0, 0, 0);
           acc[dy * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, *reinterpret_cast<const wgb_bf16x8*>(&s2), acc[dy * 3 + 2], 0, 0, 0);
