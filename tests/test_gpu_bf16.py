@@ -555,3 +555,86 @@ def test_small_k_3x3_kernels_match_the_general_conv(rev, channels, hw):
     names = ['y', 'logdet', 'dx'] + [n for n, _ in blk.named_parameters()]
     for n, a, b in zip(names, *res):
         assert relerr(a, b) < 8e-3 and rel_l2(a, b) < 5e-4, (n, relerr(a, b), rel_l2(a, b))
+
+
+@pytest.mark.parametrize('b,hw,inverse', [(2, (19, 40), False), (1, (6, 18), True), (16, (64, 64), False)])
+def test_wide_1x1_bf16_kernels_through_the_pair_entry_point(b, hw, inverse):
+    """The level-1 kernels of conv_sub1_bf16.hip (96 -> 256 -> 192) behind sininn_conv_pair_k1, called directly: the persistent forward
+    (h stored and not stored, both coupling directions) and the persistent backward pair WITHOUT the weight-gradient rider (the
+    block executor always uses the rider; this is the instantiation a caller of the C ABI gets) against torch arithmetic on the
+    same bf16-rounded operands, float64 sums: budgets of test_fused_1x1_subnet_bf16_c_abi (2e-5 L2 / 2e-3 max-norm for tensors that
+    pass through a rounding to bf16, 1e-4 for the log-det); h and dh themselves: equal up to one bf16 ulp in a few places."""
+    import ctypes as C
+    import sin_inn_amd
+    from sin_inn_amd import _lib, ops
+    lib = _lib.lib()
+    dev = torch.device('cuda')
+    torch.manual_seed(b + hw[0])
+    h, w = hw
+    co, k1, k2, m = 96, 96, 192, b * h * w
+    bft = torch.bfloat16
+    x = torch.randn(m, k1, device=dev)
+    v = torch.randn(m, co, device=dev)
+    conv1 = torch.nn.Conv2d(k1, 256, 1).to(dev)
+    conv2 = torch.nn.Conv2d(256, k2, 1).to(dev)
+    with torch.no_grad():
+        conv2.weight.mul_(0.3)
+    pk1 = ops.pack_conv_bf16(conv1.weight.detach(), conv1.bias.detach(), None, True)
+    pk2 = ops.pack_conv_bf16(conv2.weight.detach(), conv2.bias.detach(), ops.coupling_colmap(co, dev), True)
+
+    def args(**kw):
+        a = _lib.ConvArgs()
+        for k, val in kw.items():
+            setattr(a, 'inp' if k == 'in_' else k, val)
+        return a
+    pb = lambda t: ops.ptr(t, dtype=bft)
+    common = dict(B=b, H=h, W=w, ksize=1, w_bf16=1)
+    close = lambda a_, b_: relerr(a_, b_) < 2e-3 and rel_l2(a_, b_) < 2e-5
+    # ---- reference ------------------------------------------------------------------------------------------------------------------
+    xb = bf(x).double()
+    w1, w2 = bf(conv1.weight.detach().reshape(256, k1)).double(), bf(conv2.weight.detach().reshape(k2, 256)).double()
+    hid32 = torch.relu(xb @ w1.t() + conv1.bias.detach().double()).float()
+    hid = bf(hid32).double()
+    st = hid @ w2.t() + conv2.bias.detach().double()
+    s_ref, t_ref = st[:, :co], st[:, co:]
+    L = 1.2 * 0.636 * torch.atan(s_ref / 1.2)
+    if not inverse:
+        y_ref, ld_ref = torch.exp(L) * v.double() + t_ref, L.reshape(b, -1).sum(1)
+    else:
+        y_ref, ld_ref = (v.double() - t_ref) / torch.exp(L), -L.reshape(b, -1).sum(1)
+    # ---- forward, h stored / not stored ------------------------------------------------------------------------------------------------
+    for store_h in (True, False):
+        out = torch.full((m, co), float('nan'), device=dev); sb = torch.empty(m, co, device=dev); ld = torch.zeros(b, device=dev)
+        hs = torch.full((m, 256), float('nan'), device=dev, dtype=bft)
+        f1 = args(in_=ops.ptr(x), in_stride=k1, Cin=k1, w=pb(pk1[0]), bias=ops.ptr(pk1[1]), Np=256, mode=_lib.CONV_RELU,
+                  out=pb(hs) if store_h else None, out_stride=256, N=256, out_bf16=1, **common)
+        f2 = args(in_=pb(hs), in_stride=256, Cin=256, w=pb(pk2[0]), bias=ops.ptr(pk2[1]), Np=k2,
+                  mode=_lib.CONV_COUPLE_INV if inverse else _lib.CONV_COUPLE_FWD, out=ops.ptr(out), out_stride=co, v=ops.ptr(v), v_stride=co,
+                  sbuf=ops.ptr(sb), logdet=ops.ptr(ld), Co=co, clamp=1.2, col_tile=ops.coupling_tile(co), in_bf16=1, **common)
+        assert lib.sininn_conv_pair_k1_supported(C.byref(f1), C.byref(f2)) == 1
+        _lib.check(lib.sininn_conv_pair_k1(C.byref(f1), C.byref(f2), ops._stream()))
+        torch.cuda.synchronize()
+        assert close(out, y_ref.float()) and close(sb, s_ref.float()) and relerr(ld, ld_ref.float()) < 1e-4
+        if store_h:
+            d = (hs.float() - hid.float()).abs()
+            assert float(d.max()) <= 2.0 ** -7 * float(hid.abs().max()) and float((d > 0).float().mean()) < 1e-3
+        else:
+            assert bool(torch.isnan(hs.float()).all())
+    # ---- backward pair: dh = (dr W2) . [h > 0] (stored), dx = dh W1 + addend --------------------------------------------------------------
+    dr = torch.randn(m, k2, device=dev)
+    addend = torch.randn(m, k1, device=dev)
+    hmask = bf(hid32).to(bft)                                       # the h the forward pass stores (reference rounding)
+    dh_ref = bf(((bf(dr).double() @ w2) * (hid > 0)).float()).double()
+    dx_ref = dh_ref @ w1 + addend.double()
+    dh = torch.full((m, 256), float('nan'), device=dev, dtype=bft)
+    dx = torch.full((m, k1), float('nan'), device=dev)
+    d2 = args(in_=ops.ptr(dr), in_stride=k2, Cin=k2, w=pb(pk2[2]), Np=256, mode=_lib.CONV_MASK, out=pb(dh), out_stride=256, N=256,
+              mask=pb(hmask), mask_stride=256, out_bf16=1, mask_bf16=1, **common)
+    d1 = args(in_=pb(dh), in_stride=256, Cin=256, w=pb(pk1[2]), Np=ops.pad16(k1), mode=_lib.CONV_ADD, out=ops.ptr(dx), out_stride=k1, N=k1,
+              addend=ops.ptr(addend), addend_stride=k1, in_bf16=1, **common)
+    assert lib.sininn_conv_pair_k1_supported(C.byref(d2), C.byref(d1)) == 1
+    _lib.check(lib.sininn_conv_pair_k1(C.byref(d2), C.byref(d1), ops._stream()))
+    torch.cuda.synchronize()
+    assert close(dx, dx_ref.float()), (relerr(dx, dx_ref.float()), rel_l2(dx, dx_ref.float()))
+    d = (dh.float() - dh_ref.float()).abs()
+    assert float(d.max()) <= 2.0 ** -7 * float(dh_ref.abs().max()) and float((d > 0).float().mean()) < 1e-3
