@@ -171,7 +171,10 @@ def test_bench_self_launches_its_ranks_cpu_rehearsal(n):
     day an 8-GPU node runs it (reference parallelism: main.py:112 Trainer(gpus=...))."""
     import json
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
-    for attempt in range(2):        # the launcher picks a free port and hands it to torchrun: a second try covers the rare race for it
+    for attempt in range(3):        # the launcher picks a free port and hands it to torchrun: further tries cover the rare race for it
+        if attempt:                 # (and a box that is busy with something else: 8 ranks import torch on 8 cores)
+            import time
+            time.sleep(2.0)
         out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--rehearse', '--steps', '3', '--config', '2'],
                              capture_output=True, text=True, env=env, timeout=600)
         if out.returncode == 0:
